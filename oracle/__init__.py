@@ -1,0 +1,22 @@
+"""oracle/ -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A CPU (PyTorch fp32, eager) restatement of the reference's algorithm for the h-Edit sampling
+hot path: scheduler algebra, the four h-Edit loops, DDPM inversion, the
+Prompt-to-Prompt controller / LocalBlend / attention processor, and the SD-1.x eps-network the
+loops call.  Every function cites the reference file:line it follows.
+
+Who may import this package: ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg -- as the checker / the timed CPU baseline only.  The product package
+(``h-edit_amd/hedit``) never imports it and fails loudly when its HIP library is missing.
+
+Pinning status
+  * loops, scheduler algebra, controller, LocalBlend, processor: PINNED against golden vectors
+    produced by running the reference's own modules (tests/golden/make_golden.py, committed
+    fixtures tests/golden/g1..g6).
+  * SD-1.x UNet arithmetic (oracle/sd_unet.py): the reference delegates it to the third-party
+    package diffusers==0.18.0 (text-guided/environment_p2p.yaml:88), which is absent from
+    /root/reference and from this image, and the reference holds no test or golden vector for
+    it => PARITY UNPINNED for the network body.  What is pinned: the attention op order (through
+    the reference's P2PCrossAttnProcessor, g6), and the parameter inventory (859.5 M params,
+    diffusers state_dict key names) -- see DESIGN.md §Oracle.
+"""

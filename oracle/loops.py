@@ -1,0 +1,204 @@
+"""h-Edit sampling loops + DDPM inversion (oracle; see oracle/__init__.py).
+
+Restates, against the same duck-typed ``model`` object the reference uses:
+  encode_text                   text-guided/inversion/inversion_utils.py:13-35
+  sample_xts / ddpm_inversion   text-guided/inversion/ddpm_inversion.py:5-52, 54-167
+  h_edit_r_explicit             text-guided/inversion/p2p_h_edit.py:21-156
+  h_edit_r_implicit             text-guided/inversion/p2p_h_edit.py:162-362
+  h_edit_p2p_explicit           text-guided/inversion/p2p_h_edit.py:380-523
+  h_edit_p2p_implicit           text-guided/inversion/p2p_h_edit.py:529-701
+The four loops share one skeleton here (``_loop``); the per-variant differences are the UNet
+batches and which eps feeds the three CFG mixes.
+"""
+import torch
+
+from . import sched as S
+
+
+def encode_text(model, prompts):
+    ids = model.tokenizer(prompts, padding="max_length",
+                          max_length=model.tokenizer.model_max_length, truncation=True,
+                          return_tensors="pt").input_ids
+    with torch.no_grad():
+        return model.text_encoder(ids.to(model.device))[0]
+
+
+# --------------------------------------------------------------------------- inversion
+def sample_xts(model, x0, T):
+    """x_t ~ q(x_t | x_0) independently for every step (ddpm_inversion.py:22-52).  Draws one
+    ``randn_like(x0)`` per timestep, walking the timesteps from small to large."""
+    sch = model.scheduler
+    ab = sch.alphas_cumprod
+    ts = sch.timesteps
+    pos = {int(v): k for k, v in enumerate(ts)}
+    c, s = model.unet.in_channels, model.unet.sample_size
+    xts = torch.zeros(T + 1, c, s, s)
+    noise = torch.zeros(T + 1, c, s, s)
+    xts[0] = x0
+    for t in reversed(ts):
+        i = T - pos[int(t)]
+        n = torch.randn_like(x0)
+        xts[i] = x0 * ab[t] ** 0.5 + n * (1 - ab[t]) ** 0.5
+        noise[i] = n
+    return xts, noise
+
+
+def ddpm_inversion(model, x0, eta=1.0, prompt="", cfg_src=1.0, T=50):
+    """Edit-friendly DDPM inversion: z_t such that the eta-chain reproduces the sampled x_t's
+    (ddpm_inversion.py:86-162).  Returns (zs[T], xts[T+1], noise)."""
+    sch = model.scheduler
+    ab = sch.alphas_cumprod
+    ts = sch.timesteps
+    unc = encode_text(model, "")
+    cond = encode_text(model, prompt) if prompt != "" else None
+    xts, noise = sample_xts(model, x0, T)
+    c, s = model.unet.in_channels, model.unet.sample_size
+    zs = torch.zeros(T, c, s, s)
+    pos = {int(v): k for k, v in enumerate(ts)}
+    for t in ts:
+        i = T - pos[int(t)] - 1
+        xt = xts[i + 1][None]
+        with torch.no_grad():
+            e = model.unet.forward(xt, timestep=t, encoder_hidden_states=unc).sample
+            if cond is not None:
+                ec = model.unet.forward(xt, timestep=t, encoder_hidden_states=cond).sample
+                e = e + cfg_src * (ec - e)
+        x0_hat = (xt - (1 - ab[t]) ** 0.5 * e) / ab[t] ** 0.5
+        a_p = S._abar_prev(sch, t)
+        var = S.get_variance(sch, t)
+        mu = a_p ** 0.5 * x0_hat + (1 - a_p - (eta ** 2) * var) ** 0.5 * e
+        z = (xts[i][None] - mu) / (eta * var ** 0.5)
+        zs[i] = z
+        xts[i] = mu + (eta * var ** 0.5) * z                      # re-anchor (:160-162)
+    return zs, xts, noise
+
+
+# --------------------------------------------------------------------------- loops
+def _prep(model, xT, prompts, cfg_scales, after_skip_steps):
+    sch = model.scheduler
+    assert len(prompts) >= 2, "only support prompt editing"
+    cfg = torch.Tensor(cfg_scales).view(-1, 1, 1, 1)
+    txt = encode_text(model, prompts)
+    unc = encode_text(model, [""] * len(prompts))
+    ts = sch.timesteps
+    xt = xT.unsqueeze(0) if xT.dim() < 4 else xT
+    xt = torch.cat([xt] * len(prompts))
+    op = list(ts[-after_skip_steps:])
+    return sch, cfg.chunk(3), txt, unc, xt, op
+
+
+def _rms(v):
+    return (v * v).mean().sqrt().item()
+
+
+def _l1_pull(x, anchor, corr, w):
+    """k>0 reconstruction pull (p2p_h_edit.py:670-684): x - rho * d|x-anchor|_1/dx with
+    rho = rms(corr)/(rms(grad)+1e-8) * w.  The L1 mean gradient is sign(x-anchor)/numel."""
+    xg = x.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        loss = torch.nn.functional.l1_loss(xg, anchor)
+        g = torch.autograd.grad(loss, xg)[0]
+    rho = _rms(corr) / (_rms(g) + 1e-8) * w
+    return x - rho * g
+
+
+def _loop(model, xT, eta, prompts, cfg_scales, zs, controller, after_skip_steps, ddim_inv,
+          p2p, implicit, K=1, w_rec=0.1):
+    sch, (w_src, w_hat, w_tar), txt, unc, xt, op = _prep(model, xT, prompts, cfg_scales,
+                                                          after_skip_steps)
+    T = sch.num_inference_steps
+    if not p2p:
+        assert not ddim_inv, "only support prompt editing and DDPM sampling"
+    off = {"use_controller": False}
+    pos = {int(v): k for k, v in enumerate(op)}
+
+    def unet(x, t, ctx, kw):
+        with torch.no_grad():
+            return model.unet(x, t, encoder_hidden_states=ctx, cross_attention_kwargs=kw).sample
+
+    def mixes(e_u_src, e_c_src, e_u_tar, e_c_tar):
+        e_hat = e_u_src + w_hat * (e_c_src - e_u_src)
+        e_tar = e_u_tar + w_tar * (e_c_tar - e_u_tar)
+        return e_tar - e_hat
+
+    ahead = sch.timesteps[-(after_skip_steps + 1)] if after_skip_steps != T else -1
+
+    for i, t in enumerate(op):
+        idx = T - pos[int(t)] - (T - after_skip_steps + 1)
+        z = zs[idx] if zs is not None else None
+        tt = op[i + 1] if i < len(op) - 1 else 0
+
+        # (R-implicit only) one extra correction of the start sample when steps were skipped
+        # (p2p_h_edit.py:239-267)
+        if (not p2p) and implicit and i == 0 and ahead != -1:
+            e = unet(torch.cat([xt[1:]] * 4), t, torch.cat([unc, txt]), off)
+            corr = mixes(e[0:1], e[2:3], e[1:2], e[3:4])
+            xt[1] = xt[1] + S.edit_coeff(sch, ahead, t, eta, ddim_inv) * corr[0]
+
+        # base pass: eps with the source prompt, CFG weight w_src  -> x_{t-1}^{orig}, x_{t-1}^{base}
+        if p2p:
+            e = unet(torch.cat([xt] * 2), t, torch.cat([unc[:1], unc[:1], txt[:1], txt[:1]]), off)
+        else:
+            e = unet(torch.cat([xt[1:]] * 2), t, torch.cat([unc[:1], txt[:1]]), off)
+        e_u, e_c = e.chunk(2)
+        prev = S.reverse_step(sch, e_u + w_src * (e_c - e_u), t, xt, eta=eta, z=z, ddim_inv=ddim_inv)
+        x_orig, x_base = prev.chunk(2)
+        coeff = S.edit_coeff(sch, t, tt, eta, ddim_inv)
+
+        if not implicit:
+            # correction evaluated at x_t (explicit form)
+            if p2p:
+                e_c_src = unet(xt[1:], t, txt[:1], off)
+                e = unet(torch.cat([xt] * 2), t, torch.cat([unc, txt]), {"save_attn": True})
+                corr = mixes(e[1:2], e_c_src, e[1:2], e[3:4])
+            else:
+                e = unet(torch.cat([xt[1:]] * 4), t, torch.cat([unc, txt]), off)
+                corr = mixes(e[0:1], e[2:3], e[1:2], e[3:4])
+            x_k = x_base + coeff * corr
+        else:
+            x_k = x_base.clone()
+            for k in range(K):
+                if p2p:
+                    save = not (k < K - 1 and K > 1)
+                    e_c_src = unet(x_k, tt, txt[:1], off)
+                    e = unet(torch.cat([x_orig, x_k] * 2), tt, torch.cat([unc, txt]),
+                             {"save_attn": save})
+                    corr = mixes(e[1:2], e_c_src, e[1:2], e[3:4])
+                else:
+                    e = unet(torch.cat([x_k] * 4), tt, torch.cat([unc, txt]), off)
+                    corr = mixes(e[0:1], e[2:3], e[1:2], e[3:4])
+                rec = _l1_pull(x_k, x_base, corr, w_rec) if k > 0 else x_k
+                x_k = rec + coeff * corr
+
+        xt = torch.cat([x_orig, x_k.detach()])
+        if controller is not None:
+            xt = controller.step_callback(xt)
+    return xt[1].unsqueeze(0), xt[0].unsqueeze(0)
+
+
+def h_edit_r_explicit(model, xT, eta=1.0, prompts="", cfg_scales=None, zs=None, controller=None,
+                      after_skip_steps=35, is_ddim_inversion=False):
+    return _loop(model, xT, eta, prompts, cfg_scales, zs, controller, after_skip_steps,
+                 is_ddim_inversion, p2p=False, implicit=False)
+
+
+def h_edit_r_implicit(model, xT, eta=1.0, prompts="", cfg_scales=None, zs=None, controller=None,
+                      weight_reconstruction=0.1, optimization_steps=1, after_skip_steps=35,
+                      is_ddim_inversion=False):
+    return _loop(model, xT, eta, prompts, cfg_scales, zs, controller, after_skip_steps,
+                 is_ddim_inversion, p2p=False, implicit=True, K=optimization_steps,
+                 w_rec=weight_reconstruction)
+
+
+def h_edit_p2p_explicit(model, xT, eta=1.0, prompts="", cfg_scales=None, zs=None, controller=None,
+                        is_ddim_inversion=True, after_skip_steps=35):
+    return _loop(model, xT, eta, prompts, cfg_scales, zs, controller, after_skip_steps,
+                 is_ddim_inversion, p2p=True, implicit=False)
+
+
+def h_edit_p2p_implicit(model, xT, eta=1.0, prompts="", cfg_scales=None, zs=None, controller=None,
+                        weight_reconstruction=0.075, optimization_steps=1, after_skip_steps=35,
+                        is_ddim_inversion=True):
+    return _loop(model, xT, eta, prompts, cfg_scales, zs, controller, after_skip_steps,
+                 is_ddim_inversion, p2p=True, implicit=True, K=optimization_steps,
+                 w_rec=weight_reconstruction)

@@ -1,0 +1,327 @@
+"""Tiny duck-typed stand-ins for the third-party objects the h-Edit loop talks to.
+
+The reference never touches diffusers/transformers internals on the hot path: it only needs a
+``model`` exposing ``.unet/.scheduler/.tokenizer/.text_encoder/.device``.
+These classes implement exactly that protocol at toy size with seeded weights so that
+
+  * ``tests/golden/make_golden.py`` can drive the REFERENCE's own loop / controller / processor
+    code (imported from /root/reference in the build container only), and
+  * the tests can drive ``oracle/`` on the identical model and compare with the committed vectors.
+
+Nothing here is product code and nothing here is copied from the reference.
+"""
+import math
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def hash_uniform(shape, seed):
+    """Exactly reproducible pseudo-random float32 in [0,1): a 64-bit integer mix of the flat
+    index (no libm, no torch RNG), so fixtures need not store their inputs."""
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        x = np.arange(n, dtype=np.uint64) + np.array([seed], dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    u = (x >> np.uint64(40)).astype(np.float32) / np.float32(1 << 24)
+    return torch.from_numpy(u.reshape(shape))
+
+
+def hash_normal(shape, seed):
+    """Sum of 4 uniforms, centred and scaled to unit variance (exactly reproducible)."""
+    u = sum(hash_uniform(shape, seed * 4 + i) for i in range(4))
+    return (u - 2.0) * np.float32(np.sqrt(3.0))
+
+
+def hash_probs(shape, seed, sharp=4.0):
+    """Row-stochastic test 'attention probabilities' (last dim sums to 1)."""
+    u = hash_uniform(shape, seed) ** sharp + 1e-4
+    return u / u.sum(-1, keepdim=True)
+
+
+# --------------------------------------------------------------------------- tokenizer
+class WordTokenizer:
+    """Whitespace word-level tokenizer with the CLIPTokenizer call surface the path uses
+    (reference call sites: text-guided/inversion/inversion_utils.py:25-31,
+    text-guided/p2p/ptp_utils.py:306, text-guided/p2p/seq_aligner.py:110-111)."""
+
+    bos_id, eos_id = 1, 2
+    model_max_length = 77
+
+    def __init__(self, split_long_words_at=None):
+        self.vocab = {}
+        self.inv = {}
+        # words longer than this are split into several tokens, so that the word->token
+        # bookkeeping of get_word_inds is exercised with multi-token words too
+        self.split_at = split_long_words_at
+
+    def _id(self, piece):
+        if piece not in self.vocab:
+            i = 3 + len(self.vocab)
+            self.vocab[piece] = i
+            self.inv[i] = piece
+        return self.vocab[piece]
+
+    def _pieces(self, word):
+        if self.split_at is None or len(word) <= self.split_at:
+            return [word]
+        return [word[i:i + self.split_at] for i in range(0, len(word), self.split_at)]
+
+    def encode(self, text):
+        ids = [self.bos_id]
+        for w in text.split(" "):
+            if w == "":
+                continue
+            ids.extend(self._id(p) for p in self._pieces(w))
+        ids.append(self.eos_id)
+        return ids
+
+    def decode(self, ids):
+        out = []
+        for i in ids:
+            i = int(i)
+            out.append({self.bos_id: "<s>", self.eos_id: "</s>"}.get(i, self.inv.get(i, "?")))
+        return "".join(out)
+
+    def __call__(self, prompts, padding="max_length", max_length=None, truncation=True,
+                 return_tensors="pt"):
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        max_length = max_length or self.model_max_length
+        rows = []
+        for p in prompts:
+            ids = self.encode(p)[:max_length]
+            ids = ids + [self.eos_id] * (max_length - len(ids))
+            rows.append(ids)
+        return types.SimpleNamespace(input_ids=torch.tensor(rows, dtype=torch.int64))
+
+
+class TinyTextEncoder(nn.Module):
+    """ids (n,77) -> ((n,77,dim),)  -- token + position embedding, one mixing layer."""
+
+    def __init__(self, dim=32, vocab=512, seed=11):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.tok = nn.Parameter(torch.randn(vocab, dim, generator=g))
+        self.pos = nn.Parameter(torch.randn(77, dim, generator=g) * 0.3)
+        self.mix = nn.Parameter(torch.randn(dim, dim, generator=g) / math.sqrt(dim))
+
+    def forward(self, ids):
+        h = self.tok[ids % self.tok.shape[0]] + self.pos[None]
+        h = h + torch.tanh(h @ self.mix)
+        return (h,)
+
+
+# --------------------------------------------------------------------------- attention module
+class TinyAttention(nn.Module):
+    """Exposes the attribute surface of diffusers' ``Attention`` that the P2P processor reads
+    (reference: text-guided/p2p/ptp_utils.py:67-120)."""
+
+    def __init__(self, dim, ctx_dim, heads, gen):
+        super().__init__()
+        self.heads = heads
+        self.scale = (dim // heads) ** -0.5
+        kd = ctx_dim if ctx_dim is not None else dim
+
+        def lin(i, o, bias):
+            l = nn.Linear(i, o, bias=bias)
+            with torch.no_grad():
+                l.weight.copy_(torch.randn(o, i, generator=gen) / math.sqrt(i))
+                if bias:
+                    l.bias.copy_(torch.randn(o, generator=gen) * 0.05)
+            return l
+
+        self.to_q = lin(dim, dim, False)
+        self.to_k = lin(kd, dim, False)
+        self.to_v = lin(kd, dim, False)
+        self.to_out = nn.ModuleList([lin(dim, dim, True), nn.Identity()])
+        self.spatial_norm = None
+        self.group_norm = None
+        self.norm_cross = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+        self.processor = None
+
+    def prepare_attention_mask(self, mask, seq_len, batch):
+        return mask
+
+    def head_to_batch_dim(self, t):
+        b, n, c = t.shape
+        h = self.heads
+        return t.reshape(b, n, h, c // h).permute(0, 2, 1, 3).reshape(b * h, n, c // h)
+
+    def batch_to_head_dim(self, t):
+        bh, n, d = t.shape
+        h = self.heads
+        return t.reshape(bh // h, h, n, d).permute(0, 2, 1, 3).reshape(bh // h, n, d * h)
+
+    def get_attention_scores(self, q, k, mask=None):
+        s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype),
+                          q, k.transpose(-1, -2), beta=0, alpha=self.scale)
+        return s.softmax(dim=-1)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, **kw):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states, **kw)
+
+
+class PlainProcessor:
+    """Default (no-controller) processor; accepts and ignores the P2P kwargs."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None,
+                 temb=None, use_controller=True, save_attn=True):
+        q = attn.to_q(hidden_states)
+        ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        k, v = attn.to_k(ctx), attn.to_v(ctx)
+        q, k, v = map(attn.head_to_batch_dim, (q, k, v))
+        p = attn.get_attention_scores(q, k)
+        o = attn.batch_to_head_dim(torch.bmm(p, v))
+        return attn.to_out[1](attn.to_out[0](o))
+
+
+class UNetOutput(dict):
+    @property
+    def sample(self):
+        return self["sample"]
+
+
+class TinyUNet(nn.Module):
+    """A toy eps-network with the call/registry surface of diffusers' UNet2DConditionModel
+    (SURVEY.md §8b): 4 down blocks + 3 up blocks at 16x16 tokens and one mid block at 8x8, each
+    block = conv mix + self-attention + cross-attention, so that LocalBlend finds its five
+    16x16 cross maps (reference: text-guided/p2p/ptp_classes.py:59-62)."""
+
+    def __init__(self, ch=16, ctx_dim=32, heads=2, size=16, seed=5):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.in_channels = 4
+        self.sample_size = size
+        self.ch = ch
+        self.conv_in = nn.Conv2d(4, ch, 3, padding=1)
+        self.conv_out = nn.Conv2d(ch, 4, 3, padding=1)
+        self.t_proj = nn.Linear(ch, ch)
+        self.names = ([f"down_blocks.{i}" for i in range(4)] + ["mid_block"] +
+                      [f"up_blocks.{i}" for i in range(3)])
+        self.mix = nn.ModuleDict()
+        self.attn = nn.ModuleDict()
+        for n in self.names:
+            key = n.replace(".", "_")
+            self.mix[key] = nn.Conv2d(ch, ch, 3, padding=1)
+            self.attn[key + "_attn1"] = TinyAttention(ch, None, heads, g)
+            self.attn[key + "_attn2"] = TinyAttention(ch, ctx_dim, heads, g)
+        with torch.no_grad():
+            for p in list(self.conv_in.parameters()) + list(self.conv_out.parameters()) + \
+                    list(self.t_proj.parameters()) + list(self.mix.parameters()):
+                fan = p[0].numel() if p.dim() > 1 else 1
+                p.copy_(torch.randn(p.shape, generator=g) * (0.8 / math.sqrt(fan) if p.dim() > 1 else 0.05))
+        self._procs = {}
+        self.set_attn_processor({k: PlainProcessor() for k in self._proc_names()})
+
+    def _proc_names(self):
+        out = []
+        for n in self.names:
+            out.append(f"{n}.attentions.0.transformer_blocks.0.attn1.processor")
+            out.append(f"{n}.attentions.0.transformer_blocks.0.attn2.processor")
+        return out
+
+    @property
+    def attn_processors(self):
+        return dict(self._procs)
+
+    def set_attn_processor(self, procs):
+        for name, p in procs.items():
+            self._procs[name] = p
+            blk = name.split(".attentions")[0].replace(".", "_")
+            which = "attn1" if ".attn1." in name else "attn2"
+            self.attn[f"{blk}_{which}"].processor = p
+
+    def _temb(self, t, b, dtype):
+        t = torch.as_tensor(t, dtype=torch.float32).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(b)
+        half = self.ch // 2
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+        a = t[:, None] * freqs[None]
+        return self.t_proj(torch.cat([a.sin(), a.cos()], dim=-1).to(dtype))
+
+    def forward(self, sample, timestep=None, encoder_hidden_states=None, cross_attention_kwargs=None):
+        kw = dict(cross_attention_kwargs or {})
+        b = sample.shape[0]
+        h = self.conv_in(sample) + self._temb(timestep, b, sample.dtype)[:, :, None, None]
+        for n in self.names:
+            key = n.replace(".", "_")
+            if n == "mid_block":
+                hh = F.avg_pool2d(h, 2)
+            else:
+                hh = h
+            hh = hh + torch.tanh(self.mix[key](hh))
+            bb, c, H, W = hh.shape
+            tok = hh.reshape(bb, c, H * W).transpose(1, 2)
+            tok = tok + self.attn[key + "_attn1"](tok, None, **kw)
+            tok = tok + self.attn[key + "_attn2"](tok, encoder_hidden_states, **kw)
+            hh = tok.transpose(1, 2).reshape(bb, c, H, W)
+            if n == "mid_block":
+                h = h + F.interpolate(hh, scale_factor=2.0, mode="nearest")
+            else:
+                h = hh
+        # bounded output keeps the sampler trajectories O(1) like a trained eps-network
+        return UNetOutput(sample=0.5 * torch.tanh(0.1 * self.conv_out(h)) + 0.25 * sample)
+
+    def zero_grad(self, *a, **k):
+        return None
+
+
+# --------------------------------------------------------------------------- scheduler / model
+def ddim_tables(num_inference_steps, num_train_timesteps=1000, beta_start=0.00085,
+                beta_end=0.012, steps_offset=1, set_alpha_to_one=False):
+    """The fields of diffusers' DDIMScheduler that the path reads (EXT):
+    scaled-linear betas, leading spacing."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
+                           dtype=torch.float32) ** 2
+    alphas = 1.0 - betas
+    ac = torch.cumprod(alphas, dim=0)
+    ratio = num_train_timesteps // num_inference_steps
+    ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + steps_offset
+    s = types.SimpleNamespace()
+    s.alphas = alphas
+    s.alphas_cumprod = ac
+    s.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else ac[0]
+    s.timesteps = torch.from_numpy(ts)
+    s.num_inference_steps = num_inference_steps
+    s.config = types.SimpleNamespace(num_train_timesteps=num_train_timesteps)
+    return s
+
+
+def make_tiny_model(num_inference_steps, ch=16, ctx_dim=32, heads=2, size=16, seed=5,
+                    split_long_words_at=6):
+    m = types.SimpleNamespace()
+    m.device = torch.device("cpu")
+    m.unet = TinyUNet(ch=ch, ctx_dim=ctx_dim, heads=heads, size=size, seed=seed).eval()
+    m.scheduler = ddim_tables(num_inference_steps)
+    m.tokenizer = WordTokenizer(split_long_words_at=split_long_words_at)
+    m.text_encoder = TinyTextEncoder(dim=ctx_dim).eval()
+    m.vae = None
+    for p in list(m.unet.parameters()) + list(m.text_encoder.parameters()):
+        p.requires_grad_(False)
+    return m
+
+
+PROMPT_PAIRS = [
+    # (source, target, blended_word or None, use_replace_controller)
+    ("a green lizard is sitting on a branch", "a brown lizard is sitting on a branch",
+     ("lizard", "lizard"), True),
+    ("an orange van with surfboards on top", "an orange van with flowers on top",
+     ("surfboards", "flowers"), True),
+    ("a round cake with orange frosting on a wooden plate",
+     "a square cake with orange frosting on a wooden plate", ("cake", "cake"), False),
+    ("a cat sitting next to a mirror", "a silver cat sculpture sitting next to a mirror",
+     ("cat", "cat"), False),
+    ("a photo of a house on a hill", "a watercolor painting of a house on a hill", None, False),
+    ("the dog runs", "the dog runs on a sunny beach", ("dog", "dog"), False),
+]
