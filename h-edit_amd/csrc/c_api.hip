@@ -1,0 +1,125 @@
+// C-ABI glue: error reporting, sampler-step entry points and the single-kernel entry points the
+// parity tests call (see include/hedit.h).
+#include "../../include/hedit.h"
+#include "common.h"
+#include "kernels.h"
+
+static thread_local std::string g_last_error;
+void hedit_set_error(const std::string& msg) { g_last_error = msg; }
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline StepCoef to_coef(const hedit_step_coef* c) {
+  StepCoef k;
+  k.sqrt_ab_t = c->sqrt_ab_t; k.sqrt_1m_ab_t = c->sqrt_1m_ab_t; k.sqrt_ab_prev = c->sqrt_ab_prev;
+  k.dir_coef = c->dir_coef; k.noise_coef = c->noise_coef;
+  k.w_src = c->w_src; k.w_hat = c->w_hat; k.w_tar = c->w_tar; k.coeff = c->coeff; k.w_rec = c->w_rec;
+  return k;
+}
+
+extern "C" {
+
+const char* hedit_last_error(void) { return g_last_error.c_str(); }
+int hedit_version(void) { return 1; }
+
+int hedit_step_base(const float* eps, const float* xt, const float* z, float* x_prev, int n_img, int elems,
+                    int eps_rows_per_img, const hedit_step_coef* c, void* stream) {
+  ARG_CHECK(eps && xt && x_prev && c && n_img > 0 && elems > 0, "step_base args");
+  return step_base_launch(eps, xt, z, x_prev, n_img, elems, eps_rows_per_img, to_coef(c), S(stream));
+}
+
+int hedit_step_update(const float* e_u_src, const float* e_c_src, const float* e_u_tar, const float* e_c_tar,
+                      int64_t stride_img, const float* x_k, const float* x_base, float* x_out, int n_img,
+                      int elems, int k_gt0, const hedit_step_coef* c, void* stream) {
+  ARG_CHECK(e_u_src && e_c_src && e_u_tar && e_c_tar && x_k && x_base && x_out && c, "step_update args");
+  return step_update_launch(e_u_src, e_c_src, e_u_tar, e_c_tar, (long)stride_img, x_k, x_base, x_out, n_img,
+                            elems, k_gt0, to_coef(c), S(stream));
+}
+
+int hedit_local_blend(float* const* h_maps, int n_maps, int heads, const float* alpha_layers,
+                      const int32_t* enabled, float* xt, int n_img, int C, int H, int W, float th, void* stream) {
+  ARG_CHECK(h_maps && alpha_layers && xt, "local_blend args");
+  return local_blend_launch(const_cast<const float* const*>(h_maps), n_maps, heads, alpha_layers, enabled, xt, n_img, C, H, W, th, S(stream));
+}
+
+size_t hedit_k_gemm_ws_bytes(int M, int N, int K, int splits) {
+  const int s = gemm_pick_splits(M, N, K, splits);
+  return gemm_partial_bytes(M, N, s);
+}
+
+int hedit_k_gemm(const void* A, const void* W, const float* bias, const void* residual, void* C, int M, int N,
+                 int K, int lda, int ldc, int ldr, int mode, int Hin, int Win, int Cin, int Hout, int Wout,
+                 int splits, void* partial_ws, void* stream) {
+  ARG_CHECK(A && W && C, "gemm args");
+  GemmParams p{};
+  p.A = reinterpret_cast<const bf16_t*>(A);
+  p.W = reinterpret_cast<const bf16_t*>(W);
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.mode = mode;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout;
+  p.bias = bias;
+  p.residual = reinterpret_cast<const bf16_t*>(residual);
+  p.ldr = ldr;
+  p.C = reinterpret_cast<bf16_t*>(C);
+  p.ldc = ldc;
+  const int s = gemm_pick_splits(M, N, K, splits);
+  return gemm_launch(p, s, reinterpret_cast<float*>(partial_ws), S(stream));
+}
+
+size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C) { return groupnorm_ws_bytes(B, HW, C); }
+
+int hedit_k_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G,
+                      float eps, int silu, void* ws, void* stream) {
+  ARG_CHECK(x && y && gamma && beta && ws, "groupnorm args");
+  return groupnorm_launch(reinterpret_cast<const bf16_t*>(x), reinterpret_cast<bf16_t*>(y), gamma, beta, B, HW, C, G,
+                          eps, silu, reinterpret_cast<float*>(ws), S(stream));
+}
+
+int hedit_k_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int C, float eps,
+                      void* stream) {
+  ARG_CHECK(x && y && gamma && beta, "layernorm args");
+  return layernorm_launch(reinterpret_cast<const bf16_t*>(x), reinterpret_cast<bf16_t*>(y), gamma, beta, (long)rows, C, eps, S(stream));
+}
+
+int hedit_k_geglu(const void* x, void* y, int64_t rows, int inner, void* stream) {
+  ARG_CHECK(x && y, "geglu args");
+  return geglu_launch(reinterpret_cast<const bf16_t*>(x), reinterpret_cast<bf16_t*>(y), (long)rows, inner, S(stream));
+}
+
+int hedit_k_self_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int64_t ldvt, void* out, int ldo,
+                      int B, int N, int heads, int d, const int32_t* qk_src, void* stream) {
+  ARG_CHECK(q && k && vt && out, "self_attn args");
+  SelfAttnParams p{};
+  p.q = reinterpret_cast<const bf16_t*>(q); p.ldq = ldq;
+  p.k = reinterpret_cast<const bf16_t*>(k); p.ldk = ldk;
+  p.vt = reinterpret_cast<const bf16_t*>(vt); p.ldvt = (long)ldvt;
+  p.out = reinterpret_cast<bf16_t*>(out); p.ldo = ldo;
+  p.B = B; p.N = N; p.heads = heads; p.d = d; p.qk_src = qk_src;
+  return self_attn_launch(p, S(stream));
+}
+
+int hedit_k_cross_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int64_t ldvt, void* out, int ldo,
+                       int B, int N, int heads, int d, const hedit_p2p_plan* plan, float* store, void* stream) {
+  ARG_CHECK(q && k && vt && out && plan, "cross_attn args");
+  CrossAttnParams p{};
+  p.q = reinterpret_cast<const bf16_t*>(q); p.ldq = ldq;
+  p.k = reinterpret_cast<const bf16_t*>(k); p.ldk = ldk;
+  p.vt = reinterpret_cast<const bf16_t*>(vt); p.ldvt = (long)ldvt;
+  p.out = reinterpret_cast<bf16_t*>(out); p.ldo = ldo;
+  p.B = B; p.N = N; p.heads = heads; p.d = d;
+  p.n_pairs = plan->n_pairs; p.pair_src = plan->pair_src; p.pair_tar = plan->pair_tar;
+  p.mixT = reinterpret_cast<const bf16_t*>(plan->mixT); p.bvec = plan->bvec;
+  p.singles = plan->singles; p.n_single = plan->n_single;
+  p.store = store;
+  return cross_attn_launch(p, S(stream));
+}
+
+int hedit_k_pack_conv3x3(const float* w, void* out, int O, int I, void* stream) {
+  ARG_CHECK(w && out, "pack args");
+  return pack_conv3x3_launch(w, reinterpret_cast<bf16_t*>(out), O, I, S(stream));
+}
+
+int hedit_k_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+  ARG_CHECK(x && y, "cast args");
+  return f32_to_bf16_launch(x, reinterpret_cast<bf16_t*>(y), (long)n, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// Shared device/host helpers for the h-Edit HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define WAVE 64
+
+// ---- error plumbing: thread-local message, negative return codes, never throws across the ABI
+void hedit_set_error(const std::string& msg);
+#define HEDIT_OK 0
+#define HEDIT_ERR_ARG (-1)
+#define HEDIT_ERR_HIP (-2)
+#define HEDIT_ERR_STATE (-3)
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      hedit_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                     \
+      return HEDIT_ERR_HIP;                                                                   \
+    }                                                                                         \
+  } while (0)
+
+#define ARG_CHECK(cond, msg)                                                                  \
+  do {                                                                                        \
+    if (!(cond)) {                                                                            \
+      hedit_set_error(std::string("bad argument: ") + (msg) + " [" #cond "]");                \
+      return HEDIT_ERR_ARG;                                                                   \
+    }                                                                                         \
+  } while (0)
+
+#define LAUNCH_CHECK()                                                                        \
+  do {                                                                                        \
+    hipError_t _e = hipGetLastError();                                                        \
+    if (_e != hipSuccess) {                                                                   \
+      hedit_set_error(std::string("kernel launch failed: ") + hipGetErrorString(_e) + " at " + \
+                      __FILE__ + ":" + std::to_string(__LINE__));                             \
+      return HEDIT_ERR_HIP;                                                                   \
+    }                                                                                         \
+  } while (0)
+
+// ---- bf16 <-> f32 (round to nearest even), usable on host and device
+__host__ __device__ inline float bf16_to_f32(bf16_t h) {
+  union { uint32_t u; float f; } v;
+  v.u = ((uint32_t)h) << 16;
+  return v.f;
+}
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+  union { uint32_t u; float f; } v;
+  v.f = f;
+  uint32_t u = v.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ inline float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ inline float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

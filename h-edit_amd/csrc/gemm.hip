@@ -1,0 +1,333 @@
+// Implicit-GEMM on MFMA for every dense contraction of the SD UNet: linear / 1x1-conv layers and
+// 3x3 convolutions (stride 1, stride 2, and 3x3 on a 2x nearest-upsampled input) over NHWC bf16
+// activations.   C[M][N] = A[M][K] * W[N][K]^T (+bias[n]) (+residual[m][n]),  fp32 accumulate.
+//
+// gfx950 mapping
+//   * v_mfma_f32_16x16x32_bf16; the WEIGHT fragment is fed as the MFMA "A" operand and the
+//     activation fragment as "B", so a lane ends up holding 4 consecutive output channels n of
+//     one row m -> 8-byte bf16x4 / 16-byte f32x4 epilogue stores along the contiguous NHWC axis.
+//   * 256 threads = 4 waves (2 along m x 2 along n); block tile 128 x BN x 64 with BN = 128 or
+//     160 (every SD-1.x channel count is a multiple of 160, so no n-tile is wasted).
+//   * operands staged global -> VGPR -> LDS (the conv gather needs per-lane addresses and zero
+//     fill at the image border), double-buffered: the next K-tile's global loads are issued
+//     before the MFMAs of the current one and written to the other LDS buffer afterwards, one
+//     barrier per K-tile.
+//   * LDS rows are 64 bf16 = 8 chunks of 16 B, chunk index XOR (row & 7): ds_read_b128 fragment
+//     reads and ds_write_b128 staging writes are both bank-conflict free.
+//   * split-K (grid.y) for the low-resolution, weight-heavy layers: fp32 partial slabs + a
+//     reduce/epilogue kernel.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+
+template <int BN>
+struct Smem {
+  static constexpr int A_BYTES = BM * BK * 2;
+  static constexpr int W_BYTES = BN * BK * 2;
+  static constexpr int STAGE = A_BYTES + W_BYTES;
+  static constexpr int TOTAL = 2 * STAGE;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <int BN, int MODE>
+__global__ __launch_bounds__(256) void igemm_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NI = BN / 32;      // 16-wide n sub-tiles per wave
+  constexpr int MI = 4;            // 16-wide m sub-tiles per wave
+  constexpr int A_CH = BM * 8 / 256;
+  constexpr int W_CH = BN * 8 / 256;
+  using S = Smem<BN>;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tile_m = blockIdx.x % tiles_m;
+  const int tile_n = blockIdx.x / tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int split = blockIdx.y;
+  const int kt_begin = split * p.kt_per_split;
+  int kt_end = kt_begin + p.kt_per_split;
+  const int kt_total = p.K / BK;
+  if (kt_end > kt_total) kt_end = kt_total;
+
+  // ---- per-thread staging coordinates (fixed for the whole K loop)
+  long a_base[A_CH];   // linear: row*lda ; conv: b*Hin*Win (pixel index base)
+  int a_oy[A_CH], a_ox[A_CH];
+  bool a_ok[A_CH];
+  int a_lds[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    int id = tid + i * 256;
+    int row = id >> 3, c = id & 7;
+    int m = m0 + row;
+    a_ok[i] = m < p.M;
+    a_lds[i] = swz(row, c);
+    if (MODE == 0) {
+      a_base[i] = (long)m * p.lda + c * 8;
+      a_oy[i] = a_ox[i] = 0;
+    } else {
+      int hw = p.Hout * p.Wout;
+      int b = m / hw;
+      int r = m - b * hw;
+      int oy = r / p.Wout;
+      int ox = r - oy * p.Wout;
+      a_base[i] = (long)b * p.Hin * p.Win;
+      a_oy[i] = oy;
+      a_ox[i] = ox;
+    }
+  }
+  long w_base[W_CH];
+  bool w_ok[W_CH];
+  int w_lds[W_CH];
+#pragma unroll
+  for (int i = 0; i < W_CH; ++i) {
+    int id = tid + i * 256;
+    int row = id >> 3, c = id & 7;
+    int n = n0 + row;
+    w_ok[i] = n < p.N;
+    w_lds[i] = swz(row, c);
+    w_base[i] = (long)n * p.K + c * 8;
+  }
+
+  uint4 a_reg[A_CH], w_reg[W_CH];
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (a_ok[i]) v = *reinterpret_cast<const uint4*>(p.A + a_base[i] + k0);
+        a_reg[i] = v;
+      }
+    } else {
+      const int tap = k0 / p.Cin;
+      const int ci0 = k0 - tap * p.Cin;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        int c = (tid + i * 256) & 7;
+        int iy, ix;
+        bool ok = a_ok[i];
+        if (MODE == 1) {
+          iy = a_oy[i] + dy; ix = a_ox[i] + dx;
+          ok = ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        } else if (MODE == 2) {
+          iy = a_oy[i] * 2 + dy; ix = a_ox[i] * 2 + dx;
+          ok = ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        } else {
+          int uy = a_oy[i] + dy, ux = a_ox[i] + dx;
+          ok = ok && (unsigned)uy < (unsigned)(2 * p.Hin) && (unsigned)ux < (unsigned)(2 * p.Win);
+          iy = uy >> 1; ix = ux >> 1;
+        }
+        long off = (a_base[i] + (long)iy * p.Win + ix) * p.Cin + ci0 + c * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ok) v = *reinterpret_cast<const uint4*>(p.A + off);
+        a_reg[i] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (w_ok[i]) v = *reinterpret_cast<const uint4*>(p.W + w_base[i] + k0);
+      w_reg[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* sa = smem + buf * S::STAGE;
+    char* sw = sa + S::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) *reinterpret_cast<uint4*>(sa + a_lds[i]) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i) *reinterpret_cast<uint4*>(sw + w_lds[i]) = w_reg[i];
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15;   // fragment row within a 16-row sub-tile
+  const int fq = lane >> 4;   // k-group (8 bf16 each) within a 32-deep MFMA step
+
+  if (kt_begin < kt_end) {
+    load_tile(kt_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    if (more) load_tile(kt + 1);
+    const char* sa = smem + buf * S::STAGE;
+    const char* sw = sa + S::A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 xf[MI], wf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        int row = wm * 64 + i * 16 + fr;
+        xf[i] = *reinterpret_cast<const bf16x8*>(sa + swz(row, ks * 4 + fq));
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        int row = wn * (BN / 2) + j * 16 + fr;
+        wf[j] = *reinterpret_cast<const bf16x8*>(sw + swz(row, ks * 4 + fq));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds rows n = nb + fq*4 + {0..3} of column m = mb + fr
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 16 + fq * 4;
+      if (n >= p.N) continue;   // N is a multiple of 4
+      f32x4 v = acc[i][j];
+      if (p.partial) {
+        float* dst = p.partial + ((long)split * p.M + m) * p.N + n;
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+        if (p.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+          v += b;
+        }
+        if (p.residual) {
+          const uint2 r = *reinterpret_cast<const uint2*>(p.residual + (long)m * p.ldr + n);
+          v[0] += bf16_to_f32((bf16_t)(r.x & 0xffff));
+          v[1] += bf16_to_f32((bf16_t)(r.x >> 16));
+          v[2] += bf16_to_f32((bf16_t)(r.y & 0xffff));
+          v[3] += bf16_to_f32((bf16_t)(r.y >> 16));
+        }
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(p.C + (long)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+// sum the split-K slabs and apply the epilogue; one thread per 4 consecutive n
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = p.N / 4;
+  const long total = (long)p.M * n4;
+  if (idx >= total) return;
+  const int m = (int)(idx / n4);
+  const int n = (int)(idx - (long)m * n4) * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.splits; ++s)
+    v += *reinterpret_cast<const f32x4*>(p.partial + ((long)s * p.M + m) * p.N + n);
+  if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+  if (p.residual) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p.residual + (long)m * p.ldr + n);
+    v[0] += bf16_to_f32((bf16_t)(r.x & 0xffff));
+    v[1] += bf16_to_f32((bf16_t)(r.x >> 16));
+    v[2] += bf16_to_f32((bf16_t)(r.y & 0xffff));
+    v[3] += bf16_to_f32((bf16_t)(r.y >> 16));
+  }
+  uint2 o;
+  o.x = pack_bf16x2(v[0], v[1]);
+  o.y = pack_bf16x2(v[2], v[3]);
+  *reinterpret_cast<uint2*>(p.C + (long)m * p.ldc + n) = o;
+}
+
+template <int BN, int MODE>
+int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
+  using S = Smem<BN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BN, MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, S::TOTAL));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), splits);
+  hipLaunchKernelGGL((igemm_kernel<BN, MODE>), grid, dim3(256), S::TOTAL, st, p);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+}  // namespace
+
+int gemm_pick_bn(int N) {
+  // smallest padded width wins; ties go to the wider tile
+  long w160 = (long)cdiv(N, 160) * 160, w128 = (long)cdiv(N, 128) * 128;
+  return w160 <= w128 ? 160 : 128;
+}
+
+int gemm_pick_splits(int M, int N, int K, int force) {
+  if (force > 0) return force;
+  const int bn = gemm_pick_bn(N);
+  const long tiles = (long)cdiv(M, BM) * cdiv(N, bn);
+  const int kt = K / BK;
+  if (tiles >= 192 || kt < 8) return 1;
+  int s = (int)((512 + tiles - 1) / tiles);     // aim at ~2 blocks per CU
+  int max_s = kt / 4;                            // keep >= 4 K-tiles per split
+  if (s > max_s) s = max_s;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : s;
+}
+
+size_t gemm_partial_bytes(int M, int N, int splits) {
+  return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+
+int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
+  ARG_CHECK(p.K % BK == 0, "gemm: K must be a multiple of 64");
+  ARG_CHECK(p.N % 4 == 0, "gemm: N must be a multiple of 4");
+  ARG_CHECK(p.mode >= 0 && p.mode <= 3, "gemm: mode");
+  if (p.mode != 0) ARG_CHECK(p.Cin % BK == 0 && p.K == 9 * p.Cin, "gemm: conv needs Cin % 64 == 0 and K = 9 Cin");
+  ARG_CHECK(p.ldc % 4 == 0 && (p.residual == nullptr || p.ldr % 4 == 0), "gemm: ldc/ldr alignment");
+  const int kt = p.K / BK;
+  if (splits < 1) splits = 1;
+  if (splits > kt) splits = kt;
+  p.splits = splits;
+  p.kt_per_split = cdiv(kt, splits);
+  p.splits = cdiv(kt, p.kt_per_split);
+  splits = p.splits;
+  if (splits > 1) {
+    ARG_CHECK(partial_ws != nullptr, "gemm: split-K needs a partial workspace");
+    p.partial = partial_ws;
+  } else {
+    p.partial = nullptr;
+  }
+  const int bn = gemm_pick_bn(p.N);
+  int rc;
+#define DISPATCH(BNV)                                                     \
+  switch (p.mode) {                                                       \
+    case 0: rc = launch_igemm<BNV, 0>(p, splits, st); break;              \
+    case 1: rc = launch_igemm<BNV, 1>(p, splits, st); break;              \
+    case 2: rc = launch_igemm<BNV, 2>(p, splits, st); break;              \
+    default: rc = launch_igemm<BNV, 3>(p, splits, st); break;             \
+  }
+  if (bn == 160) { DISPATCH(160) } else { DISPATCH(128) }
+#undef DISPATCH
+  if (rc != HEDIT_OK) return rc;
+  if (splits > 1) {
+    long total = (long)p.M * (p.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p);
+    LAUNCH_CHECK();
+  }
+  return HEDIT_OK;
+}

@@ -1,0 +1,101 @@
+// Internal launcher interface between the kernel files and the UNet executor / C-ABI.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------- gemm.hip
+struct GemmParams {
+  const bf16_t* A;   // mode 0: [M][lda]; conv modes: NHWC [B][Hin][Win][Cin]
+  const bf16_t* W;   // [N][K], K-contiguous (conv: k = (ky*3+kx)*Cin + ci)
+  int M, N, K;
+  int lda;
+  int mode;          // 0 linear/1x1, 1 conv3x3 s1 p1, 2 conv3x3 s2 p1, 3 conv3x3 p1 on 2x nearest upsample
+  int Hin, Win, Cin, Hout, Wout;
+  const float* bias;        // [N] or null
+  const bf16_t* residual;   // [M][ldr] or null
+  int ldr;
+  bf16_t* C;
+  int ldc;
+  float* partial;    // set by gemm_launch
+  int splits, kt_per_split;
+};
+int gemm_pick_bn(int N);
+int gemm_pick_splits(int M, int N, int K, int force);
+size_t gemm_partial_bytes(int M, int N, int splits);
+int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st);
+
+#define HEDIT_MAXW 77
+#define HEDIT_WPAD 96
+#define HEDIT_CTXP 80           // context rows per batch item in K / V^T buffers (77 + zero pad)
+
+// ---------------------------------------------------------------- norm.hip
+// GroupNorm over NHWC bf16 [B][HW][C] with G groups; deterministic two-stage statistics.
+size_t groupnorm_ws_bytes(int B, int HW, int C);
+int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B,
+                     int HW, int C, int G, float eps, int silu, float* ws, hipStream_t st);
+int layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, long rows,
+                     int C, float eps, hipStream_t st);
+int geglu_launch(const bf16_t* x, bf16_t* y, long rows, int inner, hipStream_t st);
+int concat_launch(const bf16_t* a, int ca, const bf16_t* b, int cb, bf16_t* y, long rows, hipStream_t st);
+int f32_to_bf16_launch(const float* x, bf16_t* y, long n, hipStream_t st);
+int ctx_pad_launch(const float* x, bf16_t* y, int B, int dim, hipStream_t st);
+// out[n] = sum_k W[n][k] * act(x[k]) + b0[n] + b1[n]   (act = SiLU if silu), x/out fp32, W bf16
+int gemv_launch(const bf16_t* W, const float* x, const float* b0, const float* b1, float* out,
+                int N, int K, int silu, hipStream_t st);
+int timestep_embed_launch(float t, float* out, int dim, hipStream_t st);
+// conv_in: x fp32 NCHW [B][Cin<=8][H][W], w fp32 [Cout][Cin][3][3] -> y NHWC bf16 [B][H][W][Cout]
+int conv_in_launch(const float* x, const float* w, const float* bias, bf16_t* y, int B, int Cin,
+                   int H, int W, int Cout, hipStream_t st);
+// conv_out: x NHWC bf16 [B][H][W][C], w bf16 [Cout<=4][9][C] -> y fp32 NCHW [B][Cout][H][W]
+int conv_out_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* y, int B, int H,
+                    int W, int C, int Cout, hipStream_t st);
+// weight packing (fp32 source tensors in torch layouts -> bf16 GEMM layouts), optional scale
+int pack_linear_launch(const float* w, bf16_t* out, long n, float scale, hipStream_t st);
+int pack_conv3x3_launch(const float* w_oihw, bf16_t* out, int O, int I, hipStream_t st);
+
+// ---------------------------------------------------------------- attn.hip
+struct SelfAttnParams {
+  const bf16_t* q; int ldq;     // [B*N][ldq], head h at column h*d ; pre-scaled by scale*log2(e)
+  const bf16_t* k; int ldk;     // [B*N][ldk]
+  const bf16_t* vt; long ldvt;  // V^T: [heads*d][B*N]  (row = h*d + dd, col = b*N + token)
+  bf16_t* out; int ldo;         // [B*N][ldo]
+  int B, N, heads, d;
+  const int* qk_src;            // [B] batch index whose q,k are used (P2P self-replace) or null
+};
+int self_attn_launch(const SelfAttnParams& p, hipStream_t st);
+
+struct CrossAttnParams {
+  const bf16_t* q; int ldq;     // [B*N][ldq] pre-scaled
+  const bf16_t* k; int ldk;     // [B*77][ldk]
+  const bf16_t* vt; long ldvt;  // [heads*d][B*77]
+  bf16_t* out; int ldo;
+  int B, N, heads, d;
+  // P2P: n_pairs (src,tar) pairs; items not in any pair are plain.  Tables per pair.
+  int n_pairs;
+  const int* pair_src;          // [n_pairs] batch index of the source-conditional row
+  const int* pair_tar;          // [n_pairs]
+  const bf16_t* mixT;           // [n_pairs][96][96]: mixT[n][w] = A[w][n]  (P_new = P_src A + bvec*P_tar)
+  const float* bvec;            // [n_pairs][96]
+  float* store;                 // [n_pairs][2][heads][N][77] fp32 accumulators or null
+  const int* singles;           // [n_single] batch rows that are not part of any pair
+  int n_single;
+};
+int cross_attn_launch(const CrossAttnParams& p, hipStream_t st);
+
+// ---------------------------------------------------------------- step.hip
+struct StepCoef {
+  float sqrt_ab_t, sqrt_1m_ab_t;     // of the current timestep t
+  float sqrt_ab_prev;                // sqrt(abar_prev)
+  float dir_coef;                    // sqrt(1-abar_prev - eta^2 var)  or sqrt(1-abar_prev) (ddim-inv)
+  float noise_coef;                  // eta*sqrt(var) or eta (ddim-inv); 0 when eta == 0
+  float w_src, w_hat, w_tar;         // CFG weights
+  float coeff;                       // edit coefficient of the correction term
+  float w_rec;                       // reconstruction weight (k > 0)
+};
+// base pass: eps [rows][n_img][elems], rows = [x_o|null, x_e|null, x_o|src, x_e|src] -> x_prev [2][n_img][elems]
+int step_base_launch(const float* eps, const float* xt, const float* z, float* x_prev, int n_img,
+                     int elems, int eps_rows_per_img, StepCoef c, hipStream_t st);
+int step_update_launch(const float* e_u_src, const float* e_c_src, const float* e_u_tar,
+                       const float* e_c_tar, long stride_img, const float* x_k, const float* x_base,
+                       float* x_out, int n_img, int elems, int k_gt0, StepCoef c, hipStream_t st);
+int local_blend_launch(const float* const* maps, int n_maps, int heads, const float* alpha_layers,
+                       const int* enabled, float* xt, int n_img, int C, int H, int W, float th, hipStream_t st);

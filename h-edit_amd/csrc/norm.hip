@@ -1,0 +1,472 @@
+// HBM-bound kernels around the GEMMs: GroupNorm(+SiLU), LayerNorm, GEGLU, concat, casts, the
+// time-embedding GEMV chain, conv_in / conv_out and weight packing.  NHWC bf16 activations, all
+// global accesses 16 B per lane along the contiguous channel axis, fp32 statistics.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = bf16_to_f32((bf16_t)(v.x & 0xffff)); f[1] = bf16_to_f32((bf16_t)(v.x >> 16));
+  f[2] = bf16_to_f32((bf16_t)(v.y & 0xffff)); f[3] = bf16_to_f32((bf16_t)(v.y >> 16));
+  f[4] = bf16_to_f32((bf16_t)(v.z & 0xffff)); f[5] = bf16_to_f32((bf16_t)(v.z >> 16));
+  f[6] = bf16_to_f32((bf16_t)(v.w & 0xffff)); f[7] = bf16_to_f32((bf16_t)(v.w >> 16));
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+  v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+  return v;
+}
+
+// ------------------------------------------------------------------ GroupNorm
+// stage 1: per (batch, pixel-slab) partial sums per group.  Threads are laid out as
+// (row r, channel-vector cv); a thread keeps the 8 channels of its cv in registers across the
+// rows of the slab, then the block folds rows and channels into the 32 group sums through LDS.
+constexpr int GN_MAXV = 2;   // channel vectors per thread when C/8 > 256 (C up to 4096)
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ part,
+                                                         int HW, int C, int G, int nslab) {
+  extern __shared__ float lds[];   // [R][C][2]
+  const int CV = C / 8;
+  const int slab = blockIdx.x, b = blockIdx.y;
+  const int pix_per = (HW + nslab - 1) / nslab;
+  const int p0 = slab * pix_per;
+  int p1 = p0 + pix_per;
+  if (p1 > HW) p1 = HW;
+  const int R = CV <= 256 ? 256 / CV : 1;
+  const int r = CV <= 256 ? threadIdx.x / CV : 0;
+  const int cv0 = CV <= 256 ? threadIdx.x % CV : threadIdx.x;
+  const bool active = r < R;
+  float s[GN_MAXV][8], q[GN_MAXV][8];
+#pragma unroll
+  for (int v = 0; v < GN_MAXV; ++v)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[v][j] = q[v][j] = 0.f;
+  if (active) {
+    const bf16_t* xb = x + (long)b * HW * C;
+    for (int p = p0 + r; p < p1; p += R) {
+#pragma unroll
+      for (int v = 0; v < GN_MAXV; ++v) {
+        int cv = cv0 + v * 256;
+        if (cv < CV && (v == 0 || CV > 256)) {
+          uint4 u = *reinterpret_cast<const uint4*>(xb + (long)p * C + cv * 8);
+          float f[8];
+          unpack8(u, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s[v][j] += f[j]; q[v][j] += f[j] * f[j]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < GN_MAXV; ++v) {
+      int cv = cv0 + v * 256;
+      if (cv < CV && (v == 0 || CV > 256)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          lds[((long)r * C + cv * 8 + j) * 2 + 0] = s[v][j];
+          lds[((long)r * C + cv * 8 + j) * 2 + 1] = q[v][j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    const int g = threadIdx.x, cpg = C / G;
+    float ss = 0.f, qq = 0.f;
+    for (int rr = 0; rr < R; ++rr)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        ss += lds[((long)rr * C + c) * 2 + 0];
+        qq += lds[((long)rr * C + c) * 2 + 1];
+      }
+    float* dst = part + (((long)b * nslab + slab) * G + g) * 2;
+    dst[0] = ss;
+    dst[1] = qq;
+  }
+}
+
+// stage 2: fold slabs -> mean / rstd per group, then per-channel scale & shift for this batch
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ ss,
+                                                          int HW, int C, int G, int nslab, float eps) {
+  __shared__ float mean[64], rstd[64];
+  const int b = blockIdx.x;
+  if ((int)threadIdx.x < G) {
+    const int g = threadIdx.x;
+    float s = 0.f, q = 0.f;
+    for (int sl = 0; sl < nslab; ++sl) {
+      const float* src = part + (((long)b * nslab + sl) * G + g) * 2;
+      s += src[0];
+      q += src[1];
+    }
+    const float n = (float)HW * (float)(C / G);
+    const float m = s / n;
+    float var = q / n - m * m;
+    var = var < 0.f ? 0.f : var;
+    mean[g] = m;
+    rstd[g] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    const float sc = rstd[g] * gamma[c];
+    ss[((long)b * C + c) * 2 + 0] = sc;
+    ss[((long)b * C + c) * 2 + 1] = beta[c] - mean[g] * sc;
+  }
+}
+
+// stage 3: y = x*scale + shift (+SiLU)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                       const float* __restrict__ ss, long total_v, int HW, int C, int silu) {
+  const int CV = C / 8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_v; i += (long)gridDim.x * 256) {
+    const long pix = i / CV;
+    const int cv = (int)(i - pix * CV);
+    const int b = (int)(pix / HW);
+    uint4 u = *reinterpret_cast<const uint4*>(x + i * 8);
+    float f[8];
+    unpack8(u, f);
+    const float4* t = reinterpret_cast<const float4*>(ss + ((long)b * C + cv * 8) * 2);
+    float4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+    f[0] = f[0] * t0.x + t0.y; f[1] = f[1] * t0.z + t0.w;
+    f[2] = f[2] * t1.x + t1.y; f[3] = f[3] * t1.z + t1.w;
+    f[4] = f[4] * t2.x + t2.y; f[5] = f[5] * t2.z + t2.w;
+    f[6] = f[6] * t3.x + t3.y; f[7] = f[7] * t3.z + t3.w;
+    if (silu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+    }
+    *reinterpret_cast<uint4*>(y + i * 8) = pack8(f);
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm: one wave per row
+constexpr int LN_MAXV = 5;   // C up to 2560
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int CV = C / 8;
+  float f[LN_MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < LN_MAXV; ++v) {
+    int cv = lane + v * 64;
+    if (cv < CV) {
+      uint4 u = *reinterpret_cast<const uint4*>(x + row * C + cv * 8);
+      unpack8(u, f[v]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += f[v][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int v = 0; v < LN_MAXV; ++v) {
+    int cv = lane + v * 64;
+    if (cv < CV) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float d = f[v][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int v = 0; v < LN_MAXV; ++v) {
+    int cv = lane + v * 64;
+    if (cv < CV) {
+      const float4* g4 = reinterpret_cast<const float4*>(gamma + cv * 8);
+      const float4* b4 = reinterpret_cast<const float4*>(beta + cv * 8);
+      float4 g0 = g4[0], g1 = g4[1], b0 = b4[0], b1 = b4[1];
+      float o[8];
+      o[0] = (f[v][0] - mean) * rstd * g0.x + b0.x; o[1] = (f[v][1] - mean) * rstd * g0.y + b0.y;
+      o[2] = (f[v][2] - mean) * rstd * g0.z + b0.z; o[3] = (f[v][3] - mean) * rstd * g0.w + b0.w;
+      o[4] = (f[v][4] - mean) * rstd * g1.x + b1.x; o[5] = (f[v][5] - mean) * rstd * g1.y + b1.y;
+      o[6] = (f[v][6] - mean) * rstd * g1.z + b1.z; o[7] = (f[v][7] - mean) * rstd * g1.w + b1.w;
+      *reinterpret_cast<uint4*>(y + row * C + cv * 8) = pack8(o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ GEGLU: y = h * gelu(g), x = [h | g]
+__global__ __launch_bounds__(256) void geglu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long rows, int inner) {
+  const int IV = inner / 8;
+  const long total = rows * IV;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / IV;
+    const int v = (int)(i - row * IV);
+    const bf16_t* src = x + row * (2L * inner) + v * 8;
+    uint4 uh = *reinterpret_cast<const uint4*>(src);
+    uint4 ug = *reinterpret_cast<const uint4*>(src + inner);
+    float h[8], g[8];
+    unpack8(uh, h);
+    unpack8(ug, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] *= gelu_erf_f(g[j]);
+    *reinterpret_cast<uint4*>(y + row * inner + v * 8) = pack8(h);
+  }
+}
+
+__global__ __launch_bounds__(256) void concat_kernel(const bf16_t* __restrict__ a, int ca, const bf16_t* __restrict__ b, int cb,
+                                                     bf16_t* __restrict__ y, long rows) {
+  const int CV = (ca + cb) / 8, AV = ca / 8;
+  const long total = rows * CV;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / CV;
+    const int v = (int)(i - row * CV);
+    uint4 u = v < AV ? *reinterpret_cast<const uint4*>(a + row * ca + v * 8)
+                     : *reinterpret_cast<const uint4*>(b + row * cb + (v - AV) * 8);
+    *reinterpret_cast<uint4*>(y + i * 8) = u;
+  }
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n, float scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    y[i] = f32_to_bf16(x[i] * scale);
+}
+
+// text context fp32 [B][77][dim] -> bf16 [B][80][dim], rows 77..79 zero (16-byte aligned V^T rows)
+__global__ __launch_bounds__(256) void ctx_pad_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int B, int dim) {
+  const long total = (long)B * HEDIT_CTXP * dim;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % dim);
+    const long r = i / dim;
+    const int tok = (int)(r % HEDIT_CTXP);
+    const long b = r / HEDIT_CTXP;
+    y[i] = tok < HEDIT_MAXW ? f32_to_bf16(x[(b * HEDIT_MAXW + tok) * dim + c]) : (bf16_t)0;
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int O, int I) {
+  const long total = (long)O * 9 * I;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int i = (int)(idx % I);
+    const long t = idx / I;
+    const int tap = (int)(t % 9);
+    const int o = (int)(t / 9);
+    out[idx] = f32_to_bf16(w[((long)o * I + i) * 9 + tap]);
+  }
+}
+
+// ------------------------------------------------------------------ GEMV (time-embedding chain)
+__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W, const float* __restrict__ x, const float* __restrict__ b0,
+                                                   const float* __restrict__ b1, float* __restrict__ out, int N, int K, int silu) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    uint4 u = *reinterpret_cast<const uint4*>(W + (long)n * K + k);
+    float w[8];
+    unpack8(u, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float xv = x[k + j];
+      if (silu) xv = silu_f(xv);
+      acc += w[j] * xv;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[n] = acc + (b0 ? b0[n] : 0.f) + (b1 ? b1[n] : 0.f);
+}
+
+// sinusoidal timestep embedding, flip_sin_to_cos: [cos | sin](t * 10000^(-i/half))
+__global__ void timestep_embed_kernel(float t, float* out, int dim) {
+  const int half = dim / 2;
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float fr = expf(-9.210340371976184f * (float)i / (float)half);
+    const float a = t * fr;
+    out[i] = cosf(a);
+    out[half + i] = sinf(a);
+  }
+}
+
+// ------------------------------------------------------------------ conv_in (Cin <= 8, K = 9 Cin tiny -> VALU)
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      bf16_t* __restrict__ y, int B, int Cin, int H, int Wd, int Cout) {
+  const int CV = Cout / 8;
+  const long total = (long)B * H * Wd * CV;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    const long pix = i / CV;
+    const int ox = (int)(pix % Wd);
+    const int oy = (int)((pix / Wd) % H);
+    const int b = (int)(pix / ((long)Wd * H));
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias[cv * 8 + j];
+    for (int ci = 0; ci < Cin; ++ci) {
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy + ky - 1;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = ox + kx - 1;
+          if ((unsigned)ix >= (unsigned)Wd) continue;
+          const float xv = x[(((long)b * Cin + ci) * H + iy) * Wd + ix];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            acc[j] += xv * w[(((long)(cv * 8 + j) * Cin + ci) * 3 + ky) * 3 + kx];
+        }
+      }
+    }
+    *reinterpret_cast<uint4*>(y + pix * Cout + cv * 8) = pack8(acc);
+  }
+}
+
+// ------------------------------------------------------------------ conv_out (Cout <= 4): one wave per pixel
+__global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ y, int B, int H, int Wd, int C, int Cout) {
+  const int lane = threadIdx.x & 63;
+  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= (long)B * H * Wd) return;
+  const int ox = (int)(pix % Wd);
+  const int oy = (int)((pix / Wd) % H);
+  const int b = (int)(pix / ((long)Wd * H));
+  const int CV = C / 8;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int idx = lane; idx < 9 * CV; idx += 64) {
+    const int tap = idx / CV, cv = idx - tap * CV;
+    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+    if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)Wd) continue;
+    uint4 u = *reinterpret_cast<const uint4*>(x + (((long)b * H + iy) * Wd + ix) * C + cv * 8);
+    float f[8];
+    unpack8(u, f);
+    for (int co = 0; co < Cout; ++co) {
+      uint4 uw = *reinterpret_cast<const uint4*>(w + ((long)co * 9 + tap) * C + cv * 8);
+      float ww[8];
+      unpack8(uw, ww);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[co] += f[j] * ww[j];
+    }
+  }
+  for (int co = 0; co < Cout; ++co) {
+    float v = wave_sum(acc[co]);
+    if (lane == 0) y[(((long)b * Cout + co) * H + oy) * Wd + ox] = v + bias[co];
+  }
+}
+
+inline int ew_grid(long work_items) {
+  long g = (work_items + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int gn_nslab(int B, int HW, int C) {
+  const int CV = C / 8;
+  const int R = CV <= 256 ? 256 / CV : 1;
+  int n = HW / (R * 4);         // >= 4 rows per thread
+  int want = 1024 / (B > 0 ? B : 1);
+  if (want < 1) want = 1;
+  if (n > want) n = want;
+  if (n > 128) n = 128;
+  if (n < 1) n = 1;
+  return n;
+}
+
+}  // namespace
+
+size_t groupnorm_ws_bytes(int B, int HW, int C) {
+  const int nslab = gn_nslab(B, HW, C);
+  return ((size_t)B * nslab * 64 * 2 + (size_t)B * C * 2) * sizeof(float);
+}
+
+int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B, int HW,
+                     int C, int G, float eps, int silu, float* ws, hipStream_t st) {
+  ARG_CHECK(C % 8 == 0 && C % G == 0 && G <= 64, "groupnorm: C % 8, C % G, G <= 64");
+  ARG_CHECK(C / 8 <= 256 * GN_MAXV, "groupnorm: C too large");
+  const int nslab = gn_nslab(B, HW, C);
+  float* part = ws;
+  float* ss = ws + (size_t)B * nslab * 64 * 2;
+  const int CV = C / 8;
+  const int R = CV <= 256 ? 256 / CV : 1;
+  const size_t lds = (size_t)R * C * 2 * sizeof(float);
+  ARG_CHECK(lds <= 64 * 1024, "groupnorm: LDS");
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, B), dim3(256), lds, st, x, part, HW, C, G, nslab);
+  LAUNCH_CHECK();
+  // partial buffer is indexed with stride G (<=64 reserved)
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, gamma, beta, ss, HW, C, G, nslab, eps);
+  LAUNCH_CHECK();
+  const long total_v = (long)B * HW * CV;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(total_v)), dim3(256), 0, st, x, y, ss, total_v, HW, C, silu);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, long rows, int C,
+                     float eps, hipStream_t st) {
+  ARG_CHECK(C % 8 == 0 && C / 8 <= 64 * LN_MAXV, "layernorm: C");
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int geglu_launch(const bf16_t* x, bf16_t* y, long rows, int inner, hipStream_t st) {
+  ARG_CHECK(inner % 8 == 0, "geglu: inner % 8");
+  hipLaunchKernelGGL(geglu_kernel, dim3(ew_grid(rows * (inner / 8))), dim3(256), 0, st, x, y, rows, inner);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int concat_launch(const bf16_t* a, int ca, const bf16_t* b, int cb, bf16_t* y, long rows, hipStream_t st) {
+  ARG_CHECK(ca % 8 == 0 && cb % 8 == 0, "concat: channels % 8");
+  hipLaunchKernelGGL(concat_kernel, dim3(ew_grid(rows * ((ca + cb) / 8))), dim3(256), 0, st, a, ca, b, cb, y, rows);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int f32_to_bf16_launch(const float* x, bf16_t* y, long n, hipStream_t st) {
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, y, n, 1.0f);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int ctx_pad_launch(const float* x, bf16_t* y, int B, int dim, hipStream_t st) {
+  hipLaunchKernelGGL(ctx_pad_kernel, dim3(ew_grid((long)B * HEDIT_CTXP * dim)), dim3(256), 0, st, x, y, B, dim);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int pack_linear_launch(const float* w, bf16_t* out, long n, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ew_grid(n)), dim3(256), 0, st, w, out, n, scale);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int pack_conv3x3_launch(const float* w, bf16_t* out, int O, int I, hipStream_t st) {
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(ew_grid((long)O * 9 * I)), dim3(256), 0, st, w, out, O, I);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int gemv_launch(const bf16_t* W, const float* x, const float* b0, const float* b1, float* out, int N, int K,
+                int silu, hipStream_t st) {
+  ARG_CHECK(K % 8 == 0, "gemv: K % 8");
+  hipLaunchKernelGGL(gemv_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, W, x, b0, b1, out, N, K, silu);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int timestep_embed_launch(float t, float* out, int dim, hipStream_t st) {
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3(1), dim3(256), 0, st, t, out, dim);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int conv_in_launch(const float* x, const float* w, const float* bias, bf16_t* y, int B, int Cin, int H, int W,
+                   int Cout, hipStream_t st) {
+  ARG_CHECK(Cout % 8 == 0, "conv_in: Cout % 8");
+  hipLaunchKernelGGL(conv_in_kernel, dim3(ew_grid((long)B * H * W * (Cout / 8))), dim3(256), 0, st, x, w, bias, y, B, Cin, H, W, Cout);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int conv_out_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* y, int B, int H, int W, int C,
+                    int Cout, hipStream_t st) {
+  ARG_CHECK(C % 8 == 0 && Cout <= 4, "conv_out: C % 8, Cout <= 4");
+  hipLaunchKernelGGL(conv_out_kernel, dim3(cdiv((long)B * H * W, 4)), dim3(256), 0, st, x, w, bias, y, B, H, W, C, Cout);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}

@@ -1,0 +1,185 @@
+// Loop-level kernels of the h-Edit sampler: everything the reference does between two UNet calls
+// with ~15 tiny torch ops and two .item() host syncs (text-guided/inversion/p2p_h_edit.py:616-699,
+// inversion_utils.py:84-119, p2p/ptp_classes.py:44-72) as three launch-bound kernels with no host
+// round trip.  fp32 NCHW latents, one workgroup per image (the per-image RMS norms of the
+// reconstruction pull are block reductions).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  const int nw = blockDim.x >> 6;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// x_prev[j] = sqrt(ab_prev) * (x[j] - sqrt(1-ab_t) e) / sqrt(ab_t) + dir * e + noise * z
+// with e = e_u + w_src (e_c - e_u).  Batched tensors are [row][image][elems] ("row-major over
+// images", identical to the reference layout for one image):
+//   rows == 4: P2P layout [x_o|0, x_e|0, x_o|src, x_e|src];
+//   rows == 2: no-P2P layout [x_e|0, x_e|src], the same eps drives both branches;
+//   xt / x_prev: [2][n_img][elems] = (x^orig, x^edit).
+__global__ __launch_bounds__(256) void step_base_kernel(const float* __restrict__ eps, const float* __restrict__ xt,
+                                                        const float* __restrict__ z, float* __restrict__ x_prev,
+                                                        int n_img, int elems, int rows, StepCoef c) {
+  const int img = blockIdx.y;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < elems; i += gridDim.x * 256) {
+    const float zz = z ? z[(long)img * elems + i] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ru = rows == 4 ? j : 0, rc = rows == 4 ? 2 + j : 1;
+      const float eu = eps[((long)ru * n_img + img) * elems + i];
+      const float ec = eps[((long)rc * n_img + img) * elems + i];
+      const float en = eu + c.w_src * (ec - eu);
+      const long xi = ((long)j * n_img + img) * elems + i;
+      const float x0 = (xt[xi] - c.sqrt_1m_ab_t * en) / c.sqrt_ab_t;
+      float pv = c.sqrt_ab_prev * x0 + c.dir_coef * en;
+      pv = pv + c.noise_coef * zz;
+      x_prev[xi] = pv;
+    }
+  }
+}
+
+// x_out = rec + coeff * corr,  corr = e_tar - e_hat;  k > 0: rec = x_k - rho * sign(x_k - x_base)/N
+__global__ __launch_bounds__(1024) void step_update_kernel(const float* __restrict__ e_u_src, const float* __restrict__ e_c_src,
+                                                           const float* __restrict__ e_u_tar, const float* __restrict__ e_c_tar,
+                                                           long stride_img, const float* __restrict__ x_k,
+                                                           const float* __restrict__ x_base, float* __restrict__ x_out,
+                                                           int elems, int k_gt0, StepCoef c) {
+  __shared__ float red[16];
+  const int img = blockIdx.x;
+  const long eo = (long)img * stride_img;
+  const float* xk = x_k + (long)img * elems;
+  const float* xb = x_base + (long)img * elems;
+  float* xo = x_out + (long)img * elems;
+  float rho = 0.f;
+  const float invn = 1.0f / (float)elems;
+  if (k_gt0) {
+    float sc = 0.f, sg = 0.f;
+    for (int i = threadIdx.x; i < elems; i += blockDim.x) {
+      const float ehat = e_u_src[eo + i] + c.w_hat * (e_c_src[eo + i] - e_u_src[eo + i]);
+      const float etar = e_u_tar[eo + i] + c.w_tar * (e_c_tar[eo + i] - e_u_tar[eo + i]);
+      const float corr = etar - ehat;
+      sc += corr * corr;
+      const float d = xk[i] - xb[i];
+      const float g = (d > 0.f ? invn : (d < 0.f ? -invn : 0.f));
+      sg += g * g;
+    }
+    sc = block_sum(sc, red);
+    sg = block_sum(sg, red);
+    const float nc = sqrtf(sc * invn), ng = sqrtf(sg * invn);
+    rho = nc / (ng + 1e-8f) * c.w_rec;
+  }
+  for (int i = threadIdx.x; i < elems; i += blockDim.x) {
+    const float ehat = e_u_src[eo + i] + c.w_hat * (e_c_src[eo + i] - e_u_src[eo + i]);
+    const float etar = e_u_tar[eo + i] + c.w_tar * (e_c_tar[eo + i] - e_u_tar[eo + i]);
+    const float corr = etar - ehat;
+    float rec = xk[i];
+    if (k_gt0) {
+      const float d = xk[i] - xb[i];
+      const float g = (d > 0.f ? invn : (d < 0.f ? -invn : 0.f));
+      rec = rec - rho * g;
+    }
+    xo[i] = rec + c.coeff * corr;
+  }
+}
+
+struct BlendMaps { const float* p[8]; };
+
+// LocalBlend: word-selected mean of the 16x16 cross maps -> 3x3 max-pool -> nearest upsample ->
+// /max -> threshold -> OR(src, tar) -> x_e = x_o + mask (x_e - x_o).  One workgroup per image.
+__global__ __launch_bounds__(256) void local_blend_kernel(BlendMaps maps, int n_maps, int heads, const float* __restrict__ alpha,
+                                                          const int* __restrict__ enabled, float* __restrict__ xt, int n_img,
+                                                          int C, int H, int W, float th) {
+  __shared__ float m[2][256];
+  __shared__ float pooled[2][256];
+  __shared__ float red[4];
+  __shared__ float mxs[2];
+  const int img = blockIdx.x, p = threadIdx.x;
+  if (enabled && !enabled[img]) return;     // this image has no LocalBlend
+  const float* al = alpha + (long)img * 2 * HEDIT_MAXW;
+  for (int s = 0; s < 2; ++s) {
+    float acc = 0.f;
+    for (int l = 0; l < n_maps; ++l) {
+      const float* base = maps.p[l] + (((long)img * 2 + s) * heads) * 256 * HEDIT_MAXW;
+      for (int n = 0; n < HEDIT_MAXW; ++n) {
+        const float a = al[s * HEDIT_MAXW + n];
+        if (a == 0.f) continue;
+        for (int h = 0; h < heads; ++h) acc += base[((long)h * 256 + p) * HEDIT_MAXW + n] * a;
+      }
+    }
+    m[s][p] = acc / (float)(n_maps * heads);
+  }
+  __syncthreads();
+  const int py = p >> 4, px = p & 15;
+  for (int s = 0; s < 2; ++s) {
+    float v = -3.4e38f;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yy = py + dy, xx = px + dx;
+        if ((unsigned)yy < 16u && (unsigned)xx < 16u) v = fmaxf(v, m[s][yy * 16 + xx]);
+      }
+    pooled[s][p] = v;
+  }
+  __syncthreads();
+  for (int s = 0; s < 2; ++s) {
+    float v = wave_max(pooled[s][p]);
+    if ((p & 63) == 0) red[p >> 6] = v;
+    __syncthreads();
+    if (p == 0) mxs[s] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+  }
+  float* xo = xt + (long)img * C * H * W;            // xt is [2][n_img][C][H][W]
+  float* xe = xt + ((long)n_img + img) * C * H * W;
+  for (int i = p; i < H * W; i += 256) {
+    const int y = i / W, x = i - y * W;
+    const int sp = ((y * 16) / H) * 16 + (x * 16) / W;
+    const bool on = (pooled[0][sp] / mxs[0] > th) || (pooled[1][sp] / mxs[1] > th);
+    if (!on) {
+      for (int ch = 0; ch < C; ++ch) xe[(long)ch * H * W + i] = xo[(long)ch * H * W + i];
+    } else {
+      // x_o + 1.0 * (x_e - x_o): keep the reference's rounding
+      for (int ch = 0; ch < C; ++ch) {
+        const float a = xo[(long)ch * H * W + i];
+        xe[(long)ch * H * W + i] = a + (xe[(long)ch * H * W + i] - a);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int step_base_launch(const float* eps, const float* xt, const float* z, float* x_prev, int n_img, int elems,
+                     int rows, StepCoef c, hipStream_t st) {
+  ARG_CHECK(rows == 4 || rows == 2, "step_base: eps rows per image must be 4 (P2P) or 2");
+  dim3 grid(cdiv(elems, 256) > 64 ? 64 : cdiv(elems, 256), n_img);
+  hipLaunchKernelGGL(step_base_kernel, grid, dim3(256), 0, st, eps, xt, z, x_prev, n_img, elems, rows, c);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int step_update_launch(const float* e_u_src, const float* e_c_src, const float* e_u_tar, const float* e_c_tar,
+                       long stride_img, const float* x_k, const float* x_base, float* x_out, int n_img, int elems,
+                       int k_gt0, StepCoef c, hipStream_t st) {
+  hipLaunchKernelGGL(step_update_kernel, dim3(n_img), dim3(1024), 0, st, e_u_src, e_c_src, e_u_tar, e_c_tar,
+                     stride_img, x_k, x_base, x_out, elems, k_gt0, c);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int local_blend_launch(const float* const* maps, int n_maps, int heads, const float* alpha_layers,
+                       const int* enabled, float* xt, int n_img, int C, int H, int W, float th, hipStream_t st) {
+  ARG_CHECK(n_maps >= 1 && n_maps <= 8, "local_blend: 1..8 maps");
+  BlendMaps bm;
+  for (int i = 0; i < 8; ++i) bm.p[i] = i < n_maps ? maps[i] : nullptr;
+  hipLaunchKernelGGL(local_blend_kernel, dim3(n_img), dim3(256), 0, st, bm, n_maps, heads, alpha_layers, enabled, xt, n_img, C, H, W, th);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}

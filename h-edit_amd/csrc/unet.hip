@@ -1,0 +1,741 @@
+// The SD-1.x eps-network as a native executor: owns the packed bf16 weights, plans activation
+// memory inside a caller-provided workspace (first-fit arena, stream-ordered reuse) and walks the
+// network issuing the HIP kernels of gemm.hip / norm.hip / attn.hip on one stream.  One C call
+// per UNet evaluation replaces the ~700 eager launches of the reference stack.
+//
+// Architecture = diffusers' UNet2DConditionModel as used by SD-1.4/1.5;
+// parameter names are the diffusers state_dict keys so real checkpoints load unchanged.
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hedit.h"
+#include "common.h"
+#include "kernels.h"
+
+#define TRY(expr)                        \
+  do {                                   \
+    int _rc = (expr);                    \
+    if (_rc != HEDIT_OK) return _rc;     \
+  } while (0)
+
+namespace {
+
+struct Slot {
+  std::string name;
+  int kind;        // 0 fp32 copy, 1 linear -> bf16 (scaled), 2 conv3x3 OIHW -> bf16 [O][9][I]
+  void* dst;
+  size_t numel;
+  int O, I;
+  float scale;
+  bool loaded;
+  int ndim;
+  int dims[4];
+};
+
+struct Res {
+  int cin, cout, temb_off;
+  float *n1g, *n1b, *n2g, *n2b, *conv2_b, *sc_b;
+  bf16_t *conv1, *conv2, *sc_w;
+};
+
+struct Attn {
+  int C;
+  float *gn_g, *gn_b, *pin_b, *ln1g, *ln1b, *ln2g, *ln2b, *ln3g, *ln3b, *o1_b, *o2_b, *ff1_b, *ff2_b, *pout_b;
+  bf16_t *pin, *w_qk, *w_v1, *w_o1, *w_q2, *w_k2, *w_v2, *w_o2, *ff1, *ff2, *pout;
+};
+
+struct Block {
+  std::vector<Res> res;
+  std::vector<Attn> attn;
+  bool has_attn = false, has_sampler = false;
+  bf16_t* samp_w = nullptr;
+  float* samp_b = nullptr;
+  int ch = 0;
+};
+
+// first-fit arena over the caller's workspace; "dry" mode only records the peak
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, peak = 0;
+  bool dry = false;
+  std::map<size_t, size_t> used;   // offset -> size
+  bool failed = false;
+
+  void* alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    size_t pos = 0;
+    for (auto& kv : used) {
+      if (kv.first >= pos + bytes) break;
+      pos = kv.first + kv.second;
+    }
+    if (!dry && pos + bytes > cap) { failed = true; return nullptr; }
+    used[pos] = bytes;
+    if (pos + bytes > peak) peak = pos + bytes;
+    return dry ? reinterpret_cast<void*>(pos + 4096) : base + pos;
+  }
+  void free(void* p) {
+    if (!p) return;
+    size_t off = dry ? reinterpret_cast<size_t>(p) - 4096 : (size_t)(reinterpret_cast<char*>(p) - base);
+    used.erase(off);
+  }
+};
+
+}  // namespace
+
+struct hedit_unet {
+  hedit_unet_cfg cfg;
+  std::vector<void*> owned;
+  std::vector<Slot> slots;
+  std::map<std::string, int> index;
+  int temb_dim = 0, temb_total = 0;
+  // stem / head
+  float *conv_in_w = nullptr, *conv_in_b = nullptr, *te1_b = nullptr, *te2_b = nullptr;
+  bf16_t *te1_w = nullptr, *te2_w = nullptr, *temb_w_all = nullptr, *conv_out_w = nullptr;
+  float *temb_b_all = nullptr, *conv1_b_all = nullptr, *gn_out_g = nullptr, *gn_out_b = nullptr, *conv_out_b = nullptr;
+  std::vector<Block> down, up;
+  Res mid_res[2];
+  Attn mid_attn;
+  int32_t* iota = nullptr;
+  int iota_cap = 0;
+};
+
+namespace {
+
+template <class T>
+T* dalloc(hedit_unet* h, size_t n) {
+  void* p = nullptr;
+  if (hipMalloc(&p, n * sizeof(T) > 0 ? n * sizeof(T) : 16) != hipSuccess) return nullptr;
+  h->owned.push_back(p);
+  return reinterpret_cast<T*>(p);
+}
+
+void add_slot(hedit_unet* h, const std::string& name, int kind, void* dst, size_t numel, int O = 0, int I = 0, float scale = 1.f) {
+  Slot s{name, kind, dst, numel, O, I, scale, false, 1, {(int)numel, 1, 1, 1}};
+  if (kind == 1) { s.ndim = 2; s.dims[0] = O; s.dims[1] = I; }
+  if (kind == 2) { s.ndim = 4; s.dims[0] = O; s.dims[1] = I; s.dims[2] = 3; s.dims[3] = 3; }
+  // 1x1 convolutions keep their 4-D torch shape
+  if (kind == 1 && (name.find("proj_in.weight") != std::string::npos || name.find("proj_out.weight") != std::string::npos ||
+                    name.find("conv_shortcut.weight") != std::string::npos)) {
+    s.ndim = 4; s.dims[2] = 1; s.dims[3] = 1;
+  }
+  h->index[name] = (int)h->slots.size();
+  h->slots.push_back(s);
+}
+float* f32p(hedit_unet* h, const std::string& name, size_t n, float* dst = nullptr) {
+  if (!dst) dst = dalloc<float>(h, n);
+  add_slot(h, name, 0, dst, n);
+  return dst;
+}
+bf16_t* linp(hedit_unet* h, const std::string& name, int O, int I, bf16_t* dst = nullptr, float scale = 1.f) {
+  if (!dst) dst = dalloc<bf16_t>(h, (size_t)O * I);
+  add_slot(h, name, 1, dst, (size_t)O * I, O, I, scale);
+  return dst;
+}
+bf16_t* conv3p(hedit_unet* h, const std::string& name, int O, int I) {
+  bf16_t* dst = dalloc<bf16_t>(h, (size_t)O * I * 9);
+  add_slot(h, name, 2, dst, (size_t)O * I * 9, O, I);
+  return dst;
+}
+
+Res make_res(hedit_unet* h, const std::string& pre, int cin, int cout, int& temb_off) {
+  Res r{};
+  r.cin = cin; r.cout = cout; r.temb_off = temb_off;
+  r.n1g = f32p(h, pre + ".norm1.weight", cin);
+  r.n1b = f32p(h, pre + ".norm1.bias", cin);
+  r.conv1 = conv3p(h, pre + ".conv1.weight", cout, cin);
+  f32p(h, pre + ".conv1.bias", cout, h->conv1_b_all + temb_off);
+  linp(h, pre + ".time_emb_proj.weight", cout, h->temb_dim, h->temb_w_all + (size_t)temb_off * h->temb_dim);
+  f32p(h, pre + ".time_emb_proj.bias", cout, h->temb_b_all + temb_off);
+  r.n2g = f32p(h, pre + ".norm2.weight", cout);
+  r.n2b = f32p(h, pre + ".norm2.bias", cout);
+  r.conv2 = conv3p(h, pre + ".conv2.weight", cout, cout);
+  r.conv2_b = f32p(h, pre + ".conv2.bias", cout);
+  if (cin != cout) {
+    r.sc_w = linp(h, pre + ".conv_shortcut.weight", cout, cin);
+    r.sc_b = f32p(h, pre + ".conv_shortcut.bias", cout);
+  }
+  temb_off += cout;
+  return r;
+}
+
+Attn make_attn(hedit_unet* h, const std::string& pre, int C) {
+  Attn a{};
+  a.C = C;
+  const int ctx = h->cfg.cross_attention_dim;
+  const int d = C / h->cfg.heads;
+  const float qscale = 1.0f / sqrtf((float)d) * 1.4426950408889634f;   // softmax scale * log2(e)
+  a.gn_g = f32p(h, pre + ".norm.weight", C);
+  a.gn_b = f32p(h, pre + ".norm.bias", C);
+  a.pin = linp(h, pre + ".proj_in.weight", C, C);
+  a.pin_b = f32p(h, pre + ".proj_in.bias", C);
+  const std::string tb = pre + ".transformer_blocks.0";
+  a.ln1g = f32p(h, tb + ".norm1.weight", C);
+  a.ln1b = f32p(h, tb + ".norm1.bias", C);
+  a.w_qk = dalloc<bf16_t>(h, (size_t)2 * C * C);
+  linp(h, tb + ".attn1.to_q.weight", C, C, a.w_qk, qscale);
+  linp(h, tb + ".attn1.to_k.weight", C, C, a.w_qk + (size_t)C * C);
+  a.w_v1 = linp(h, tb + ".attn1.to_v.weight", C, C);
+  a.w_o1 = linp(h, tb + ".attn1.to_out.0.weight", C, C);
+  a.o1_b = f32p(h, tb + ".attn1.to_out.0.bias", C);
+  a.ln2g = f32p(h, tb + ".norm2.weight", C);
+  a.ln2b = f32p(h, tb + ".norm2.bias", C);
+  a.w_q2 = linp(h, tb + ".attn2.to_q.weight", C, C, nullptr, qscale);
+  a.w_k2 = linp(h, tb + ".attn2.to_k.weight", C, ctx);
+  a.w_v2 = linp(h, tb + ".attn2.to_v.weight", C, ctx);
+  a.w_o2 = linp(h, tb + ".attn2.to_out.0.weight", C, C);
+  a.o2_b = f32p(h, tb + ".attn2.to_out.0.bias", C);
+  a.ln3g = f32p(h, tb + ".norm3.weight", C);
+  a.ln3b = f32p(h, tb + ".norm3.bias", C);
+  a.ff1 = linp(h, tb + ".ff.net.0.proj.weight", 8 * C, C);
+  a.ff1_b = f32p(h, tb + ".ff.net.0.proj.bias", 8 * C);
+  a.ff2 = linp(h, tb + ".ff.net.2.weight", C, 4 * C);
+  a.ff2_b = f32p(h, tb + ".ff.net.2.bias", C);
+  a.pout = linp(h, pre + ".proj_out.weight", C, C);
+  a.pout_b = f32p(h, pre + ".proj_out.bias", C);
+  return a;
+}
+
+// ------------------------------------------------------------------------------ forward
+struct Fwd {
+  hedit_unet* h;
+  int B;
+  hipStream_t st;
+  Arena ar;
+  const hedit_p2p_plan* plan;
+  const float* temb_all;     // fused (time_emb_proj(silu(temb)) + conv1.bias) of every ResBlock
+  const bf16_t* ctxb;        // [B*80][ctx_dim]
+  int store_idx = 0;
+  bool dry() const { return ar.dry; }
+};
+
+#define RUN(f, expr)            \
+  do {                          \
+    if (!(f).dry()) TRY(expr);  \
+  } while (0)
+
+template <class T>
+int aalloc(Fwd& f, T** out, size_t n) {
+  *out = reinterpret_cast<T*>(f.ar.alloc(n * sizeof(T)));
+  if (!*out) {
+    hedit_set_error("workspace too small (need more than " + std::to_string(f.ar.cap) + " bytes)");
+    return HEDIT_ERR_ARG;
+  }
+  return HEDIT_OK;
+}
+
+int run_gemm(Fwd& f, GemmParams p) {
+  const int splits = gemm_pick_splits(p.M, p.N, p.K, 0);
+  float* part = nullptr;
+  if (splits > 1) TRY(aalloc(f, &part, (size_t)splits * p.M * p.N));
+  RUN(f, gemm_launch(p, splits, part, f.st));
+  if (part) f.ar.free(part);
+  return HEDIT_OK;
+}
+
+int linear(Fwd& f, const bf16_t* A, int M, int K, const bf16_t* W, int N, const float* bias,
+           const bf16_t* residual, bf16_t* C, int ldc) {
+  GemmParams p{};
+  p.A = A; p.W = W; p.M = M; p.N = N; p.K = K; p.lda = K; p.mode = 0;
+  p.bias = bias; p.residual = residual; p.ldr = N; p.C = C; p.ldc = ldc;
+  return run_gemm(f, p);
+}
+
+int conv3x3(Fwd& f, const bf16_t* X, int Hin, int Win, int Cin, const bf16_t* W, int Cout, const float* bias,
+            const bf16_t* residual, bf16_t* Y, int mode) {
+  GemmParams p{};
+  p.mode = mode;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin;
+  p.Hout = mode == 2 ? Hin / 2 : (mode == 3 ? Hin * 2 : Hin);
+  p.Wout = mode == 2 ? Win / 2 : (mode == 3 ? Win * 2 : Win);
+  p.A = X; p.W = W; p.M = f.B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin; p.lda = Cin;
+  p.bias = bias; p.residual = residual; p.ldr = Cout; p.C = Y; p.ldc = Cout;
+  return run_gemm(f, p);
+}
+
+int groupnorm(Fwd& f, const bf16_t* x, bf16_t* y, const float* g, const float* b, int HW, int C, float eps, int silu) {
+  float* ws;
+  TRY(aalloc(f, &ws, groupnorm_ws_bytes(f.B, HW, C) / sizeof(float)));
+  RUN(f, groupnorm_launch(x, y, g, b, f.B, HW, C, f.h->cfg.norm_num_groups, eps, silu, ws, f.st));
+  f.ar.free(ws);
+  return HEDIT_OK;
+}
+
+// x [M][cin] -> *out [M][cout] (allocated here; x is NOT freed)
+int resblock(Fwd& f, const Res& r, const bf16_t* x, int H, int W, bf16_t** out) {
+  const size_t M = (size_t)f.B * H * W;
+  bf16_t *a1, *h1, *a2, *sc = nullptr, *y;
+  TRY(aalloc(f, &a1, M * r.cin));
+  TRY(groupnorm(f, x, a1, r.n1g, r.n1b, H * W, r.cin, 1e-5f, 1));
+  TRY(aalloc(f, &h1, M * r.cout));
+  TRY(conv3x3(f, a1, H, W, r.cin, r.conv1, r.cout, f.temb_all + r.temb_off, nullptr, h1, 1));
+  f.ar.free(a1);
+  TRY(aalloc(f, &a2, M * r.cout));
+  TRY(groupnorm(f, h1, a2, r.n2g, r.n2b, H * W, r.cout, 1e-5f, 1));
+  f.ar.free(h1);
+  const bf16_t* res = x;
+  if (r.sc_w) {
+    TRY(aalloc(f, &sc, M * r.cout));
+    TRY(linear(f, x, (int)M, r.cin, r.sc_w, r.cout, r.sc_b, nullptr, sc, r.cout));
+    res = sc;
+  }
+  TRY(aalloc(f, &y, M * r.cout));
+  TRY(conv3x3(f, a2, H, W, r.cout, r.conv2, r.cout, r.conv2_b, res, y, 1));
+  f.ar.free(a2);
+  if (sc) f.ar.free(sc);
+  *out = y;
+  return HEDIT_OK;
+}
+
+// x [M][C] -> *out [M][C] (allocated here; x is NOT freed)
+int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** out) {
+  const int C = a.C, N = H * W, B = f.B, heads = f.h->cfg.heads, d = C / heads;
+  const int ctx_dim = f.h->cfg.cross_attention_dim;
+  const size_t M = (size_t)B * N;
+  const hedit_p2p_plan* pl = (f.plan && f.plan->mode > 0) ? f.plan : nullptr;
+  bf16_t *xn, *t0, *tn, *qk, *vt, *ao, *t1, *q2, *k2, *vt2, *t2, *hf, *gf, *t3, *y;
+
+  TRY(aalloc(f, &xn, M * C));
+  TRY(groupnorm(f, x, xn, a.gn_g, a.gn_b, N, C, 1e-6f, 0));
+  TRY(aalloc(f, &t0, M * C));
+  TRY(linear(f, xn, (int)M, C, a.pin, C, a.pin_b, nullptr, t0, C));
+  f.ar.free(xn);
+
+  // ---- self-attention
+  TRY(aalloc(f, &tn, M * C));
+  RUN(f, layernorm_launch(t0, tn, a.ln1g, a.ln1b, (long)M, C, 1e-5f, f.st));
+  TRY(aalloc(f, &qk, M * 2 * C));
+  TRY(linear(f, tn, (int)M, C, a.w_qk, 2 * C, nullptr, nullptr, qk, 2 * C));
+  TRY(aalloc(f, &vt, M * C));
+  TRY(linear(f, a.w_v1, C, C, tn, (int)M, nullptr, nullptr, vt, (int)M));   // V^T = W_v . X^T
+  f.ar.free(tn);
+  TRY(aalloc(f, &ao, M * C));
+  {
+    SelfAttnParams sp{};
+    sp.q = qk; sp.ldq = 2 * C; sp.k = qk + C; sp.ldk = 2 * C; sp.vt = vt; sp.ldvt = (long)M;
+    sp.out = ao; sp.ldo = C; sp.B = B; sp.N = N; sp.heads = heads; sp.d = d;
+    sp.qk_src = (pl && pl->qk_src && N <= 1024) ? pl->qk_src : nullptr;
+    RUN(f, self_attn_launch(sp, f.st));
+  }
+  f.ar.free(qk);
+  f.ar.free(vt);
+  TRY(aalloc(f, &t1, M * C));
+  TRY(linear(f, ao, (int)M, C, a.w_o1, C, a.o1_b, t0, t1, C));
+  f.ar.free(ao);
+  f.ar.free(t0);
+
+  // ---- cross-attention (P2P edits + store happen inside the kernel)
+  TRY(aalloc(f, &tn, M * C));
+  RUN(f, layernorm_launch(t1, tn, a.ln2g, a.ln2b, (long)M, C, 1e-5f, f.st));
+  TRY(aalloc(f, &q2, M * C));
+  TRY(linear(f, tn, (int)M, C, a.w_q2, C, nullptr, nullptr, q2, C));
+  f.ar.free(tn);
+  const int MC = B * HEDIT_CTXP;
+  TRY(aalloc(f, &k2, (size_t)MC * C));
+  TRY(linear(f, f.ctxb, MC, ctx_dim, a.w_k2, C, nullptr, nullptr, k2, C));
+  TRY(aalloc(f, &vt2, (size_t)MC * C));
+  TRY(linear(f, a.w_v2, C, ctx_dim, f.ctxb, MC, nullptr, nullptr, vt2, MC));
+  TRY(aalloc(f, &ao, M * C));
+  {
+    CrossAttnParams cp{};
+    cp.q = q2; cp.ldq = C; cp.k = k2; cp.ldk = C; cp.vt = vt2; cp.ldvt = MC; cp.out = ao; cp.ldo = C;
+    cp.B = B; cp.N = N; cp.heads = heads; cp.d = d;
+    const bool stored_layer = N <= 1024;
+    if (pl) {
+      cp.n_pairs = pl->n_pairs; cp.pair_src = pl->pair_src; cp.pair_tar = pl->pair_tar;
+      cp.mixT = reinterpret_cast<const bf16_t*>(pl->mixT); cp.bvec = pl->bvec;
+      cp.singles = pl->singles; cp.n_single = pl->n_single;
+      cp.store = (pl->mode == 2 && stored_layer && pl->h_store && f.store_idx < pl->n_store) ? pl->h_store[f.store_idx] : nullptr;
+    } else {
+      cp.n_pairs = 0; cp.singles = f.h->iota; cp.n_single = B;
+    }
+    if (stored_layer) f.store_idx++;
+    RUN(f, cross_attn_launch(cp, f.st));
+  }
+  f.ar.free(q2);
+  f.ar.free(k2);
+  f.ar.free(vt2);
+  TRY(aalloc(f, &t2, M * C));
+  TRY(linear(f, ao, (int)M, C, a.w_o2, C, a.o2_b, t1, t2, C));
+  f.ar.free(ao);
+  f.ar.free(t1);
+
+  // ---- GEGLU feed-forward
+  TRY(aalloc(f, &tn, M * C));
+  RUN(f, layernorm_launch(t2, tn, a.ln3g, a.ln3b, (long)M, C, 1e-5f, f.st));
+  TRY(aalloc(f, &hf, M * 8 * C));
+  TRY(linear(f, tn, (int)M, C, a.ff1, 8 * C, a.ff1_b, nullptr, hf, 8 * C));
+  f.ar.free(tn);
+  TRY(aalloc(f, &gf, M * 4 * C));
+  RUN(f, geglu_launch(hf, gf, (long)M, 4 * C, f.st));
+  f.ar.free(hf);
+  TRY(aalloc(f, &t3, M * C));
+  TRY(linear(f, gf, (int)M, 4 * C, a.ff2, C, a.ff2_b, t2, t3, C));
+  f.ar.free(gf);
+  f.ar.free(t2);
+
+  TRY(aalloc(f, &y, M * C));
+  TRY(linear(f, t3, (int)M, C, a.pout, C, a.pout_b, x, y, C));
+  f.ar.free(t3);
+  *out = y;
+  return HEDIT_OK;
+}
+
+struct Skip { bf16_t* p; int C; };
+
+int forward_impl(hedit_unet* h, const float* x, float t, const float* ctx, int B, int H0, int W0,
+                 const hedit_p2p_plan* plan, float* eps_out, void* ws, size_t ws_bytes, hipStream_t st,
+                 bool dry, size_t* peak) {
+  const hedit_unet_cfg& c = h->cfg;
+  Fwd f;
+  f.h = h; f.B = B; f.st = st; f.plan = plan;
+  f.ar.base = reinterpret_cast<char*>(ws); f.ar.cap = ws_bytes; f.ar.dry = dry;
+  const int ch0 = c.block_out_channels[0];
+
+  if (!dry && h->iota_cap < B) {
+    // identity row list for "all rows are singles" (controller off); grown on demand, off the hot path
+    std::vector<int32_t> v(B > 64 ? B : 64);
+    for (size_t i = 0; i < v.size(); ++i) v[i] = (int32_t)i;
+    int32_t* p = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), v.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->owned.push_back(p);
+    h->iota = p;
+    h->iota_cap = (int)v.size();
+  }
+
+  // ---- text context -> bf16, padded to 80 rows per item
+  bf16_t* ctxb;
+  TRY(aalloc(f, &ctxb, (size_t)B * HEDIT_CTXP * c.cross_attention_dim));
+  RUN(f, ctx_pad_launch(ctx, ctxb, B, c.cross_attention_dim, st));
+  f.ctxb = ctxb;
+
+  // ---- time embedding chain (the timestep is shared by the batch, so this is one GEMV chain)
+  float *te0, *te1, *te2, *temb_all;
+  TRY(aalloc(f, &te0, (size_t)ch0));
+  TRY(aalloc(f, &te1, (size_t)h->temb_dim));
+  TRY(aalloc(f, &te2, (size_t)h->temb_dim));
+  TRY(aalloc(f, &temb_all, (size_t)h->temb_total));
+  RUN(f, timestep_embed_launch(t, te0, ch0, st));
+  RUN(f, gemv_launch(h->te1_w, te0, h->te1_b, nullptr, te1, h->temb_dim, ch0, 0, st));
+  RUN(f, gemv_launch(h->te2_w, te1, h->te2_b, nullptr, te2, h->temb_dim, h->temb_dim, 1, st));
+  RUN(f, gemv_launch(h->temb_w_all, te2, h->temb_b_all, h->conv1_b_all, temb_all, h->temb_total, h->temb_dim, 1, st));
+  f.temb_all = temb_all;
+
+  // ---- stem
+  int H = H0, W = W0;
+  bf16_t* cur;
+  TRY(aalloc(f, &cur, (size_t)B * H * W * ch0));
+  RUN(f, conv_in_launch(x, h->conv_in_w, h->conv_in_b, cur, B, c.in_channels, H, W, ch0, st));
+  std::vector<Skip> skips;
+  skips.push_back({cur, ch0});
+
+  // ---- down path
+  for (int i = 0; i < c.n_levels; ++i) {
+    Block& blk = h->down[i];
+    for (size_t j = 0; j < blk.res.size(); ++j) {
+      bf16_t* y;
+      TRY(resblock(f, blk.res[j], cur, H, W, &y));
+      // cur stays alive as a skip
+      cur = y;
+      if (blk.has_attn) {
+        bf16_t* z;
+        TRY(transformer(f, blk.attn[j], cur, H, W, &z));
+        f.ar.free(cur);
+        cur = z;
+      }
+      skips.push_back({cur, blk.ch});
+    }
+    if (blk.has_sampler) {
+      bf16_t* y;
+      TRY(aalloc(f, &y, (size_t)B * (H / 2) * (W / 2) * blk.ch));
+      TRY(conv3x3(f, cur, H, W, blk.ch, blk.samp_w, blk.ch, blk.samp_b, nullptr, y, 2));
+      H /= 2; W /= 2;
+      cur = y;
+      skips.push_back({cur, blk.ch});
+    }
+  }
+
+  // ---- mid (cur is the last skip: do not free it here)
+  {
+    bf16_t *y, *z, *w;
+    TRY(resblock(f, h->mid_res[0], cur, H, W, &y));
+    TRY(transformer(f, h->mid_attn, y, H, W, &z));
+    f.ar.free(y);
+    TRY(resblock(f, h->mid_res[1], z, H, W, &w));
+    f.ar.free(z);
+    cur = w;
+  }
+  int cur_c = c.block_out_channels[c.n_levels - 1];
+
+  // ---- up path
+  for (int i = 0; i < c.n_levels; ++i) {
+    Block& blk = h->up[i];
+    for (size_t j = 0; j < blk.res.size(); ++j) {
+      Skip s = skips.back();
+      skips.pop_back();
+      bf16_t* cat;
+      const size_t M = (size_t)B * H * W;
+      TRY(aalloc(f, &cat, M * (cur_c + s.C)));
+      RUN(f, concat_launch(cur, cur_c, s.p, s.C, cat, (long)M, st));
+      f.ar.free(cur);
+      f.ar.free(s.p);
+      bf16_t* y;
+      TRY(resblock(f, blk.res[j], cat, H, W, &y));
+      f.ar.free(cat);
+      cur = y;
+      cur_c = blk.ch;
+      if (blk.has_attn) {
+        bf16_t* z;
+        TRY(transformer(f, blk.attn[j], cur, H, W, &z));
+        f.ar.free(cur);
+        cur = z;
+      }
+    }
+    if (blk.has_sampler) {
+      bf16_t* y;
+      TRY(aalloc(f, &y, (size_t)B * (H * 2) * (W * 2) * blk.ch));
+      TRY(conv3x3(f, cur, H, W, blk.ch, blk.samp_w, blk.ch, blk.samp_b, nullptr, y, 3));
+      f.ar.free(cur);
+      H *= 2; W *= 2;
+      cur = y;
+    }
+  }
+
+  // ---- head
+  {
+    bf16_t* a;
+    TRY(aalloc(f, &a, (size_t)B * H * W * ch0));
+    TRY(groupnorm(f, cur, a, h->gn_out_g, h->gn_out_b, H * W, ch0, 1e-5f, 1));
+    RUN(f, conv_out_launch(a, h->conv_out_w, h->conv_out_b, eps_out, B, H, W, ch0, c.out_channels, st));
+    f.ar.free(a);
+    f.ar.free(cur);
+  }
+  if (peak) *peak = f.ar.peak;
+  return HEDIT_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+int hedit_unet_create(const hedit_unet_cfg* cfg, hedit_unet** out) {
+  ARG_CHECK(cfg && out, "null");
+  ARG_CHECK(cfg->n_levels >= 2 && cfg->n_levels <= HEDIT_MAX_LEVELS, "n_levels");
+  ARG_CHECK(cfg->in_channels <= 8 && cfg->out_channels <= 4, "in/out channels");
+  ARG_CHECK(cfg->cross_attention_dim % 64 == 0, "cross_attention_dim % 64");
+  for (int i = 0; i < cfg->n_levels; ++i) {
+    ARG_CHECK(cfg->block_out_channels[i] % 64 == 0, "block_out_channels % 64");
+    ARG_CHECK(cfg->block_out_channels[i] % cfg->norm_num_groups == 0, "channels % groups");
+    const int d = cfg->block_out_channels[i] / cfg->heads;
+    ARG_CHECK(d == 32 || d == 40 || d == 64 || d == 80 || d == 160, "head dim must be one of 32,40,64,80,160");
+  }
+  hedit_unet* h = new hedit_unet();
+  h->cfg = *cfg;
+  const int* ch = cfg->block_out_channels;
+  const int L = cfg->layers_per_block, n = cfg->n_levels;
+  h->temb_dim = ch[0] * 4;
+
+  // channel plan of every ResBlock (needed up-front to size the fused time-embedding projection)
+  int total = 0;
+  {
+    int outc = ch[0];
+    for (int i = 0; i < n; ++i) { outc = ch[i]; total += L * outc; }
+    total += 2 * ch[n - 1];
+    for (int i = 0; i < n; ++i) total += (L + 1) * ch[n - 1 - i];
+  }
+  h->temb_total = total;
+  h->temb_w_all = dalloc<bf16_t>(h, (size_t)total * h->temb_dim);
+  h->temb_b_all = dalloc<float>(h, total);
+  h->conv1_b_all = dalloc<float>(h, total);
+
+  h->conv_in_w = f32p(h, "conv_in.weight", (size_t)ch[0] * cfg->in_channels * 9);
+  {
+    Slot& cs = h->slots.back();
+    cs.ndim = 4; cs.dims[0] = ch[0]; cs.dims[1] = cfg->in_channels; cs.dims[2] = 3; cs.dims[3] = 3;
+  }
+  h->conv_in_b = f32p(h, "conv_in.bias", ch[0]);
+  h->te1_w = linp(h, "time_embedding.linear_1.weight", h->temb_dim, ch[0]);
+  h->te1_b = f32p(h, "time_embedding.linear_1.bias", h->temb_dim);
+  h->te2_w = linp(h, "time_embedding.linear_2.weight", h->temb_dim, h->temb_dim);
+  h->te2_b = f32p(h, "time_embedding.linear_2.bias", h->temb_dim);
+
+  int toff = 0;
+  int outc = ch[0];
+  for (int i = 0; i < n; ++i) {
+    const int inc = outc;
+    outc = ch[i];
+    Block b;
+    b.ch = outc;
+    b.has_attn = cfg->down_has_attn[i] != 0;
+    const std::string pre = "down_blocks." + std::to_string(i);
+    for (int j = 0; j < L; ++j) {
+      b.res.push_back(make_res(h, pre + ".resnets." + std::to_string(j), j == 0 ? inc : outc, outc, toff));
+      if (b.has_attn) b.attn.push_back(make_attn(h, pre + ".attentions." + std::to_string(j), outc));
+    }
+    if (i != n - 1) {
+      b.has_sampler = true;
+      b.samp_w = conv3p(h, pre + ".downsamplers.0.conv.weight", outc, outc);
+      b.samp_b = f32p(h, pre + ".downsamplers.0.conv.bias", outc);
+    }
+    h->down.push_back(b);
+  }
+  h->mid_attn = make_attn(h, "mid_block.attentions.0", ch[n - 1]);
+  h->mid_res[0] = make_res(h, "mid_block.resnets.0", ch[n - 1], ch[n - 1], toff);
+  h->mid_res[1] = make_res(h, "mid_block.resnets.1", ch[n - 1], ch[n - 1], toff);
+  outc = ch[n - 1];
+  for (int i = 0; i < n; ++i) {
+    const int prev = outc;
+    outc = ch[n - 1 - i];
+    const int inp = ch[n - 1 - (i + 1 < n ? i + 1 : n - 1)];
+    Block b;
+    b.ch = outc;
+    b.has_attn = cfg->up_has_attn[i] != 0;
+    const std::string pre = "up_blocks." + std::to_string(i);
+    for (int j = 0; j < L + 1; ++j) {
+      const int skip = j == L ? inp : outc;
+      const int rin = j == 0 ? prev : outc;
+      b.res.push_back(make_res(h, pre + ".resnets." + std::to_string(j), rin + skip, outc, toff));
+      if (b.has_attn) b.attn.push_back(make_attn(h, pre + ".attentions." + std::to_string(j), outc));
+    }
+    if (i != n - 1) {
+      b.has_sampler = true;
+      b.samp_w = conv3p(h, pre + ".upsamplers.0.conv.weight", outc, outc);
+      b.samp_b = f32p(h, pre + ".upsamplers.0.conv.bias", outc);
+    }
+    h->up.push_back(b);
+  }
+  h->gn_out_g = f32p(h, "conv_norm_out.weight", ch[0]);
+  h->gn_out_b = f32p(h, "conv_norm_out.bias", ch[0]);
+  h->conv_out_w = conv3p(h, "conv_out.weight", cfg->out_channels, ch[0]);
+  h->conv_out_b = f32p(h, "conv_out.bias", cfg->out_channels);
+
+  if (toff != total) {
+    hedit_set_error("internal: time-embedding plan mismatch");
+    delete h;
+    return HEDIT_ERR_STATE;
+  }
+  for (void* p : h->owned)
+    if (!p) { hedit_set_error("hipMalloc failed while creating the UNet"); return HEDIT_ERR_HIP; }
+  for (auto& s : h->slots)
+    if (!s.dst) { hedit_set_error("hipMalloc failed for " + s.name); return HEDIT_ERR_HIP; }
+  *out = h;
+  return HEDIT_OK;
+}
+
+void hedit_unet_destroy(hedit_unet* h) {
+  if (!h) return;
+  for (void* p : h->owned) (void)hipFree(p);
+  delete h;
+}
+
+int hedit_unet_num_params(const hedit_unet* h) { return h ? (int)h->slots.size() : 0; }
+const char* hedit_unet_param_name(const hedit_unet* h, int i) {
+  if (!h || i < 0 || i >= (int)h->slots.size()) return nullptr;
+  return h->slots[i].name.c_str();
+}
+
+int hedit_unet_param_shape(const hedit_unet* h, int i, int* ndim, int* dims4) {
+  ARG_CHECK(h && ndim && dims4 && i >= 0 && i < (int)h->slots.size(), "param index");
+  *ndim = h->slots[i].ndim;
+  for (int k = 0; k < 4; ++k) dims4[k] = h->slots[i].dims[k];
+  return HEDIT_OK;
+}
+
+int hedit_unet_load(hedit_unet* h, const char* name, const float* w, size_t numel, void* stream) {
+  ARG_CHECK(h && name && w, "null");
+  auto it = h->index.find(name);
+  if (it == h->index.end()) {
+    hedit_set_error(std::string("unknown parameter: ") + name);
+    return HEDIT_ERR_ARG;
+  }
+  Slot& s = h->slots[it->second];
+  if (s.numel != numel) {
+    hedit_set_error(std::string("size mismatch for ") + name + ": expected " + std::to_string(s.numel) + ", got " + std::to_string(numel));
+    return HEDIT_ERR_ARG;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (s.kind == 0) {
+    HIP_TRY(hipMemcpyAsync(s.dst, w, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else if (s.kind == 1) {
+    TRY(pack_linear_launch(w, reinterpret_cast<bf16_t*>(s.dst), (long)numel, s.scale, st));
+  } else {
+    TRY(pack_conv3x3_launch(w, reinterpret_cast<bf16_t*>(s.dst), s.O, s.I, st));
+  }
+  s.loaded = true;
+  return HEDIT_OK;
+}
+
+int hedit_unet_missing(const hedit_unet* h) {
+  if (!h) return -1;
+  int m = 0;
+  for (auto& s : h->slots) m += s.loaded ? 0 : 1;
+  return m;
+}
+
+size_t hedit_unet_workspace_bytes(hedit_unet* h, int B, int height, int width) {
+  if (!h) return 0;
+  size_t peak = 0;
+  if (forward_impl(h, nullptr, 0.f, nullptr, B, height, width, nullptr, nullptr, nullptr, 0, nullptr, true, &peak) != HEDIT_OK) return 0;
+  return peak + 4096;
+}
+
+int hedit_unet_forward(hedit_unet* h, const float* x, float t, const float* ctx, int B, int height, int width,
+                       const hedit_p2p_plan* plan, float* eps_out, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+  ARG_CHECK(h && x && ctx && eps_out && workspace, "null");
+  ARG_CHECK(B >= 1, "B");
+  const int div = 1 << (h->cfg.n_levels - 1);
+  ARG_CHECK(height % div == 0 && width % div == 0, "latent size must be divisible by 2^(levels-1)");
+  const int lowest = (height / div) * (width / div);
+  ARG_CHECK(lowest % 64 == 0, "lowest-resolution level must have a multiple of 64 tokens");
+  if (hedit_unet_missing(h) != 0) {
+    hedit_set_error("UNet has " + std::to_string(hedit_unet_missing(h)) + " unloaded parameters");
+    return HEDIT_ERR_STATE;
+  }
+  if (plan && plan->mode > 0) {
+    ARG_CHECK(plan->n_pairs >= 0 && plan->n_pairs + plan->n_single > 0, "plan rows");
+    ARG_CHECK(plan->n_pairs == 0 || (plan->pair_src && plan->pair_tar && plan->mixT && plan->bvec), "plan tables");
+  }
+  return forward_impl(h, x, t, ctx, B, height, width, plan, eps_out, workspace, workspace_bytes,
+                      reinterpret_cast<hipStream_t>(stream), false, nullptr);
+}
+
+static void store_layers(const hedit_unet* h, int height, int width, std::vector<std::pair<int, int>>& v) {
+  const hedit_unet_cfg& c = h->cfg;
+  int H = height, W = width;
+  for (int i = 0; i < c.n_levels; ++i) {
+    if (c.down_has_attn[i])
+      for (int j = 0; j < c.layers_per_block; ++j)
+        if (H * W <= 1024) v.push_back({H * W, 0});
+    if (i != c.n_levels - 1) { H /= 2; W /= 2; }
+  }
+  if (H * W <= 1024) v.push_back({H * W, 1});
+  for (int i = 0; i < c.n_levels; ++i) {
+    if (c.up_has_attn[i])
+      for (int j = 0; j < c.layers_per_block + 1; ++j)
+        if (H * W <= 1024) v.push_back({H * W, 2});
+    if (i != c.n_levels - 1) { H *= 2; W *= 2; }
+  }
+}
+
+int hedit_unet_num_store_layers(const hedit_unet* h, int height, int width) {
+  if (!h) return 0;
+  std::vector<std::pair<int, int>> v;
+  store_layers(h, height, width, v);
+  return (int)v.size();
+}
+
+int hedit_unet_store_layer_info(const hedit_unet* h, int height, int width, int i, int* tokens, int* place) {
+  ARG_CHECK(h && tokens && place, "null");
+  std::vector<std::pair<int, int>> v;
+  store_layers(h, height, width, v);
+  ARG_CHECK(i >= 0 && i < (int)v.size(), "layer index");
+  *tokens = v[i].first;
+  *place = v[i].second;
+  return HEDIT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+"""ctypes binding of libhedit_hip.so (include/hedit.h).  Fails loudly if the library is absent."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhedit_hip.so")
+HEDIT_MAX_LEVELS = 8
+
+
+class UnetCfg(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("sample_size", C.c_int),
+                ("n_levels", C.c_int),
+                ("block_out_channels", C.c_int * HEDIT_MAX_LEVELS),
+                ("down_has_attn", C.c_int * HEDIT_MAX_LEVELS),
+                ("up_has_attn", C.c_int * HEDIT_MAX_LEVELS),
+                ("layers_per_block", C.c_int), ("cross_attention_dim", C.c_int),
+                ("heads", C.c_int), ("norm_num_groups", C.c_int)]
+
+
+class P2PPlan(C.Structure):
+    _fields_ = [("mode", C.c_int), ("n_pairs", C.c_int),
+                ("pair_src", C.c_void_p), ("pair_tar", C.c_void_p),
+                ("singles", C.c_void_p), ("n_single", C.c_int),
+                ("qk_src", C.c_void_p), ("mixT", C.c_void_p), ("bvec", C.c_void_p),
+                ("h_store", C.POINTER(C.c_void_p)), ("n_store", C.c_int)]
+
+
+class StepCoef(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("sqrt_ab_t", "sqrt_1m_ab_t", "sqrt_ab_prev", "dir_coef",
+                                         "noise_coef", "w_src", "w_hat", "w_tar", "coeff", "w_rec")]
+
+
+_SIGS = {
+    "hedit_last_error": (C.c_char_p, []),
+    "hedit_version": (C.c_int, []),
+    "hedit_unet_create": (C.c_int, [C.POINTER(UnetCfg), C.POINTER(C.c_void_p)]),
+    "hedit_unet_destroy": (None, [C.c_void_p]),
+    "hedit_unet_num_params": (C.c_int, [C.c_void_p]),
+    "hedit_unet_param_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "hedit_unet_param_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "hedit_unet_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hedit_unet_missing": (C.c_int, [C.c_void_p]),
+    "hedit_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "hedit_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_int, C.POINTER(P2PPlan), C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]),
+    "hedit_unet_num_store_layers": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "hedit_unet_store_layer_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                              C.POINTER(C.c_int)]),
+    "hedit_step_base": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                  C.c_int, C.POINTER(StepCoef), C.c_void_p]),
+    "hedit_step_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(StepCoef),
+                                    C.c_void_p]),
+    "hedit_local_blend": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "hedit_k_gemm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "hedit_k_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 13 +
+                     [C.c_void_p, C.c_void_p]),
+    "hedit_k_groupnorm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "hedit_k_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "hedit_k_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                    C.c_float, C.c_void_p]),
+    "hedit_k_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "hedit_k_self_attn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "hedit_k_cross_attn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(P2PPlan), C.c_void_p,
+                                     C.c_void_p]),
+    "hedit_k_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "hedit_k_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS.keys())
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use).  There is deliberately no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python h-edit_amd/build.py` "
+                "(hipcc --offload-arch=gfx950); hedit has no CPU/eager fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)     # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise HipError(f"libhedit_hip error {rc}: {lib().hedit_last_error().decode()}")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def cur_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,242 @@
+"""Batched h-Edit sampler on the HIP path.
+
+One engine runs n independent images in lock-step (the reference edits one image at a time,
+text-guided/main_p2p.py:110; images are independent, so batching is a pure throughput
+generalisation -- SURVEY.md section 0.1 / 8e).  For n = 1 the sequence of UNet evaluations is the
+reference's, call for call (p2p_h_edit.py:613,644,652 etc.):
+
+    per step:  1 base pass (4n rows, controller off)
+               K x [ 1 source pass (n rows, controller off) + 1 P2P pass (4n rows, controller on) ]
+
+Row layout of every batched tensor is [row-kind][image]: e.g. the P2P pass feeds
+[x_orig|null]*n, [x_k|null]*n, [x_orig|src]*n, [x_k|tar]*n, which for n = 1 is exactly the
+reference's batch.  All arithmetic between UNet calls runs in the fused HIP step kernels
+(csrc/step.hip); the host only computes the scalar schedule coefficients (fp32, same formulas
+as inversion_utils.py:38-56,84-119,168-195) and never synchronises with the device.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _f(x):
+    return float(x)
+
+
+class Schedule:
+    """Scalar coefficient tables of a DDIM scheduler (host, fp32 like the reference)."""
+
+    def __init__(self, scheduler):
+        self.s = scheduler
+        self.ab = scheduler.alphas_cumprod.float().cpu()
+        self.final = scheduler.final_alpha_cumprod.float().cpu() if isinstance(
+            scheduler.final_alpha_cumprod, torch.Tensor) else torch.tensor(float(scheduler.final_alpha_cumprod))
+        self.T = scheduler.num_inference_steps
+        self.n_train = scheduler.config.num_train_timesteps
+
+    def ab_prev(self, t):
+        p = t - self.n_train // self.T
+        return self.ab[p] if p >= 0 else self.final
+
+    def variance(self, t):
+        a_t, a_p = self.ab[t], self.ab_prev(t)
+        return ((1 - a_p) / (1 - a_t)) * (1 - a_t / a_p)
+
+    def full_coeff(self, t, t_prev, eta, ddim_inv):
+        ab = self.ab
+        sig, a = (1 - ab) ** 0.5, ab ** 0.5
+        omega = eta * (sig[t_prev] / (sig[t] * a[t_prev])) * ((ab[t_prev] - ab[t]) ** 0.5)
+        if ddim_inv:
+            omega = 0
+        return (1 - ab[t_prev] - omega ** 2) ** 0.5
+
+    def edit_coeff(self, t, t_prev, eta, ddim_inv):
+        ab = self.ab
+        ratio = (ab ** 0.5)[t_prev] / (ab ** 0.5)[t]
+        return self.full_coeff(t, t_prev, eta, ddim_inv) - ((1 - ab) ** 0.5)[t] * ratio
+
+    def step_coef(self, t, t_prev, eta, ddim_inv, cfg, w_rec=0.0, coeff=None):
+        a_t, a_p = self.ab[t], self.ab_prev(t)
+        var = self.variance(t)
+        c = _lib.StepCoef()
+        c.sqrt_ab_t = _f(a_t ** 0.5)
+        c.sqrt_1m_ab_t = _f((1 - a_t) ** 0.5)
+        c.sqrt_ab_prev = _f(a_p ** 0.5)
+        c.dir_coef = _f((1 - a_p) ** 0.5) if ddim_inv else _f((1 - a_p - (eta ** 2) * var) ** 0.5)
+        c.noise_coef = 0.0 if eta <= 0 else (_f(eta) if ddim_inv else _f(eta * var ** 0.5))
+        c.w_src, c.w_hat, c.w_tar = (float(v) for v in cfg)
+        c.coeff = _f(self.edit_coeff(t, t_prev, eta, ddim_inv)) if coeff is None else _f(coeff)
+        c.w_rec = float(w_rec)
+        return c
+
+
+class HEditEngine:
+    def __init__(self, model):
+        self.model = model
+        self.unet = model.unet
+        self.lib = _lib.lib()
+        self.dev = model.unet.device
+
+    # ------------------------------------------------------------------ kernels
+    def step_base(self, eps, xt, z, out, n, rows, coef):
+        elems = xt[0].numel()
+        _lib.check(self.lib.hedit_step_base(_lib.ptr(eps), _lib.ptr(xt), _lib.ptr(z), _lib.ptr(out), n, elems,
+                                            rows, C.byref(coef), _lib.cur_stream()))
+
+    def step_update(self, e_u_src, e_c_src, e_u_tar, e_c_tar, x_k, x_base, out, n, k_gt0, coef):
+        elems = x_k[0].numel()
+        for t_ in (e_u_src, e_c_src, e_u_tar, e_c_tar, x_k, x_base, out):
+            assert t_.is_contiguous() and t_.dtype == torch.float32
+        _lib.check(self.lib.hedit_step_update(_lib.ptr(e_u_src), _lib.ptr(e_c_src), _lib.ptr(e_u_tar),
+                                              _lib.ptr(e_c_tar), elems, _lib.ptr(x_k), _lib.ptr(x_base),
+                                              _lib.ptr(out), n, elems, int(k_gt0), C.byref(coef),
+                                              _lib.cur_stream()))
+
+    # ------------------------------------------------------------------ text
+    def encode(self, prompts):
+        tok = self.model.tokenizer(prompts, padding="max_length", max_length=self.model.tokenizer.model_max_length,
+                                   truncation=True, return_tensors="pt")
+        with torch.no_grad():
+            return self.model.text_encoder(tok.input_ids.to(self.dev))[0].float()
+
+    # ------------------------------------------------------------------ the loop
+    @torch.no_grad()
+    def run(self, xT, zs, prompt_pairs, cfg_scales, controller=None, eta=1.0, p2p=True, implicit=True,
+            K=1, w_rec=0.1, after_skip_steps=None, ddim_inv=False, ctx=None):
+        """xT: (n,C,H,W); zs: (T',n,C,H,W) or None; prompt_pairs: n x [src, tar].
+        ctx: optional precomputed (null, src, tar) embeddings ((1|n,77,D), (n,77,D), (n,77,D)).
+        Returns (edit (n,C,H,W), recon (n,C,H,W))."""
+        sch = self.model.scheduler
+        S = Schedule(sch)
+        T = sch.num_inference_steps
+        if after_skip_steps is None:
+            after_skip_steps = T
+        n = xT.shape[0]
+        dev = self.dev
+        xT = xT.to(device=dev, dtype=torch.float32)
+        if zs is not None:
+            zs = zs.to(device=dev, dtype=torch.float32).contiguous()
+        if ctx is None:
+            null = self.encode([""])
+            src = self.encode([p[0] for p in prompt_pairs])
+            tar = self.encode([p[1] for p in prompt_pairs])
+        else:
+            null, src, tar = (c.to(device=dev, dtype=torch.float32) for c in ctx)
+        nulln = null.expand(n, -1, -1) if null.shape[0] == 1 else null
+        ctx_base4 = torch.cat([nulln, nulln, src, src]).contiguous()
+        ctx_base2 = torch.cat([nulln, src]).contiguous()
+        ctx_edit = torch.cat([nulln, nulln, src, tar]).contiguous()
+        ctx_src = src.contiguous()
+
+        ts = [int(v) for v in sch.timesteps]
+        op = ts[-after_skip_steps:]
+        ahead = ts[-(after_skip_steps + 1)] if after_skip_steps != T else -1
+        xt = torch.cat([xT, xT]).contiguous()          # [x_orig]*n, [x_edit]*n
+        x_prev = torch.empty_like(xt)
+        off = None
+
+        def p2p_pass(x_in, t, save):
+            plan = controller._plan(self.unet, 4 * n, x_in.shape[2], x_in.shape[3], save)
+            e = self.unet.forward_raw(x_in, t, ctx_edit, plan)
+            controller._after_pass(save)
+            return e
+
+        for i, t in enumerate(op):
+            idx = T - i - (T - after_skip_steps + 1)
+            z = zs[idx] if zs is not None else None
+            tt = op[i + 1] if i < len(op) - 1 else 0
+            coef = S.step_coef(t, tt, eta, ddim_inv, cfg_scales, w_rec)
+
+            if (not p2p) and implicit and i == 0 and ahead != -1:
+                # one extra correction of the start sample when steps were skipped (p2p_h_edit.py:239-267)
+                xe = xt[n:]
+                e = self.unet.forward_raw(torch.cat([xe] * 4), t, ctx_edit, off)
+                c0 = S.step_coef(t, tt, eta, ddim_inv, cfg_scales, w_rec, coeff=S.edit_coeff(ahead, t, eta, ddim_inv))
+                new = torch.empty_like(xe)
+                self.step_update(e[0:n], e[2 * n:3 * n], e[n:2 * n], e[3 * n:], xe, xe, new, n, False, c0)
+                xt = torch.cat([xt[:n], new]).contiguous()
+
+            # ---- base pass -> x_{t-1}^orig, x_{t-1}^base
+            if p2p:
+                e = self.unet.forward_raw(torch.cat([xt, xt]), t, ctx_base4, off)
+                self.step_base(e, xt, z, x_prev, n, 4, coef)
+            else:
+                e = self.unet.forward_raw(torch.cat([xt[n:], xt[n:]]), t, ctx_base2, off)
+                self.step_base(e, xt, z, x_prev, n, 2, coef)
+            x_orig, x_base = x_prev[:n], x_prev[n:]
+
+            if not implicit:
+                new = torch.empty_like(x_base)
+                if p2p:
+                    e_src = self.unet.forward_raw(xt[n:].contiguous(), t, ctx_src, off)
+                    e = p2p_pass(torch.cat([xt, xt]), t, True)
+                    self.step_update(e[n:2 * n], e_src, e[n:2 * n], e[3 * n:], x_base, x_base, new, n, False, coef)
+                else:
+                    e = self.unet.forward_raw(torch.cat([xt[n:]] * 4), t, ctx_edit, off)
+                    self.step_update(e[0:n], e[2 * n:3 * n], e[n:2 * n], e[3 * n:], x_base, x_base, new, n, False, coef)
+                x_k = new
+            else:
+                x_k = x_base.clone()
+                for k in range(K):
+                    new = torch.empty_like(x_k)
+                    if p2p:
+                        save = not (k < K - 1 and K > 1)
+                        e_src = self.unet.forward_raw(x_k, tt, ctx_src, off)
+                        e = p2p_pass(torch.cat([x_orig, x_k, x_orig, x_k]), tt, save)
+                        self.step_update(e[n:2 * n], e_src, e[n:2 * n], e[3 * n:], x_k, x_base, new, n, k > 0, coef)
+                    else:
+                        e = self.unet.forward_raw(torch.cat([x_k] * 4), tt, ctx_edit, off)
+                        self.step_update(e[0:n], e[2 * n:3 * n], e[n:2 * n], e[3 * n:], x_k, x_base, new, n, k > 0, coef)
+                    x_k = new
+
+            xt = torch.cat([x_orig, x_k]).contiguous()
+            if controller is not None:
+                xt = controller.step_callback(xt)
+        return xt[n:].clone(), xt[:n].clone()
+
+    # ------------------------------------------------------------------ DDPM inversion
+    @torch.no_grad()
+    def ddpm_inversion(self, x0, prompts, eta=1.0, cfg_src=1.0, noise=None, generator=None):
+        """Edit-friendly DDPM inversion for n images (ddpm_inversion.py:54-167).
+        x0 (n,C,H,W); prompts: n source prompts ("" = unconditional).  noise: optional
+        (T+1,n,C,H,W) tensor of the forward-process noises (row idx as in the reference).
+        Returns zs (T,n,C,H,W), xts (T+1,n,C,H,W)."""
+        sch = self.model.scheduler
+        S = Schedule(sch)
+        T = sch.num_inference_steps
+        dev = self.dev
+        x0 = x0.to(device=dev, dtype=torch.float32)
+        n = x0.shape[0]
+        ts = [int(v) for v in sch.timesteps]
+        ab = S.ab
+        xts = torch.zeros(T + 1, *x0.shape, device=dev)
+        xts[0] = x0
+        for j, t in enumerate(reversed(ts)):
+            idx = j + 1
+            if noise is not None:
+                nz = noise[idx].to(dev)
+            else:
+                nz = torch.randn(x0.shape, device=dev, generator=generator)
+            xts[idx] = x0 * _f(ab[t] ** 0.5) + nz * _f((1 - ab[t]) ** 0.5)
+        null = self.encode([""]).expand(n, -1, -1)
+        cond = all(p != "" for p in prompts)
+        ctx = torch.cat([null, self.encode(list(prompts))]).contiguous() if cond else null.contiguous()
+        zs = torch.zeros(T, *x0.shape, device=dev)
+        for i, t in enumerate(ts):
+            idx = T - i - 1
+            xt = xts[idx + 1]
+            if cond:
+                e = self.unet.forward_raw(torch.cat([xt, xt]), t, ctx)
+                eps = e[:n] + cfg_src * (e[n:] - e[:n])
+            else:
+                eps = self.unet.forward_raw(xt.contiguous(), t, ctx)
+            a_t, a_p, var = ab[t], S.ab_prev(t), S.variance(t)
+            x0_hat = (xt - _f((1 - a_t) ** 0.5) * eps) / _f(a_t ** 0.5)
+            mu = _f(a_p ** 0.5) * x0_hat + _f((1 - a_p - (eta ** 2) * var) ** 0.5) * eps
+            sig = _f(eta * var ** 0.5)
+            z = (xts[idx] - mu) / sig
+            zs[idx] = z
+            xts[idx] = mu + sig * z
+        return zs, xts

@@ -1,0 +1,20 @@
+"""Edit-friendly DDPM inversion (mirrors text-guided/inversion/ddpm_inversion.py:
+sample_xts_from_x0 :5-52, inversion_forward_process_ddpm :54-167) on the HIP UNet."""
+import torch
+
+from ..engine import HEditEngine
+
+
+def inversion_forward_process_ddpm(model, x0, etas=None, prog_bar=True, prompt="", cfg_scale_src=1.0,
+                                   cfg_scale_src_edit=3.5, num_inference_steps=50, noise=None, generator=None):
+    """Returns (xt, zs, xts, noise_added) like the reference: zs (T,C,H,W), xts (T+1,C,H,W).
+    `noise` (T+1,C,H,W) lets the caller fix the forward-process noise (parity tests)."""
+    if etas is None or (type(etas) in [int, float] and etas == 0):
+        raise AssertionError("eta must be > 0 for DDPM inversion")   # reference: assert not eta_is_zero
+    eta = float(etas) if type(etas) in [int, float] else float(etas[0])
+    assert model.scheduler.num_inference_steps == num_inference_steps
+    eng = HEditEngine(model)
+    x = x0 if x0.dim() == 4 else x0[None]
+    nz = None if noise is None else noise[:, None]
+    zs, xts = eng.ddpm_inversion(x, [prompt], eta=eta, cfg_src=cfg_scale_src, noise=nz, generator=generator)
+    return xts[1], zs[:, 0], xts[:, 0], nz

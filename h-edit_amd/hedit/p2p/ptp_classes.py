@@ -1,0 +1,393 @@
+"""Prompt-to-Prompt controllers for the HIP path.
+
+Class names, constructor arguments and public attributes follow the reference's
+text-guided/p2p/ptp_classes.py (LocalBlend :17-72, AttentionControl :74-118, AttentionStore
+:124-160, AttentionControlEdit :162-227, AttentionReplace :229-243, AttentionRefine :245-262,
+AttentionReweight :264-283, get_equalizer :285-294, load_512 :351-373), so driver code written
+for the reference runs unchanged.  What differs is WHERE the edit executes: instead of mutating a
+materialised probability tensor from Python 32 times per UNet call, a controller compiles, once,
+the per-step tables
+
+    P_new = P_src . A_s + bvec_s * P_tar          (A_s: 77x77, bvec_s: 77, s = cur_step)
+
+that encode Replace / Refine / Reweight plus the cross_replace_alpha blend, and hands the HIP
+cross-attention kernel a pointer into them; self-attention replacement becomes "the target row
+reads the source row's Q and K".  The attention store keeps the cross maps only (the reference
+also keeps <=32x32 self maps but nothing on the h-Edit path reads them) and is accumulated
+in-kernel on save_attn passes.
+
+A controller edits ONE (source, target) prompt pair, exactly like the reference;
+``ControllerBatch`` stacks several for image-batched sampling (build-side generalisation,
+SURVEY.md section 0.1).
+"""
+import abc
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from . import ptp_utils, seq_aligner
+
+LOW_RESOURCE = False
+MAX_NUM_WORDS = 77
+WPAD = 96
+
+
+class LocalBlend:
+    def __init__(self, prompts, num_steps, words, substruct_words=None, start_blend=0.2, th=(.3, .3),
+                 tokenizer=None, device=None):
+        if substruct_words is not None:
+            raise NotImplementedError("substruct_words is unused by the h-Edit drivers")
+        self.max_num_words = MAX_NUM_WORDS
+        alpha_layers = torch.zeros(len(prompts), 1, 1, 1, 1, self.max_num_words)
+        for i, (prompt, words_) in enumerate(zip(prompts, words)):
+            if isinstance(words_, str):
+                words_ = [words_]
+            for word in words_:
+                ind = ptp_utils.get_word_inds(prompt, word, tokenizer)
+                alpha_layers[i, :, :, :, :, ind] = 1
+        self.substruct_layers = None
+        self.alpha_layers = alpha_layers.to(device) if device is not None else alpha_layers
+        self.start_blend = int(start_blend * num_steps)
+        self.counter = 0
+        self.th = th
+
+    def __call__(self, x_t, attention_store):
+        self.counter += 1
+        if self.counter > self.start_blend:
+            maps = attention_store["down_cross"][2:4] + attention_store["up_cross"][:3]
+            _blend_launch(x_t, maps, [self], 1)
+        return x_t
+
+
+def _blend_launch(x_t, maps, blends, n_img):
+    """x_t: (2*n_img, C, H, W) fp32 cuda laid out [x_orig * n, x_edit * n]; edited in place."""
+    lib = _lib.lib()
+    if x_t.dtype != torch.float32 or not x_t.is_cuda or not x_t.is_contiguous():
+        raise TypeError("LocalBlend expects a contiguous float32 CUDA latent")
+    for m in maps:
+        if m.shape[-2] != 256:
+            raise ValueError("LocalBlend reads 16x16 cross maps (reference hard-codes 16x16: "
+                             "ptp_classes.py:59-62)")
+    heads = maps[0].numel() // (n_img * 2 * 256 * MAX_NUM_WORDS)
+    alpha = torch.zeros(n_img, 2, MAX_NUM_WORDS)
+    enabled = torch.zeros(n_img, dtype=torch.int32)
+    th = 0.3
+    for i, lb in enumerate(blends):
+        if lb is not None:
+            alpha[i] = lb.alpha_layers.reshape(2, MAX_NUM_WORDS).cpu()
+            enabled[i] = 1
+            th = lb.th[0]
+    alpha = alpha.to(x_t.device)
+    enabled = enabled.to(x_t.device)
+    arr = (C.c_void_p * len(maps))(*[m.data_ptr() for m in maps])
+    _, Cc, H, W = x_t.shape
+    _lib.check(lib.hedit_local_blend(arr, len(maps), heads, _lib.ptr(alpha), _lib.ptr(enabled),
+                                     _lib.ptr(x_t), n_img, Cc, H, W, C.c_float(th), _lib.cur_stream()))
+    # alpha / enabled are consumed by a stream-ordered kernel: keep them alive on the tensor
+    x_t._hedit_keep = (alpha, enabled)
+
+
+class AttentionControl(abc.ABC):
+    def __init__(self):
+        self.cur_step = 0
+        self.num_att_layers = -1
+        self.cur_att_layer = 0
+
+    @property
+    def num_uncond_att_layers(self):
+        return self.num_att_layers if LOW_RESOURCE else 0
+
+    def step_callback(self, x_t):
+        return x_t
+
+    def between_steps(self):
+        return
+
+    def reset(self):
+        self.cur_step = 0
+        self.cur_att_layer = 0
+
+    # ---- protocol with hedit.unet.UNet2DConditionModel
+    def _after_pass(self, save_attn):
+        """What the reference's per-layer ``__call__`` bookkeeping amounts to after one full UNet
+        pass over num_att_layers layers (ptp_classes.py:100-108)."""
+        if not save_attn:
+            return
+        self.cur_att_layer = 0
+        self.cur_step += 1
+        self.between_steps()
+
+    def _plan(self, unet, B, H, W, save_attn):
+        return None
+
+
+class EmptyControl(AttentionControl):
+    pass
+
+
+class _PlanState:
+    """Device-side tables + store buffers for a list of per-image controllers."""
+
+    def __init__(self, members, unet, B, H, W):
+        n = len(members)
+        if B != 4 * n:
+            raise ValueError(f"a P2P pass over {n} image(s) expects a batch of {4 * n} rows laid out "
+                             f"[x_orig|null]*n, [x_edit|null]*n, [x_orig|src]*n, [x_edit|tar]*n; got {B}")
+        dev = unet.device
+        self.key = (id(unet), B, H, W)
+        self.n = n
+        ar = torch.arange(B, dtype=torch.int32)
+        self.pair_src = ar[2 * n:3 * n].contiguous().to(dev)
+        self.pair_tar = ar[3 * n:4 * n].contiguous().to(dev)
+        self.singles = ar[:2 * n].contiguous().to(dev)
+        qk = ar.clone()
+        qk[3 * n:4 * n] = ar[2 * n:3 * n]
+        self.qk_src = qk.to(dev)
+        T1 = members[0]._n_table_steps()
+        mixT = torch.zeros(T1, n, WPAD, WPAD)
+        bvec = torch.zeros(T1, n, WPAD)
+        for i, m in enumerate(members):
+            A, b = m._mix_tables()                      # (T1,77,77), (T1,77)
+            mixT[:, i, :MAX_NUM_WORDS, :MAX_NUM_WORDS] = A.transpose(1, 2)
+            bvec[:, i, :MAX_NUM_WORDS] = b
+        self.mixT = mixT.to(torch.bfloat16).contiguous().to(dev)
+        self.bvec = bvec.contiguous().to(dev)
+        self.layers = unet.store_layers(H, W)
+        heads = unet.heads
+        self.bufs = [torch.zeros(n, 2, heads, tok, MAX_NUM_WORDS, dtype=torch.float32, device=dev)
+                     for tok, _ in self.layers]
+        self.h_store = (C.c_void_p * len(self.bufs))(*[b.data_ptr() for b in self.bufs])
+        store = {f"{p}_{k}": [] for k in ("cross", "self") for p in ("down", "mid", "up")}
+        for (tok, place), buf in zip(self.layers, self.bufs):
+            view = buf.reshape(2 * heads, tok, MAX_NUM_WORDS) if n == 1 else buf.reshape(n, 2 * heads, tok, MAX_NUM_WORDS)
+            store[f"{place}_cross"].append(view)
+        self.attention_store = store
+
+    def plan(self, cur_step, self_window, save_attn, edit=True):
+        p = _lib.P2PPlan()
+        p.mode = 2 if save_attn else 1
+        p.n_pairs = self.n
+        p.pair_src = self.pair_src.data_ptr()
+        p.pair_tar = self.pair_tar.data_ptr()
+        p.singles = self.singles.data_ptr()
+        p.n_single = 2 * self.n
+        in_window = edit and self_window[0] <= cur_step < self_window[1]
+        p.qk_src = self.qk_src.data_ptr() if in_window else None
+        s = min(cur_step, self.mixT.shape[0] - 1)
+        p.mixT = self.mixT[s].data_ptr()
+        p.bvec = self.bvec[s].data_ptr()
+        p.h_store = C.cast(self.h_store, C.POINTER(C.c_void_p))
+        p.n_store = len(self.bufs)
+        return p
+
+
+class AttentionStore(AttentionControl):
+    def __init__(self):
+        super().__init__()
+        self.step_store = self.get_empty_store()
+        self.attention_store = {}
+        self._state = None
+
+    @staticmethod
+    def get_empty_store():
+        return {"down_cross": [], "mid_cross": [], "up_cross": [],
+                "down_self": [], "mid_self": [], "up_self": []}
+
+    def get_average_attention(self):
+        return {k: [item / self.cur_step for item in v] for k, v in self.attention_store.items()}
+
+    def reset(self):
+        super().reset()
+        self.step_store = self.get_empty_store()
+        self.attention_store = {}
+        if self._state is not None:
+            for b in self._state.bufs:
+                b.zero_()
+
+    # ---- plan protocol
+    def _members(self):
+        return [self]
+
+    def _n_table_steps(self):
+        return 1
+
+    def _mix_tables(self):
+        """store-only controller: identity edit (P_new = P_tar)."""
+        return torch.zeros(1, MAX_NUM_WORDS, MAX_NUM_WORDS), torch.ones(1, MAX_NUM_WORDS)
+
+    def _self_window(self):
+        return (0, 0)
+
+    def _plan(self, unet, B, H, W, save_attn):
+        members = self._members()
+        if self._state is None or self._state.key != (id(unet), B, H, W):
+            self._state = _PlanState(members, unet, B, H, W)
+        if save_attn and not self.attention_store:
+            self.attention_store = self._state.attention_store
+        self._live_plan = self._state.plan(self.cur_step, self._self_window(), save_attn)
+        return self._live_plan
+
+
+class AttentionControlEdit(AttentionStore, abc.ABC):
+    def __init__(self, prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend,
+                 tokenizer, device):
+        super().__init__()
+        self.tokenizer = tokenizer
+        self.device = device
+        self.batch_size = len(prompts)
+        if self.batch_size != 2:
+            raise NotImplementedError("one (source, target) prompt pair per controller, as in the "
+                                      "h-Edit drivers; stack controllers with ControllerBatch")
+        self.cross_replace_alpha = ptp_utils.get_time_words_attention_alpha(
+            prompts, num_steps, cross_replace_steps, self.tokenizer)
+        if isinstance(self_replace_steps, float):
+            self_replace_steps = 0, self_replace_steps
+        self.num_self_replace = int(num_steps * self_replace_steps[0]), int(num_steps * self_replace_steps[1])
+        self.local_blend = local_blend
+
+    @abc.abstractmethod
+    def replace_cross_attention(self, attn_base, att_replace):
+        """Same contract as the reference (attn_base (h,p,77), att_replace (1,h,p,77)); used on
+        the host, on basis vectors, to derive the mixing tables."""
+        raise NotImplementedError
+
+    def step_callback(self, x_t):
+        if self.local_blend is not None:
+            x_t = self.local_blend(x_t, self.attention_store)
+        return x_t
+
+    def _self_window(self):
+        return self.num_self_replace
+
+    def _n_table_steps(self):
+        return self.cross_replace_alpha.shape[0]
+
+    def _mix_tables(self):
+        """Probe replace_cross_attention (linear in attn_base, diagonal in att_replace) with basis
+        inputs, then fold in the per-step alpha blend of AttentionControlEdit.forward
+        (ptp_classes.py:215-220):  new = R(base, repl) * a_s + (1 - a_s) * repl."""
+        W = MAX_NUM_WORDS
+        eye = torch.eye(W).reshape(1, W, W)                         # h=1, p=w index, n
+        zero = torch.zeros(1, 1, W, W)
+        A = self.replace_cross_attention(eye, zero).reshape(W, W)   # A[w][n]
+        one = torch.ones(1, 1, 1, W)
+        b = self.replace_cross_attention(torch.zeros(1, 1, W), one).reshape(W)
+        alpha = self.cross_replace_alpha[:, 0, 0, 0, :].float().cpu()      # (T+1, 77)
+        A_s = A[None] * alpha[:, None, :]
+        b_s = b[None] * alpha + (1 - alpha)
+        return A_s, b_s
+
+
+class AttentionReplace(AttentionControlEdit):
+    def __init__(self, prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend=None,
+                 tokenizer=None, device=None):
+        super().__init__(prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend, tokenizer, device)
+        self.mapper = seq_aligner.get_replacement_mapper(prompts, self.tokenizer)
+
+    def replace_cross_attention(self, attn_base, att_replace):
+        return torch.einsum("hpw,bwn->bhpn", attn_base, self.mapper)
+
+
+class AttentionRefine(AttentionControlEdit):
+    def __init__(self, prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend=None,
+                 tokenizer=None, device=None):
+        super().__init__(prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend, tokenizer, device)
+        self.mapper, alphas = seq_aligner.get_refinement_mapper(prompts, self.tokenizer)
+        self.alphas = alphas.reshape(alphas.shape[0], 1, 1, alphas.shape[1])
+
+    def replace_cross_attention(self, attn_base, att_replace):
+        base = attn_base[:, :, self.mapper].permute(2, 0, 1, 3)
+        return base * self.alphas + att_replace * (1 - self.alphas)
+
+
+class AttentionReweight(AttentionControlEdit):
+    def __init__(self, prompts, num_steps, cross_replace_steps, self_replace_steps, equalizer,
+                 local_blend=None, controller=None, tokenizer=None, device=None):
+        super().__init__(prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend, tokenizer, device)
+        self.equalizer = equalizer
+        self.prev_controller = controller
+
+    def replace_cross_attention(self, attn_base, att_replace):
+        if self.prev_controller is not None:
+            attn_base = self.prev_controller.replace_cross_attention(attn_base, att_replace)
+            return attn_base * self.equalizer[:, None, None, :]
+        return attn_base[None, :, :, :] * self.equalizer[:, None, None, :]
+
+
+class ControllerBatch(AttentionStore):
+    """Several single-pair controllers driven in lock-step over an image batch.
+    UNet batch layout: [x_orig|null]*n, [x_edit|null]*n, [x_orig|src]*n, [x_edit|tar]*n."""
+
+    def __init__(self, controllers):
+        super().__init__()
+        if not controllers:
+            raise ValueError("empty controller batch")
+        self.controllers = list(controllers)
+        win = {c._self_window() for c in self.controllers}
+        steps = {c._n_table_steps() for c in self.controllers}
+        if len(win) != 1 or len(steps) != 1:
+            raise ValueError("controllers of one batch must share num_steps and self_replace_steps")
+
+    @property
+    def n_images(self):
+        return len(self.controllers)
+
+    def _members(self):
+        return self.controllers
+
+    def _self_window(self):
+        return self.controllers[0]._self_window()
+
+    def _n_table_steps(self):
+        return self.controllers[0]._n_table_steps()
+
+    def step_callback(self, x_t):
+        blends = [getattr(c, "local_blend", None) for c in self.controllers]
+        live = [b for b in blends if b is not None]
+        if not live:
+            return x_t
+        for b in live:
+            b.counter += 1
+        if live[0].counter > live[0].start_blend:
+            maps = self.attention_store["down_cross"][2:4] + self.attention_store["up_cross"][:3]
+            _blend_launch(x_t, maps, blends, len(blends))
+        return x_t
+
+
+def get_equalizer(text, word_select, values, tokenizer):
+    if isinstance(word_select, (int, str)):
+        word_select = (word_select,)
+    equalizer = torch.ones(len(values), 77)
+    values = torch.tensor(values, dtype=torch.float32)
+    for word in word_select:
+        inds = ptp_utils.get_word_inds(text, word, tokenizer)
+        equalizer[:, inds] = values
+    return equalizer
+
+
+def load_512(image_path, left=0, right=0, top=0, bottom=0, device=None):
+    """Centre-crop to a square and resize to 512x512, range [-1,1], (1,3,512,512).
+    Reference: ptp_classes.py:351-373 (including its `top = min(top, h - left - 1)` quirk)."""
+    from PIL import Image
+    if isinstance(image_path, str):
+        image = np.array(Image.open(image_path).convert("RGB"))[:, :, :3]
+    else:
+        image = image_path
+    h, w, _ = image.shape
+    left = min(left, w - 1)
+    right = min(right, w - left - 1)
+    top = min(top, h - left - 1)
+    bottom = min(bottom, h - top - 1)
+    image = image[top:h - bottom, left:w - right]
+    h, w, _ = image.shape
+    if h < w:
+        off = (w - h) // 2
+        image = image[:, off:off + h]
+    elif w < h:
+        off = (h - w) // 2
+        image = image[off:off + w]
+    image = np.array(Image.fromarray(image).resize((512, 512)))
+    image = torch.from_numpy(image).float() / 127.5 - 1
+    return image.permute(2, 0, 1).unsqueeze(0).to(device)

@@ -1,0 +1,100 @@
+"""Tokenizer / text-encoder stand-ins for offline runs.
+
+The reference takes both from the SD pipeline (transformers CLIPTokenizer / CLIPTextModel,
+text-guided/inversion/inversion_utils.py:25-33) and calls them twice per image -- they are not on
+the accelerated path and no vocabulary / weights exist offline.  These classes
+give the same call surface with synthetic weights; real transformers objects can be passed to
+HEditPipeline instead.
+"""
+import math
+import types
+
+import torch
+import torch.nn as nn
+
+
+class WordTokenizer:
+    """Whitespace word-level tokenizer with the CLIPTokenizer surface used by the path
+    (``__call__(...).input_ids``, ``encode``, ``decode``, ``model_max_length``)."""
+    model_max_length = 77
+    bos_token_id, eos_token_id = 49406, 49407
+
+    def __init__(self, vocab_size=49408):
+        self.vocab_size = vocab_size
+        self._ids = {}
+        self._words = {}
+
+    def _id(self, w):
+        if w not in self._ids:
+            i = 1 + len(self._ids)
+            if i >= self.bos_token_id:
+                raise RuntimeError("WordTokenizer vocabulary exhausted")
+            self._ids[w] = i
+            self._words[i] = w
+        return self._ids[w]
+
+    def encode(self, text):
+        return [self.bos_token_id] + [self._id(w) for w in text.split(" ") if w != ""] + [self.eos_token_id]
+
+    def decode(self, ids):
+        sp = {self.bos_token_id: "<|startoftext|>", self.eos_token_id: "<|endoftext|>"}
+        return "".join(sp.get(int(i), self._words.get(int(i), "?")) for i in ids)
+
+    def __call__(self, prompts, padding="max_length", max_length=None, truncation=True, return_tensors="pt"):
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        max_length = max_length or self.model_max_length
+        rows = []
+        for p in prompts:
+            ids = self.encode(p)[:max_length]
+            rows.append(ids + [self.eos_token_id] * (max_length - len(ids)))
+        return types.SimpleNamespace(input_ids=torch.tensor(rows, dtype=torch.int64))
+
+
+class ClipTextEncoder(nn.Module):
+    """CLIP-text-shaped transformer (pre-LN, causal, quick-GELU) with seeded random weights.
+    forward(ids) -> (last_hidden_state,) like transformers' CLIPTextModel."""
+
+    def __init__(self, dim=768, layers=12, heads=12, vocab=49408, max_len=77, seed=7):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.dim, self.heads = dim, heads
+        self.tok = nn.Parameter(torch.randn(vocab, dim, generator=g) * 0.02)
+        self.pos = nn.Parameter(torch.randn(max_len, dim, generator=g) * 0.01)
+        blk = []
+        for _ in range(layers):
+            blk.append(nn.ParameterDict({
+                "ln1_w": nn.Parameter(torch.ones(dim)), "ln1_b": nn.Parameter(torch.zeros(dim)),
+                "qkv": nn.Parameter(torch.randn(3 * dim, dim, generator=g) / math.sqrt(dim)),
+                "qkv_b": nn.Parameter(torch.zeros(3 * dim)),
+                "out": nn.Parameter(torch.randn(dim, dim, generator=g) / math.sqrt(dim)),
+                "out_b": nn.Parameter(torch.zeros(dim)),
+                "ln2_w": nn.Parameter(torch.ones(dim)), "ln2_b": nn.Parameter(torch.zeros(dim)),
+                "fc1": nn.Parameter(torch.randn(4 * dim, dim, generator=g) / math.sqrt(dim)),
+                "fc1_b": nn.Parameter(torch.zeros(4 * dim)),
+                "fc2": nn.Parameter(torch.randn(dim, 4 * dim, generator=g) / math.sqrt(4 * dim)),
+                "fc2_b": nn.Parameter(torch.zeros(dim)),
+            }))
+        self.blocks = nn.ModuleList(blk)
+        self.lnf_w = nn.Parameter(torch.ones(dim))
+        self.lnf_b = nn.Parameter(torch.zeros(dim))
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def forward(self, ids):
+        F = torch.nn.functional
+        b, n = ids.shape
+        h = self.tok[ids] + self.pos[:n][None]
+        mask = torch.full((n, n), float("-inf"), device=h.device).triu(1)
+        hd = self.dim // self.heads
+        for p in self.blocks:
+            x = F.layer_norm(h, (self.dim,), p["ln1_w"], p["ln1_b"])
+            q, k, v = F.linear(x, p["qkv"], p["qkv_b"]).chunk(3, dim=-1)
+            q, k, v = (t.reshape(b, n, self.heads, hd).transpose(1, 2) for t in (q, k, v))
+            a = (q @ k.transpose(-1, -2)) * hd ** -0.5 + mask
+            o = (a.softmax(-1) @ v).transpose(1, 2).reshape(b, n, self.dim)
+            h = h + F.linear(o, p["out"], p["out_b"])
+            x = F.layer_norm(h, (self.dim,), p["ln2_w"], p["ln2_b"])
+            x = F.linear(x, p["fc1"], p["fc1_b"])
+            h = h + F.linear(x * torch.sigmoid(1.702 * x), p["fc2"], p["fc2_b"])
+        return (F.layer_norm(h, (self.dim,), self.lnf_w, self.lnf_b),)

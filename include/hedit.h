@@ -1,0 +1,153 @@
+/* libhedit_hip.so -- C ABI of the MI355X-native h-Edit hot path.
+ *
+ * The reference (nktoan/h-edit) is pure Python on third-party CUDA libraries and has NO FFI of
+ * its own; the boundary below is therefore build-defined and sits exactly
+ * where the reference's Python hands work to "the device":
+ *
+ *   hedit_unet_forward      replaces  model.unet(x, t, encoder_hidden_states=..,
+ *                                     cross_attention_kwargs=..).sample
+ *                           call sites text-guided/inversion/p2p_h_edit.py:98,123,245,281,315,458,
+ *                                     484,492,613,644,652 and ddpm_inversion.py:130,132
+ *                           including the P2P processor/controller body that the reference runs
+ *                           inside every attention layer (text-guided/p2p/ptp_utils.py:65-122,
+ *                           text-guided/p2p/ptp_classes.py:91-108,135-150,202-227)
+ *   hedit_step_base         replaces  CFG mix + reverse_step  (p2p_h_edit.py:614-622 /
+ *                                     inversion/inversion_utils.py:84-119)
+ *   hedit_step_update       replaces  the three CFG mixes, correction, L1 reconstruction pull with
+ *                                     its two .item() syncs, and the x_{t-1} update
+ *                                     (p2p_h_edit.py:654-692; twins :317-353, :494-514, :125-147)
+ *   hedit_local_blend       replaces  LocalBlend.__call__/get_mask (p2p/ptp_classes.py:44-72)
+ *   hedit_k_*               single-kernel entry points used by the parity tests
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  Every pointer is a DEVICE pointer unless the
+ *     parameter name starts with h_ .  The caller (PyTorch-ROCm host code) owns every buffer
+ *     including the workspace; the library owns only the opaque handle and its packed weights.
+ *   - stream-ordered: nothing here synchronises the device; `stream` is a hipStream_t.
+ *   - returns 0 on success, a negative code otherwise; hedit_last_error() gives the message of
+ *     the last failure on the calling thread.  Never throws, never exits.
+ *   - activations inside the UNet are NHWC bf16; latents/eps at the boundary are fp32 NCHW,
+ *     exactly the tensors the reference loop holds.
+ */
+#ifndef HEDIT_H
+#define HEDIT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HEDIT_MAX_LEVELS 8
+
+typedef struct hedit_unet hedit_unet;
+
+/* Architecture of a UNet2DConditionModel (diffusers naming). */
+typedef struct {
+  int in_channels, out_channels, sample_size;
+  int n_levels;
+  int block_out_channels[HEDIT_MAX_LEVELS];
+  int down_has_attn[HEDIT_MAX_LEVELS]; /* CrossAttnDownBlock2D (1) / DownBlock2D (0)            */
+  int up_has_attn[HEDIT_MAX_LEVELS];   /* CrossAttnUpBlock2D (1) / UpBlock2D (0), up-block order */
+  int layers_per_block;
+  int cross_attention_dim;
+  int heads;                           /* "attention_head_dim" of SD-1.x = number of heads      */
+  int norm_num_groups;
+} hedit_unet_cfg;
+
+/* Per-call Prompt-to-Prompt plan = the state the reference's controller holds, compiled by the
+ * host for ONE UNet call (hedit/p2p/plan.py).  All arrays are device memory. */
+typedef struct {
+  int mode;                 /* 0: controller off; 1: apply edits; 2: apply edits + accumulate store */
+  int n_pairs;              /* (source-conditional row, target-conditional row) pairs in the batch  */
+  const int32_t* pair_src;  /* [n_pairs] */
+  const int32_t* pair_tar;  /* [n_pairs] */
+  const int32_t* singles;   /* [n_single] batch rows not in any pair                                */
+  int n_single;
+  const int32_t* qk_src;    /* [B] self-attention replacement map for layers with <= 32*32 tokens
+                               (row b uses q,k of row qk_src[b]); NULL outside the self window      */
+  const void* mixT;         /* bf16 [n_pairs][96][96], mixT[n][w] = A[w][n]                         */
+  const float* bvec;        /* [n_pairs][96]:  P_new = P_src . A + bvec * P_tar                     */
+  float* const* h_store;    /* HOST array of n_store device pointers, one per cross-attention layer
+                               with <= 32*32 tokens in call order; each [n_pairs][2][heads][N][77]  */
+  int n_store;
+} hedit_p2p_plan;
+
+typedef struct {
+  float sqrt_ab_t, sqrt_1m_ab_t, sqrt_ab_prev, dir_coef, noise_coef;
+  float w_src, w_hat, w_tar, coeff, w_rec;
+} hedit_step_coef;
+
+const char* hedit_last_error(void);
+int hedit_version(void);
+
+/* ---- UNet ------------------------------------------------------------------------------- */
+int hedit_unet_create(const hedit_unet_cfg* cfg, hedit_unet** out);
+void hedit_unet_destroy(hedit_unet* h);
+/* number of parameters the handle expects; name of the i-th one (diffusers state_dict key) */
+int hedit_unet_num_params(const hedit_unet* h);
+const char* hedit_unet_param_name(const hedit_unet* h, int i);
+/* torch shape of the i-th parameter: *ndim in 1..4, dims4[0..ndim) */
+int hedit_unet_param_shape(const hedit_unet* h, int i, int* ndim, int* dims4);
+/* hand one fp32 parameter tensor (torch layout, device memory) to the library, which packs it
+ * into its own bf16/fp32 GEMM layout on `stream` */
+int hedit_unet_load(hedit_unet* h, const char* name, const float* w, size_t numel, void* stream);
+/* 0 when every parameter has been loaded, else the count still missing */
+int hedit_unet_missing(const hedit_unet* h);
+size_t hedit_unet_workspace_bytes(hedit_unet* h, int B, int height, int width);
+/* x: fp32 [B][Cin][H][W]; t: scalar timestep shared by the batch; ctx: fp32 [B][77][ctx_dim];
+ * eps_out: fp32 [B][Cout][H][W] */
+int hedit_unet_forward(hedit_unet* h, const float* x, float t, const float* ctx, int B, int height,
+                       int width, const hedit_p2p_plan* plan, float* eps_out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* number of cross-attention layers with <= 32*32 tokens (= plan.n_store) and their geometry */
+int hedit_unet_num_store_layers(const hedit_unet* h, int height, int width);
+int hedit_unet_store_layer_info(const hedit_unet* h, int height, int width, int i, int* tokens,
+                                int* place /*0 down,1 mid,2 up*/);
+
+/* ---- sampler steps ------------------------------------------------------------------------
+ * Batched tensors are [row][image][elems]: for one image this is exactly the reference layout.
+ *   eps of the base pass: rows = 4 -> [x_o|null, x_e|null, x_o|src, x_e|src] (P2P loops),
+ *                         rows = 2 -> [x_e|null, x_e|src] (no-P2P loops)
+ *   xt / x_prev: [2][n_img][elems] = (x^orig, x^edit);   z: [n_img][elems] (may be NULL)
+ *   step_update: the four eps operands are pointers to image 0, image i sits stride_img floats
+ *   further; x_k / x_base / x_out: [n_img][elems].
+ *   local_blend: h_maps = HOST array of n_maps device pointers to 16x16 cross maps, each
+ *   [n_img][2][heads][256][77]; alpha_layers [n_img][2][77]; enabled [n_img] or NULL. */
+int hedit_step_base(const float* eps, const float* xt, const float* z, float* x_prev, int n_img,
+                    int elems, int eps_rows_per_img, const hedit_step_coef* c, void* stream);
+int hedit_step_update(const float* e_u_src, const float* e_c_src, const float* e_u_tar,
+                      const float* e_c_tar, int64_t stride_img, const float* x_k,
+                      const float* x_base, float* x_out, int n_img, int elems, int k_gt0,
+                      const hedit_step_coef* c, void* stream);
+int hedit_local_blend(float* const* h_maps, int n_maps, int heads, const float* alpha_layers,
+                      const int32_t* enabled, float* xt, int n_img, int C, int H, int W, float th,
+                      void* stream);
+
+/* ---- single kernels (parity tests) ------------------------------------------------------- */
+/* C[M][N] = A . W^T (+bias)(+residual); mode 0 linear, 1 conv3x3 s1, 2 conv3x3 s2, 3 conv3x3 on
+ * 2x nearest-upsampled input.  bf16 in/out.  splits: 0 = auto.  partial_ws may be NULL if the
+ * call resolves to one split (query with hedit_k_gemm_ws_bytes). */
+size_t hedit_k_gemm_ws_bytes(int M, int N, int K, int splits);
+int hedit_k_gemm(const void* A, const void* W, const float* bias, const void* residual, void* C,
+                 int M, int N, int K, int lda, int ldc, int ldr, int mode, int Hin, int Win,
+                 int Cin, int Hout, int Wout, int splits, void* partial_ws, void* stream);
+size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C);
+int hedit_k_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW,
+                      int C, int G, float eps, int silu, void* ws, void* stream);
+int hedit_k_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows,
+                      int C, float eps, void* stream);
+int hedit_k_geglu(const void* x, void* y, int64_t rows, int inner, void* stream);
+int hedit_k_self_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int64_t ldvt,
+                      void* out, int ldo, int B, int N, int heads, int d, const int32_t* qk_src,
+                      void* stream);
+int hedit_k_cross_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int64_t ldvt,
+                       void* out, int ldo, int B, int N, int heads, int d,
+                       const hedit_p2p_plan* plan, float* store, void* stream);
+int hedit_k_pack_conv3x3(const float* w_oihw, void* out, int O, int I, void* stream);
+int hedit_k_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,39 @@
+"""Build the HIP pipeline and the oracle model on IDENTICAL synthetic weights / text encoder."""
+import types
+
+import torch
+
+from hedit.pipeline import HEditPipeline
+from hedit.scheduler import DDIMScheduler
+from hedit.text import ClipTextEncoder, WordTokenizer
+from hedit.unet import SD15_CONFIG, TINY_CONFIG, UNet2DConditionModel, random_state_dict
+
+
+def make_pair(config, num_steps, seed=0, device="cuda:0", text_layers=2):
+    """returns (hip_model, oracle_model, state_dict)"""
+    from oracle import sd_unet as OU
+    cfg = dict(config)
+    unet = UNet2DConditionModel(cfg, device=device)
+    sd = random_state_dict(unet.param_shapes, seed)
+    unet.load_state_dict(sd)
+    tok = WordTokenizer()
+    dim = cfg["cross_attention_dim"]
+    enc = ClipTextEncoder(dim=dim, layers=text_layers, heads=4, seed=seed + 7)
+    hip = HEditPipeline(unet, DDIMScheduler(), tok, enc.to(device), None, device)
+    hip.scheduler.set_timesteps(num_steps)
+
+    onet = OU.UNet2DConditionModel(**cfg)
+    onet.load_state_dict(sd)
+    for p in onet.parameters():
+        p.requires_grad_(False)
+    onet.eval()
+    om = types.SimpleNamespace()
+    om.device = torch.device("cpu")
+    om.unet = onet
+    om.scheduler = DDIMScheduler()
+    om.scheduler.set_timesteps(num_steps)
+    om.tokenizer = tok
+    cpu_enc = ClipTextEncoder(dim=dim, layers=text_layers, heads=4, seed=seed + 7)
+    om.text_encoder = cpu_enc
+    om.vae = None
+    return hip, om, sd

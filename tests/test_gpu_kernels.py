@@ -1,0 +1,296 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against a plain PyTorch fp32 reference of
+the same op on the same (bf16-rounded) inputs.  Tolerances are stated per test: bf16 storage of
+the output costs 2^-9 relative per element; accumulation is fp32."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from helpers import gpu as G  # noqa: E402
+from hedit import _lib  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return _lib.lib()
+
+
+def run_gemm(lib, A, W, bias, res, M, N, K, lda, ldc, ldr, mode=0, conv=(0, 0, 0, 0, 0), splits=0):
+    out = torch.zeros(M, ldc, dtype=torch.bfloat16, device=G.dev())
+    wsb = lib.hedit_k_gemm_ws_bytes(M, N, K, splits)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=G.dev())
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(out), M, N, K,
+                                lda, ldc, ldr, mode, *conv, splits, _lib.ptr(ws), None))
+    G.sync()
+    return out
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(256, 320, 320, 0), (128, 128, 64, 1), (1000, 640, 1280, 0),
+                                            (64, 1280, 1280, 0), (4096, 2560, 320, 1), (320, 1024, 320, 1),
+                                            (200, 132, 192, 3), (256, 1280, 11520, 0)])
+def test_gemm_linear(lib, M, N, K, splits):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = G.bf(torch.randn(M, K, generator=g))
+    W = G.bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = G.f32(torch.randn(N, generator=g))
+    res = G.bf(torch.randn(M, N, generator=g))
+    out = run_gemm(lib, A, W, bias, res, M, N, K, K, N, N, splits=splits)
+    want = A.float() @ W.float().t() + bias + res.float()
+    # asymmetric operands: a transposed C-write would be caught (guide rule 16)
+    assert G.rel_err(out.float(), want) < 6e-3
+    out2 = run_gemm(lib, A, W, None, None, M, N, K, K, N, N, splits=splits)
+    assert G.rel_err(out2.float(), A.float() @ W.float().t()) < 6e-3
+
+
+@pytest.mark.parametrize("mode,B,H,Wd,Cin,Cout", [(1, 2, 16, 16, 64, 128), (1, 1, 8, 8, 320, 320),
+                                                    (2, 2, 16, 16, 64, 64), (3, 2, 8, 8, 128, 128),
+                                                    (1, 4, 32, 32, 192, 320), (1, 2, 8, 8, 1280, 1280)])
+def test_gemm_conv3x3(lib, mode, B, H, Wd, Cin, Cout):
+    g = torch.Generator().manual_seed(mode * 1000 + Cin + Cout)
+    x = torch.randn(B, Cin, H, Wd, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g)
+    xb = G.bf(x.permute(0, 2, 3, 1))                       # NHWC
+    wq = torch.empty(Cout * 9 * Cin, dtype=torch.bfloat16, device=G.dev())
+    _lib.check(lib.hedit_k_pack_conv3x3(_lib.ptr(G.f32(w)), _lib.ptr(wq), Cout, Cin, None))
+    xr = xb.float().permute(0, 3, 1, 2)
+    wr = G.bf(w).float()
+    if mode == 1:
+        want = F.conv2d(xr, wr, G.f32(bias), padding=1)
+    elif mode == 2:
+        want = F.conv2d(xr, wr, G.f32(bias), stride=2, padding=1)
+    else:
+        want = F.conv2d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), wr, G.f32(bias), padding=1)
+    Ho, Wo = want.shape[2], want.shape[3]
+    M = B * Ho * Wo
+    out = run_gemm(lib, xb, wq, G.f32(bias), None, M, Cout, 9 * Cin, Cin, Cout, Cout, mode=mode,
+                   conv=(H, Wd, Cin, Ho, Wo))
+    got = out.float().reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    assert G.rel_err(got, want) < 6e-3
+
+
+@pytest.mark.parametrize("B,HW,Cc,silu", [(2, 256, 64, 1), (4, 4096, 320, 1), (2, 64, 1280, 0), (1, 1024, 960, 1),
+                                           (2, 256, 2560, 1), (3, 100, 128, 0)])
+def test_groupnorm(lib, B, HW, Cc, silu):
+    g = torch.Generator().manual_seed(Cc + HW)
+    x = G.bf(torch.randn(B, HW, Cc, generator=g) * 2 + 0.5)
+    gamma, beta = G.f32(1 + 0.1 * torch.randn(Cc, generator=g)), G.f32(0.1 * torch.randn(Cc, generator=g))
+    y = torch.empty_like(x)
+    ws = torch.empty(lib.hedit_k_groupnorm_ws_bytes(B, HW, Cc), dtype=torch.uint8, device=G.dev())
+    _lib.check(lib.hedit_k_groupnorm(_lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), B, HW, Cc, 32,
+                                     1e-5, silu, _lib.ptr(ws), None))
+    G.sync()
+    want = F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, eps=1e-5)
+    if silu:
+        want = F.silu(want)
+    assert G.rel_err(y.float(), want.permute(0, 2, 1)) < 5e-3
+
+
+@pytest.mark.parametrize("rows,Cc", [(1000, 320), (64, 1280), (333, 64), (128, 640)])
+def test_layernorm_geglu(lib, rows, Cc):
+    g = torch.Generator().manual_seed(rows + Cc)
+    x = G.bf(torch.randn(rows, Cc, generator=g) * 1.5 + 0.2)
+    gamma, beta = G.f32(1 + 0.1 * torch.randn(Cc, generator=g)), G.f32(0.1 * torch.randn(Cc, generator=g))
+    y = torch.empty_like(x)
+    _lib.check(lib.hedit_k_layernorm(_lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), rows, Cc, 1e-5, None))
+    G.sync()
+    assert G.rel_err(y.float(), F.layer_norm(x.float(), (Cc,), gamma, beta, 1e-5)) < 5e-3
+    inner = Cc // 2
+    z = torch.empty(rows, inner, dtype=torch.bfloat16, device=G.dev())
+    _lib.check(lib.hedit_k_geglu(_lib.ptr(x), _lib.ptr(z), rows, inner, None))
+    G.sync()
+    h, gt = x.float().chunk(2, dim=-1)
+    assert G.rel_err(z.float(), h * F.gelu(gt)) < 5e-3
+
+
+def attn_ref(q, k, v, heads):
+    """q (B,N,C) pre-scaled in log2 units, k (B,M,C), v (B,M,C) -> probs (B,h,N,M), out (B,N,C)"""
+    B, N, Cc = q.shape
+    d = Cc // heads
+    qh = q.reshape(B, N, heads, d).transpose(1, 2)
+    kh = k.reshape(B, -1, heads, d).transpose(1, 2)
+    vh = v.reshape(B, -1, heads, d).transpose(1, 2)
+    p = torch.softmax((qh @ kh.transpose(-1, -2)) * math.log(2.0), dim=-1)
+    return p, (p @ vh).transpose(1, 2).reshape(B, N, Cc)
+
+
+@pytest.mark.parametrize("d,heads,N,B", [(32, 2, 256, 2), (40, 8, 1024, 2), (64, 2, 64, 3), (80, 8, 256, 2),
+                                           (160, 8, 64, 2), (40, 8, 4096, 1), (160, 8, 256, 4)])
+def test_self_attention(lib, d, heads, N, B):
+    g = torch.Generator().manual_seed(d * 7 + N)
+    Cc = d * heads
+    scale = d ** -0.5 * math.log2(math.e)
+    q = G.bf(torch.randn(B, N, Cc, generator=g) * scale * 1.5)
+    k = G.bf(torch.randn(B, N, Cc, generator=g) * 1.5)
+    v = G.bf(torch.randn(B, N, Cc, generator=g))
+    qk = torch.cat([q, k], dim=-1).contiguous()                       # [B*N][2C]
+    vt = v.reshape(B * N, Cc).t().contiguous()                        # [C][B*N]
+    out = torch.zeros(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
+    k_view = qk.reshape(B * N, 2 * Cc)[:, Cc:]
+    _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * Cc, C.c_void_p(k_view.data_ptr()), 2 * Cc, _lib.ptr(vt),
+                                     B * N, _lib.ptr(out), Cc, B, N, heads, d, None, None))
+    G.sync()
+    _, want = attn_ref(q.float(), k.float(), v.float(), heads)
+    assert G.rel_err(out.float(), want) < 1.2e-2
+    # P2P self-replacement: row b uses q,k of row qk_src[b], v of its own row
+    src = list(range(B))
+    src[B - 1] = 0
+    idx = torch.tensor(src, dtype=torch.int32, device=G.dev())
+    out2 = torch.zeros_like(out)
+    _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * Cc, C.c_void_p(k_view.data_ptr()), 2 * Cc, _lib.ptr(vt),
+                                     B * N, _lib.ptr(out2), Cc, B, N, heads, d, _lib.ptr(idx), None))
+    G.sync()
+    _, want2 = attn_ref(q.float()[src], k.float()[src], v.float(), heads)
+    assert G.rel_err(out2.float(), want2) < 1.2e-2
+
+
+def test_self_attention_online_softmax_rescale(lib):
+    """Force the running-max rescale branch: one key late in the sequence dominates a query."""
+    d, heads, N, B = 40, 8, 512, 1
+    g = torch.Generator().manual_seed(5)
+    Cc = d * heads
+    q = torch.randn(B, N, Cc, generator=g) * 0.3
+    k = torch.randn(B, N, Cc, generator=g)
+    v = torch.randn(B, N, Cc, generator=g)
+    k[0, 400] = q[0, 7] * 40.0          # spike: raw q.k far above everything seen before tile 6
+    q, k, v = G.bf(q), G.bf(k), G.bf(v)
+    qk = torch.cat([q, k], dim=-1).contiguous()
+    vt = v.reshape(B * N, Cc).t().contiguous()
+    out = torch.zeros(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
+    k_view = qk.reshape(B * N, 2 * Cc)[:, Cc:]
+    _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * Cc, C.c_void_p(k_view.data_ptr()), 2 * Cc, _lib.ptr(vt),
+                                     B * N, _lib.ptr(out), Cc, B, N, heads, d, None, None))
+    G.sync()
+    _, want = attn_ref(q.float(), k.float(), v.float(), heads)
+    assert G.max_err(out.float(), want) < 3e-2
+    assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("d,heads,N", [(32, 2, 256), (40, 8, 1024), (64, 2, 64), (80, 8, 256), (160, 8, 64)])
+def test_cross_attention_p2p(lib, d, heads, N):
+    g = torch.Generator().manual_seed(d * 3 + N)
+    B, Cc, CT = 4, d * heads, 80
+    scale = d ** -0.5 * math.log2(math.e)
+    q = G.bf(torch.randn(B, N, Cc, generator=g) * scale * 2)
+    kc = torch.zeros(B, CT, Cc)
+    vc = torch.zeros(B, CT, Cc)
+    kc[:, :77] = torch.randn(B, 77, Cc, generator=g) * 2
+    vc[:, :77] = torch.randn(B, 77, Cc, generator=g)
+    kc, vc = G.bf(kc), G.bf(vc)
+    vt = vc.reshape(B * CT, Cc).t().contiguous()
+    # a non-trivial mixing matrix: permutation-ish gather + scaling, and a blend vector
+    A = torch.zeros(77, 77)
+    perm = torch.randperm(77, generator=g)
+    A[perm, torch.arange(77)] = torch.rand(77, generator=g) * 1.5
+    A[3, 5] = 0.5
+    A[4, 5] = 0.5
+    bvec = torch.rand(77, generator=g)
+    mixT = torch.zeros(1, 96, 96)
+    mixT[0, :77, :77] = A.t()
+    bv = torch.zeros(1, 96)
+    bv[0, :77] = bvec
+    mixT_d, bv_d = G.bf(mixT), G.f32(bv)
+    plan, keep = G.make_plan(n_pairs=1, pair_src=[2], pair_tar=[3], singles=[0, 1], mixT=mixT_d, bvec=bv_d, mode=2)
+    store = torch.zeros(1, 2, heads, N, 77, dtype=torch.float32, device=G.dev())
+    out = torch.zeros(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
+    for rep in range(2):        # two passes: the store must accumulate
+        _lib.check(lib.hedit_k_cross_attn(_lib.ptr(q), Cc, _lib.ptr(kc), Cc, _lib.ptr(vt), B * CT, _lib.ptr(out),
+                                          Cc, B, N, heads, d, C.byref(plan), _lib.ptr(store), None))
+    G.sync()
+    p, o = attn_ref(q.float(), kc.float()[:, :77], vc.float()[:, :77], heads)
+    A_b = mixT_d.float()[0, :77, :77].t()
+    p_new = p[2] @ A_b + bv_d[0, :77] * p[3]
+    vh = vc.float()[3, :77].reshape(77, heads, d).transpose(0, 1)
+    o_tar = (p_new @ vh).transpose(0, 1).reshape(N, Cc)
+    assert G.rel_err(out[:3].float(), o[:3]) < 1.2e-2          # plain rows and the source row
+    assert G.rel_err(out[3].float(), o_tar) < 1.5e-2            # edited target row
+    assert G.rel_err(store[0, 0], 2 * p[2]) < 2e-3               # source maps, two passes
+    assert G.rel_err(store[0, 1], 2 * p_new) < 1e-2              # post-edit target maps
+    # controller off: every row plain
+    plan0, keep0 = G.make_plan(n_pairs=0, singles=[0, 1, 2, 3], mode=0)
+    out0 = torch.zeros_like(out)
+    _lib.check(lib.hedit_k_cross_attn(_lib.ptr(q), Cc, _lib.ptr(kc), Cc, _lib.ptr(vt), B * CT, _lib.ptr(out0),
+                                      Cc, B, N, heads, d, C.byref(plan0), None, None))
+    G.sync()
+    assert G.rel_err(out0.float(), o) < 1.2e-2
+
+
+def test_step_kernels_match_reference_vectors(lib, golden_dir):
+    """hedit_step_base against the reference's reverse_step outputs (g2), then hedit_step_update
+    against the oracle formulas."""
+    import os
+    from helpers.tiny import ddim_tables
+    from hedit.engine import Schedule
+    g = np.load(os.path.join(golden_dir, "g2_reverse_step.npz"))
+    sch = ddim_tables(20)
+    S = Schedule(sch)
+    eps, x, z = (torch.from_numpy(g[k]) for k in ("eps", "x", "z"))
+    elems = x[0].numel()
+    for t in (951, 501, 1):
+        for eta in (0.0, 1.0):
+            for ddim in (False, True):
+                coef = S.step_coef(t, max(t - 50, 0), eta, ddim, (1.0, 5.0, 7.5))
+                # rows [x_o|0, x_e|0, x_o|src, x_e|src] with w_src = 1 -> eps = conditional rows
+                e4 = G.f32(torch.cat([torch.zeros_like(eps), eps]))
+                out = torch.zeros(2, *x.shape[1:], device=G.dev())
+                _lib.check(lib.hedit_step_base(_lib.ptr(e4), _lib.ptr(G.f32(x)), _lib.ptr(G.f32(z)), _lib.ptr(out), 1,
+                                               elems, 4, C.byref(coef), None))
+                G.sync()
+                want = torch.from_numpy(g[f"prev_t{t}_eta{int(eta)}_ddim{int(ddim)}"])
+                assert G.max_err(out, want) < 2e-5 * max(1.0, want.abs().max().item())
+    # update kernel, k = 0 and k > 0, two images
+    gen = torch.Generator().manual_seed(3)
+    n, el = 2, 4 * 16 * 16
+    e = torch.randn(4, n, el, generator=gen)
+    xk = torch.randn(n, el, generator=gen)
+    xb = xk + 0.1 * torch.randn(n, el, generator=gen)
+    xb[0, :10] = xk[0, :10]                       # exact ties -> sign 0
+    coef = S.step_coef(501, 451, 1.0, False, (1.0, 5.0, 7.5), w_rec=0.1)
+    for k_gt0 in (0, 1):
+        out = torch.zeros(n, el, device=G.dev())
+        ed = G.f32(e)
+        _lib.check(lib.hedit_step_update(_lib.ptr(ed[0]), _lib.ptr(ed[2]), _lib.ptr(ed[1]), _lib.ptr(ed[3]), el,
+                                         _lib.ptr(G.f32(xk)), _lib.ptr(G.f32(xb)), _lib.ptr(out), n, el, k_gt0,
+                                         C.byref(coef), None))
+        G.sync()
+        for i in range(n):
+            ehat = e[0, i] + coef.w_hat * (e[2, i] - e[0, i])
+            etar = e[1, i] + coef.w_tar * (e[3, i] - e[1, i])
+            corr = etar - ehat
+            rec = xk[i]
+            if k_gt0:
+                gr = torch.sign(xk[i] - xb[i]) / el
+                rho = corr.pow(2).mean().sqrt().item() / (gr.pow(2).mean().sqrt().item() + 1e-8) * coef.w_rec
+                rec = xk[i] - rho * gr
+            want = rec + coef.coeff * corr
+            assert G.max_err(out[i], want) < 1e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("pi", [0, 1, 3])
+def test_local_blend_matches_reference_vectors(lib, golden_dir, pi):
+    import os
+    from helpers.tiny import PROMPT_PAIRS, WordTokenizer, hash_normal, hash_uniform
+    from hedit.p2p import ptp_controller_utils as PCU
+    g = np.load(os.path.join(golden_dir, "g5_local_blend.npz"))
+    src, tar, blend, is_replace = PROMPT_PAIRS[pi]
+    tok = WordTokenizer(split_long_words_at=6)
+    c = PCU.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=((blend[0],), (blend[1],)),
+                            equilizer_params={"words": (blend[1],), "values": (2.0,)}, num_steps=10, tokenizer=tok)
+    heads = 2
+    five = [G.f32(hash_uniform((2 * heads, 256, 77), 3000 + pi * 10 + i) ** 6) for i in range(5)]
+    big = torch.zeros(2 * heads, 1024, 77, device=G.dev())
+    store = {"down_cross": [big, big, five[0], five[1]], "up_cross": [five[2], five[3], five[4], big]}
+    x = hash_normal((2, 4, 64, 64), 3500 + pi)
+    for counter in (0, 2, 3):
+        c.local_blend.counter = counter
+        y = c.local_blend(G.f32(x), store)
+        G.sync()
+        assert torch.equal(y[0].cpu(), x[0])
+        assert G.max_err(y[1], torch.from_numpy(g[f"p{pi}_y_counter{counter}"])) < 1e-6

@@ -1,0 +1,154 @@
+"""-m gpu: the h-Edit loops on the HIP path vs the oracle loops (same synthetic SD-shaped tiny
+network, same text encoder, same inversion noise).  Floating point: bf16 UNet vs fp32 oracle over
+tens of sequential evaluations; tolerance = relative L2 of the final latents, stated below."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import gpu as G  # noqa: E402
+from helpers.models import make_pair  # noqa: E402
+from helpers.tiny import PROMPT_PAIRS  # noqa: E402
+from hedit.unet import TINY_CONFIG  # noqa: E402
+
+T = 8
+TOL_FINAL = 8e-2          # relative L2 of the final edited latent after the whole loop
+TOL_RECON = 2e-2
+
+
+@pytest.fixture(scope="module")
+def setup():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import loops as OL
+    hip, om, _ = make_pair(TINY_CONFIG, T)
+    torch.manual_seed(11)
+    w0 = torch.randn(1, 4, 32, 32) * 0.8
+    inv = {}
+    for pi in (0, 2):
+        torch.manual_seed(100 + pi)
+        zs, wts, noise = OL.ddpm_inversion(om, w0, eta=1.0, prompt=PROMPT_PAIRS[pi][0], cfg_src=1.0, T=T)
+        inv[pi] = (zs, wts, noise)
+    return hip, om, w0, inv
+
+
+def controllers(hip, om, pi, after, p2p, eq_val=2.0):
+    from oracle import p2p as OP
+    from hedit.p2p import ptp_classes as PC
+    from hedit.p2p import ptp_controller_utils as PCU
+    from hedit.p2p.ptp_utils import register_attention_control
+    src, tar, blend, is_replace = PROMPT_PAIRS[pi]
+    if p2p:
+        bw = ((blend[0],), (blend[1],)) if blend else None
+        eq = {"words": (blend[1],), "values": (eq_val,)} if blend else None
+        hc = PCU.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=bw, equilizer_params=eq,
+                                 num_steps=after, tokenizer=hip.tokenizer, device=hip.device)
+        oc = OP.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=bw, eq_params=eq, num_steps=after,
+                                tok=om.tokenizer)
+    else:
+        hc, oc = PC.AttentionStore(), OP.Controller("store")
+    register_attention_control(hip, hc)
+    OP.register(om, oc)
+    return hc, oc
+
+
+def test_ddpm_inversion_matches_oracle(setup):
+    from hedit.inversion.ddpm_inversion import inversion_forward_process_ddpm
+    hip, om, w0, inv = setup
+    zs_o, wts_o, noise = inv[0]
+    _, zs, wts, _ = inversion_forward_process_ddpm(hip, G.f32(w0), etas=1.0, prog_bar=False, prompt=PROMPT_PAIRS[0][0],
+                                                   cfg_scale_src=1.0, num_inference_steps=T, noise=G.f32(noise))
+    G.sync()
+    assert G.rel_err(wts, wts_o) < 1e-2
+    # z = (x_{t-1} - mu)/sigma divides by small sigmas at the last steps: compare sigma-weighted
+    assert G.rel_err(zs[2:], zs_o[2:]) < 6e-2
+
+
+CASES = [
+    ("h_Edit_p2p_implicit", 0, 0, 1, False, True),
+    ("h_Edit_p2p_implicit", 2, 2, 3, False, True),
+    ("h_Edit_p2p_implicit", 0, 0, 2, True, True),
+    ("h_Edit_p2p_explicit", 0, 0, 1, False, True),
+    ("h_Edit_R_implicit", 0, 0, 2, False, False),
+    ("h_Edit_R_implicit", 2, 3, 1, False, False),
+    ("h_Edit_R_explicit", 0, 0, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("fn,pi,skip,K,ddim,p2p", CASES)
+def test_loops_match_oracle(setup, fn, pi, skip, K, ddim, p2p):
+    from oracle import loops as OL
+    from hedit.inversion import p2p_h_edit as HE
+    hip, om, w0, inv = setup
+    zs, wts, _ = inv[pi]
+    after = T - skip
+    hc, oc = controllers(hip, om, pi, after, p2p, eq_val=1.25 if K > 1 else 2.0)
+    prompts = [PROMPT_PAIRS[pi][0], PROMPT_PAIRS[pi][1]]
+    kw = dict(eta=1.0, prompts=prompts, cfg_scales=[1.0, 5.0, 7.5], after_skip_steps=after, is_ddim_inversion=ddim)
+    okw = dict(kw)
+    if "implicit" in fn:
+        kw.update(weight_reconstruction=0.1, optimization_steps=K)
+        okw.update(weight_reconstruction=0.1, optimization_steps=K)
+    ofn = {"h_Edit_p2p_implicit": OL.h_edit_p2p_implicit, "h_Edit_p2p_explicit": OL.h_edit_p2p_explicit,
+           "h_Edit_R_implicit": OL.h_edit_r_implicit, "h_Edit_R_explicit": OL.h_edit_r_explicit}[fn]
+    with torch.no_grad():
+        e_o, r_o = ofn(om, xT=wts[after], zs=zs[:after], controller=oc, **okw)
+    e_h, r_h = getattr(HE, fn)(hip, xT=G.f32(wts[after]), zs=G.f32(zs[:after]), controller=hc, prog_bar=False, **kw)
+    G.sync()
+    assert e_h.shape == (1, 4, 32, 32) and r_h.shape == (1, 4, 32, 32)
+    assert torch.isfinite(e_h).all()
+    assert G.rel_err(r_h, r_o) < (TOL_RECON if p2p and not ddim else TOL_FINAL)
+    assert G.rel_err(e_h, e_o) < TOL_FINAL
+    assert hc.cur_step == oc.cur_step
+    if p2p and not ddim:
+        # survey invariant 1: the x^orig branch reconstructs the inverted latent
+        assert G.rel_err(r_h, w0) < 5e-2
+
+
+def test_null_edit_invariant(setup):
+    """identical prompts and cfg_src_edit == cfg_tar => correction == 0 => edited == base == recon
+    (invariant 2)."""
+    from hedit.inversion import p2p_h_edit as HE
+    from hedit.p2p import ptp_classes as PC
+    from hedit.p2p.ptp_utils import register_attention_control
+    hip, om, w0, inv = setup
+    zs, wts, _ = inv[0]
+    register_attention_control(hip, PC.AttentionStore())
+    p = PROMPT_PAIRS[0][0]
+    e, r = HE.h_Edit_R_implicit(hip, xT=G.f32(wts[T]), zs=G.f32(zs), prompts=[p, p], cfg_scales=[1.0, 7.5, 7.5],
+                                controller=None, optimization_steps=1, after_skip_steps=T)
+    G.sync()
+    assert G.rel_err(e, r) < 1e-3
+
+
+def test_batched_engine_equals_single_image(setup):
+    """n = 2 images in lock-step give the same latents as two n = 1 runs (rows are independent)."""
+    from hedit.engine import HEditEngine
+    from hedit.p2p import ptp_controller_utils as PCU
+    from hedit.p2p.ptp_classes import ControllerBatch
+    from hedit.p2p.ptp_utils import register_attention_control
+    hip, om, w0, inv = setup
+    eng = HEditEngine(hip)
+
+    def ctrl(pi):
+        src, tar, blend, is_replace = PROMPT_PAIRS[pi]
+        return PCU.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=((blend[0],), (blend[1],)),
+                                   equilizer_params={"words": (blend[1],), "values": (2.0,)}, num_steps=T,
+                                   tokenizer=hip.tokenizer, device=hip.device)
+    singles = []
+    for pi in (0, 2):
+        c = ctrl(pi)
+        register_attention_control(hip, c)
+        zs, wts, _ = inv[pi]
+        singles.append(eng.run(G.f32(wts[T][None]), G.f32(zs[:, None]), [list(PROMPT_PAIRS[pi][:2])], [1.0, 5.0, 7.5],
+                               c, K=2, w_rec=0.1, after_skip_steps=T))
+    cb = ControllerBatch([ctrl(0), ctrl(2)])
+    register_attention_control(hip, cb)
+    xT = torch.stack([inv[0][1][T], inv[2][1][T]])
+    zs = torch.stack([inv[0][0], inv[2][0]], dim=1)
+    e, r = eng.run(G.f32(xT), G.f32(zs), [list(PROMPT_PAIRS[0][:2]), list(PROMPT_PAIRS[2][:2])], [1.0, 5.0, 7.5],
+                   cb, K=2, w_rec=0.1, after_skip_steps=T)
+    G.sync()
+    for i in range(2):
+        assert G.rel_err(e[i], singles[i][0][0]) < 2e-2
+        assert G.rel_err(r[i], singles[i][1][0]) < 2e-2

@@ -1,0 +1,123 @@
+"""-m gpu: the HIP UNet (hedit_unet_forward through the C ABI) against the CPU fp32 oracle on the
+same synthetic weights.  bf16 activations/weights with fp32 accumulation; tolerance stated below."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import gpu as G  # noqa: E402
+from helpers.models import make_pair  # noqa: E402
+from helpers.tiny import PROMPT_PAIRS  # noqa: E402
+from hedit.unet import SD15_CONFIG, TINY_CONFIG  # noqa: E402
+
+# relative L2 error of one eps evaluation, bf16 pipeline vs fp32 oracle
+TOL_TINY = 2.5e-2
+TOL_SD = 3.0e-2
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return make_pair(TINY_CONFIG, 10)
+
+
+def _inputs(B, cfg, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 4, cfg["sample_size"], cfg["sample_size"], generator=g)
+    ctx = torch.randn(B, 77, cfg["cross_attention_dim"], generator=g)
+    return x, ctx
+
+
+@pytest.mark.parametrize("B,t", [(1, 981), (2, 501), (4, 21), (5, 1)])
+def test_tiny_unet_forward(tiny, B, t):
+    hip, om, _ = tiny
+    x, ctx = _inputs(B, TINY_CONFIG, 10 + B)
+    with torch.no_grad():
+        want = om.unet(x, torch.tensor(t), encoder_hidden_states=ctx).sample
+    got = hip.unet(G.f32(x), t, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"use_controller": False}).sample
+    G.sync()
+    err = G.rel_err(got, want)
+    assert err < TOL_TINY, err
+    # determinism: a second evaluation is bit-identical
+    got2 = hip.unet(G.f32(x), t, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"use_controller": False}).sample
+    assert torch.equal(got, got2)
+
+
+@pytest.mark.parametrize("pi,cur_step", [(0, 0), (2, 1), (3, 5)])
+def test_tiny_unet_p2p_pass(tiny, pi, cur_step):
+    """One P2P pass (controller on, save_attn) vs the oracle processor + controller: eps of all four
+    rows, the stored 16x16 cross maps and the controller counters."""
+    from oracle import p2p as OP
+    from hedit.p2p import ptp_controller_utils as PCU
+    from hedit.p2p.ptp_utils import register_attention_control
+    hip, om, _ = tiny
+    src, tar, blend, is_replace = PROMPT_PAIRS[pi]
+    T = 10
+    bw = ((blend[0],), (blend[1],)) if blend else None
+    eq = {"words": (blend[1],), "values": (2.0,)} if blend else None
+    hc = PCU.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=bw, equilizer_params=eq, num_steps=T,
+                             tokenizer=hip.tokenizer, device=hip.device)
+    oc = OP.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=bw, eq_params=eq, num_steps=T,
+                            tok=om.tokenizer)
+    register_attention_control(hip, hc)
+    OP.register(om, oc)
+    assert hc.num_att_layers == oc.num_att_layers == 22
+    hc.cur_step = oc.cur_step = cur_step
+    x, ctx = _inputs(4, TINY_CONFIG, 77 + pi)
+    x[2], x[3] = x[0], x[1]
+    try:
+        with torch.no_grad():
+            want = om.unet(x, torch.tensor(401), encoder_hidden_states=ctx, cross_attention_kwargs={"save_attn": True}).sample
+        got = hip.unet(G.f32(x), 401, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"save_attn": True}).sample
+        G.sync()
+        assert G.rel_err(got, want) < TOL_TINY
+        assert hc.cur_step == oc.cur_step == cur_step + 1 and hc.cur_att_layer == 0
+        for key in ("down_cross", "mid_cross", "up_cross"):
+            assert len(hc.attention_store[key]) == len(oc.attention_store[key])
+            for a, b in zip(hc.attention_store[key], oc.attention_store[key]):
+                assert a.shape == b.shape
+                assert G.rel_err(a, b) < 2e-2
+        # a save_attn=False pass applies the edit but leaves counters and store untouched
+        before = [t.clone() for t in hc.attention_store["down_cross"]]
+        with torch.no_grad():
+            want2 = om.unet(x, torch.tensor(401), encoder_hidden_states=ctx, cross_attention_kwargs={"save_attn": False}).sample
+        got2 = hip.unet(G.f32(x), 401, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"save_attn": False}).sample
+        G.sync()
+        assert G.rel_err(got2, want2) < TOL_TINY
+        assert hc.cur_step == cur_step + 1
+        for a, b in zip(before, hc.attention_store["down_cross"]):
+            assert torch.equal(a, b)
+    finally:
+        from hedit.unet import AttnProcessor
+        hip.unet.set_attn_processor({k: AttnProcessor() for k in hip.unet.attn_processors})
+        from oracle.sd_unet import PlainProcessor
+        om.unet.set_attn_processor({k: PlainProcessor() for k in om.unet.attn_processors})
+
+
+def test_unet_argument_errors(tiny):
+    hip, _, _ = tiny
+    x, ctx = _inputs(2, TINY_CONFIG, 1)
+    with pytest.raises(ValueError):
+        hip.unet(G.f32(x), 1, encoder_hidden_states=G.f32(ctx[:, :50]))
+    with pytest.raises(TypeError):
+        hip.unet(G.f32(x), 1, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"bogus": 1})
+    with pytest.raises(KeyError):
+        hip.unet.load_state_dict({})
+
+
+def test_sd15_unet_forward_full_size():
+    """BASELINE.json's network at full size (859.5 M parameters, 64x64 latent), two rows."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    hip, om, _ = make_pair(SD15_CONFIG, 50, seed=3)
+    x, ctx = _inputs(2, SD15_CONFIG, 5)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    with torch.no_grad():
+        want = om.unet(x, torch.tensor(481), encoder_hidden_states=ctx).sample
+    got = hip.unet(G.f32(x), 481, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"use_controller": False}).sample
+    G.sync()
+    err = G.rel_err(got, want)
+    assert err < TOL_SD, err
+    assert len(hip.unet.attn_processors) == 32
+    assert sum(int(torch.tensor(s).prod()) for s in hip.unet.param_shapes.values()) == 859520964

@@ -1,0 +1,137 @@
+"""CPU tests of the product's host logic (no GPU, no oracle in the product path): P2P tables vs
+the reference-generated golden vectors, the folded (A_s, bvec_s) mixing tables vs the reference
+controller's outputs, scheduler coefficients, and that the C-ABI library loads and exports every
+symbol declared in include/hedit.h."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers.tiny import PROMPT_PAIRS, WordTokenizer, ddim_tables, hash_probs
+from hedit import _lib
+from hedit.engine import Schedule
+from hedit.p2p import ptp_controller_utils as PCU
+from hedit.p2p import ptp_utils as PU
+from hedit.scheduler import DDIMScheduler
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _npz(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _json(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def make(pair, num_steps, eq_val, tok):
+    src, tar, blend, is_replace = pair
+    bw = ((blend[0],), (blend[1],)) if blend else None
+    eq = {"words": (blend[1],), "values": (eq_val,)} if blend else None
+    return PCU.make_controller(prompts=[src, tar], is_replace_controller=is_replace, cross_replace_steps=0.4,
+                               self_replace_steps=0.35, blend_word=bw, equilizer_params=eq,
+                               num_steps=num_steps, tokenizer=tok, device=None)
+
+
+@pytest.mark.parametrize("pi", range(len(PROMPT_PAIRS)))
+def test_tables_match_reference(golden_dir, pi):
+    g = _npz(golden_dir, "g4_controller.npz")
+    info = _json(golden_dir, "g4_controller.json")["pairs"][pi]
+    tok = WordTokenizer(split_long_words_at=6)
+    c = make(PROMPT_PAIRS[pi], 50, info["eq_val"], tok)
+    assert type(c).__name__ == info["class"]
+    base = c.prev_controller if getattr(c, "prev_controller", None) is not None else c
+    assert type(base).__name__ == info["base_class"]
+    assert np.array_equal(base.mapper.numpy(), g[f"p{pi}_mapper"])
+    if f"p{pi}_alphas" in g:
+        assert np.array_equal(base.alphas.numpy(), g[f"p{pi}_alphas"])
+    if f"p{pi}_equalizer" in g:
+        assert np.array_equal(c.equalizer.numpy(), g[f"p{pi}_equalizer"])
+    assert np.array_equal(c.cross_replace_alpha.numpy(), g[f"p{pi}_cross_replace_alpha"])
+    assert list(c.num_self_replace) == info["num_self_replace"]
+    if c.local_blend is not None:
+        assert np.array_equal(c.local_blend.alpha_layers.numpy(), g[f"p{pi}_lb_alpha_layers"])
+        assert c.local_blend.start_blend == info["lb_start_blend"]
+    for key, want in info["word_inds"].items():
+        text, w = key.split("|")
+        assert [int(v) for v in PU.get_word_inds(text, w, tok)] == want
+
+
+@pytest.mark.parametrize("pi", range(len(PROMPT_PAIRS)))
+def test_mix_tables_reproduce_reference_edit(golden_dir, pi):
+    """P_src . A_s + bvec_s * P_tar must equal what the reference controller wrote into the
+    target-conditional rows (cross layers of the golden pass)."""
+    g = _npz(golden_dir, "g4_controller.npz")
+    info = _json(golden_dir, "g4_controller.json")["pairs"][pi]
+    tok = WordTokenizer(split_long_words_at=6)
+    c = make(PROMPT_PAIRS[pi], 50, info["eq_val"], tok)
+    A, b = c._mix_tables()
+    assert A.shape == (51, 77, 77) and b.shape == (51, 77)
+    for cur_step in (0, 16, 17, 19, 20, 49):
+        for li, (is_cross, place, n) in enumerate(info["layers"]):
+            if not is_cross:
+                continue
+            probs = hash_probs((4, n, 77), 100000 + pi * 1000 + cur_step * 10 + li)
+            src, tar = probs[2], probs[3]
+            new = src @ A[cur_step] + b[cur_step] * tar
+            want = torch.from_numpy(g[f"p{pi}_s{cur_step}_l{li}_tar"])[0]
+            assert (new - want).abs().max().item() <= 2e-6
+
+
+def test_replace_requires_equal_word_count():
+    tok = WordTokenizer()
+    with pytest.raises(ValueError):
+        make(("a b c", "a b c d", None, True), 10, 2.0, tok)
+
+
+@pytest.mark.parametrize("T", [10, 20, 50])
+def test_scheduler_and_coefficients(golden_dir, T):
+    g = _json(golden_dir, "g1_scheduler.json")[str(T)]
+    s = DDIMScheduler()
+    s.set_timesteps(T)
+    assert [int(t) for t in s.timesteps] == g["timesteps"]
+    ref = ddim_tables(T)
+    assert torch.equal(s.alphas_cumprod, ref.alphas_cumprod)
+    assert abs(float(s.final_alpha_cumprod) - g["final_alpha_cumprod"]) < 1e-9
+    S = Schedule(s)
+    for row in g["rows"]:
+        t, tt = row["t"], row["tt"]
+        assert abs(float(S.variance(t)) - row["variance"]) <= 1e-7 + 1e-6 * abs(row["variance"])
+        for eta in (0.0, 1.0):
+            for ddim in (False, True):
+                want = row[f"coeff_eta{int(eta)}_ddim{int(ddim)}"]
+                assert abs(float(S.full_coeff(t, tt, eta, ddim)) - want) <= 1e-6
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "hedit.h")).read()
+    declared = sorted(set(re.findall(r"\b(hedit_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    assert os.path.exists(_lib.LIB_PATH), "build libhedit_hip.so first: python h-edit_amd/build.py"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/hedit.h but not exported"
+    assert sorted(_lib.EXPORTS) == declared, "ctypes signature table out of sync with include/hedit.h"
+    assert _lib.lib().hedit_version() >= 1
+
+
+def test_no_fallback_without_library(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libhedit_hip.so")
+    with pytest.raises(_lib.HipLibraryMissing):
+        _lib.lib()
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "h-edit_amd", "hedit")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports oracle"
