@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""bench.py -- h-Edit sampling loop on MI355X (BASELINE.json metric: edited images/s).
+
+    python bench.py --gpus 1 --steps K --warmup W            # one process
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch of synthetic input: the complete reverse-time
+bridge sampling loop of BASELINE.json configs[1] (text-guided h_Edit_p2p_implicit, SD-1.5-shaped
+random-init UNet, 64x64 latents, 50 DDIM steps, K_opt = 1 implicit "Langevin" step, P2P
+Replace/Refine + Reweight + LocalBlend) for `--images` independent images per GPU run in
+lock-step: 50 x (1 base pass of 4n rows + 1 source pass of n rows + 1 P2P pass of 4n rows) =
+450 UNet sample-forwards per image, exactly the reference's call pattern.  Inputs (weights,
+inverted latents x_T, noise maps z_t, text embeddings) are resident in HBM before the timed
+region; DDPM inversion is outside it (it is the step BEFORE the path).
+
+Multi-GPU: one process per GPU, images sharded across ranks (weak scaling, no data-path
+collective); rank 0 creates the weights and broadcasts them over RCCL/xGMI once at start-up.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+
+import torch  # noqa: E402
+
+FLOP_PER_SAMPLE_FWD = 0.8032e12       # 401.6 GMAC per UNet sample-forward
+MFMA_PEAK_TFLOPS = 2500.0             # dense bf16 MFMA peak, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+DEMO_PAIRS = [
+    # (source, target, (blend_src, blend_tar), replace-controller?)  -- the reference's demo prompts
+    ("a green lizard is sitting on a branch", "a brown lizard is sitting on a branch", ("lizard", "lizard"), True),
+    ("an orange van with surfboards on top", "an orange van with flowers on top", ("surfboards", "flowers"), True),
+    ("a round cake with orange frosting on a wooden plate", "a square cake with orange frosting on a wooden plate",
+     ("cake", "cake"), True),
+    ("a cat sitting next to a mirror", "a silver cat sculpture sitting next to a mirror", ("cat", "cat"), False),
+]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images", type=int, default=8, help="images edited in lock-step per GPU (one 'step')")
+    ap.add_argument("--diffusion-steps", type=int, default=50)
+    ap.add_argument("--opt-steps", type=int, default=1, help="implicit optimisation ('Langevin') steps K")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-every", type=int, default=25, help="bracket every n-th UNet call with HIP events")
+    ap.add_argument("--tiny", action="store_true", help="debug: tiny network instead of SD-1.5 shape")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    from hedit.engine import HEditEngine
+    from hedit.p2p import ptp_controller_utils as PCU
+    from hedit.p2p.ptp_classes import ControllerBatch
+    from hedit.p2p.ptp_utils import register_attention_control
+    from hedit.pipeline import HEditPipeline
+    from hedit.scheduler import DDIMScheduler
+    from hedit.text import ClipTextEncoder, WordTokenizer
+    from hedit.unet import SD15_CONFIG, TINY_CONFIG, UNet2DConditionModel, random_state_dict
+
+    cfg = dict(TINY_CONFIG if args.tiny else SD15_CONFIG)
+    unet = UNet2DConditionModel(cfg, device=dev)
+
+    # ---- weights: rank 0 creates them, RCCL broadcast to the other GPUs (no steady-state traffic)
+    t_w0 = time.time()
+    sd_cpu = None
+    if world == 1:
+        sd_cpu = random_state_dict(unet.param_shapes, seed=0)
+        unet.load_state_dict(sd_cpu)
+    else:
+        names = list(unet.param_shapes.keys())
+        if rank == 0:
+            sd_cpu = random_state_dict(unet.param_shapes, seed=0)
+        for name in names:
+            shape = unet.param_shapes[name]
+            buf = sd_cpu[name].to(dev) if rank == 0 else torch.empty(shape, dtype=torch.float32, device=dev)
+            dist.broadcast(buf, src=0)
+            unet.load_state_dict({name: buf}, strict=False)
+        assert unet._lib.hedit_unet_missing(unet._h) == 0
+    t_weights = time.time() - t_w0
+
+    tok = WordTokenizer()
+    enc = ClipTextEncoder(dim=cfg["cross_attention_dim"], layers=2 if args.tiny else 12,
+                          heads=4 if args.tiny else 12, seed=7).to(dev)
+    model = HEditPipeline(unet, DDIMScheduler(), tok, enc, None, dev)
+    T = args.diffusion_steps
+    model.scheduler.set_timesteps(T)
+    eng = HEditEngine(model)
+
+    n = args.images
+    S = cfg["sample_size"]
+    pairs = [DEMO_PAIRS[(rank * n + i) % len(DEMO_PAIRS)] for i in range(n)]
+    prompt_pairs = [[p[0], p[1]] for p in pairs]
+    w0 = torch.stack([torch.randn(4, S, S, generator=torch.Generator().manual_seed(1 + rank * n + i)) * 0.8
+                      for i in range(n)]).to(dev)
+    with torch.no_grad():
+        null = eng.encode([""])
+        src = eng.encode([p[0] for p in prompt_pairs])
+        tar = eng.encode([p[1] for p in prompt_pairs])
+    # step before the path (not timed): edit-friendly DDPM inversion on the same kernels
+    g = torch.Generator(device=dev).manual_seed(3 + rank)
+    t_i0 = time.time()
+    zs, xts = eng.ddpm_inversion(w0, [p[0] for p in prompt_pairs], eta=1.0, cfg_src=1.0, generator=g)
+    torch.cuda.synchronize()
+    t_inversion = time.time() - t_i0
+    xT = xts[T].contiguous()
+    cfg_scales = [1.0, 5.0, 7.5]
+    K = args.opt_steps
+
+    def make_batch_controller():
+        ctrls = []
+        for (s_, t_, bw, is_replace) in pairs:
+            ctrls.append(PCU.make_controller(
+                prompts=[s_, t_], is_replace_controller=is_replace, cross_replace_steps=0.4,
+                self_replace_steps=0.35, blend_word=((bw[0],), (bw[1],)),
+                equilizer_params={"words": (bw[1],), "values": (2.0 if K == 1 else 1.25,)},
+                num_steps=T, tokenizer=tok, device=dev))
+        return ControllerBatch(ctrls)
+
+    # sampled launch timing: bracket every prof_every-th UNet call with HIP event pairs
+    calls = {"n": 0}
+    raw = unet.forward_raw
+
+    def forward_sampled(*a, **k):
+        calls["n"] += 1
+        on = calls["prof"] and (calls["n"] % args.prof_every == 0)
+        if on:
+            unet.prof_enable(True, 16384)
+        out = raw(*a, **k)
+        if on:
+            unet.prof_enable(False, 16384)
+        return out
+
+    calls["prof"] = False
+    unet.forward_raw = forward_sampled
+    unet.prof_enable(True, 16384)        # allocate the event pool outside the timed region
+    unet.prof_enable(False, 16384)
+
+    def one_step():
+        cb = make_batch_controller()
+        register_attention_control(model, cb)
+        return eng.run(xT, zs, prompt_pairs, cfg_scales, cb, eta=1.0, p2p=True, implicit=True, K=K, w_rec=0.1,
+                       after_skip_steps=T, ddim_inv=False, ctx=(null, src, tar))
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    unet.prof_reset()
+    calls["prof"] = True
+    calls["n"] = 0
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        edit, recon = one_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    calls["prof"] = False
+    unet_calls = calls["n"]
+
+    finite = bool(torch.isfinite(edit).all())
+    recon_err = float(((recon - w0).norm() / w0.norm()).item())
+    prof = unet.prof_collect()
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    imgs = args.steps * n * world
+    sample_fwd_per_img = (4 + 5 * K) * T
+    total_flops = imgs * sample_fwd_per_img * (FLOP_PER_SAMPLE_FWD if not args.tiny else 0.0)
+    # dominant kernel = the class with the largest sampled time
+    dom = max(prof.items(), key=lambda kv: kv[1][0])
+    dk, (dms, dfl, dcnt) = dom
+    kernels = {k: {"ms": round(v[0], 3), "tflops": round(v[1] / 1e12, 4), "launches": v[2],
+                   "tflops_per_s": round(v[1] / 1e9 / v[0], 1) if v[0] > 0 and v[1] > 0 else None}
+               for k, v in prof.items()}
+    sampled_ms = sum(v[0] for v in prof.values())
+    roof = {"bound": "mfma", "kernel": {"conv3x3_gemm": "igemm_kernel<BN,conv> (3x3 conv as implicit GEMM)",
+                                        "linear_gemm": "igemm_kernel<BN,0> (linear / 1x1)",
+                                        "self_attn": "self_attn_kernel<D>", "cross_attn": "cross_attn_kernel<D>",
+                                        "norm": "gn_*/layernorm kernels", "other": "geglu/concat"}[dk],
+            "achieved": round(dfl / 1e9 / dms, 2) if dms > 0 else None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(dfl / 1e9 / dms / MFMA_PEAK_TFLOPS, 4) if dms > 0 else None,
+            "avg_launch_us": round(1e3 * dms / max(dcnt, 1), 2), "launches_sampled": dcnt,
+            "alg_flops_per_launch": round(dfl / max(dcnt, 1), 0),
+            "share_of_sampled_time": round(dms / sampled_ms, 4) if sampled_ms > 0 else None,
+            "traffic": None}
+    pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            roof["traffic"] = json.load(open(pmc)).get(dk, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and not args.tiny:
+        cpu = cpu_baseline(cfg, sd_cpu, T, K)
+
+    out = {
+        "metric": "edited images/sec (512^2, 50 steps, K Langevin)", "value": round(imgs / elapsed, 4),
+        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: text-guided h_Edit_p2p_implicit (h-Edit-R + P2P), "
+                               "SD-1.5-shaped random-init UNet (859.5M), 64x64 latent (512^2 image), "
+                               f"{T} DDIM steps, K={K} implicit step(s), CFG (1,5,7.5), xa 0.4, sa 0.35; "
+                               f"{n} independent images per GPU in lock-step",
+                   "images_per_gpu": n, "unet_sample_forwards_per_image": sample_fwd_per_img,
+                   "unet_calls_in_timed_region": unet_calls, "parallelism": f"replica-dp{world}"},
+        "achieved_tflops_per_s_per_gpu": round(total_flops / elapsed / 1e12 / world, 1),
+        "mfma_frac_whole_loop": round(total_flops / elapsed / 1e12 / world / MFMA_PEAK_TFLOPS, 4),
+        "ms_per_unet_sample_forward": round(1e3 * elapsed * world / (imgs * sample_fwd_per_img), 4),
+        "roofline": roof, "kernels_sampled": kernels, "cpu_baseline": cpu,
+        "finite": finite, "recon_rel_err": round(recon_err, 5),
+        "setup_s": {"weights_create_broadcast_load": round(t_weights, 1), "ddpm_inversion_untimed": round(t_inversion, 2)},
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, sd_cpu, T, K):
+    """The oracle (CPU fp32 eager restatement = "port" of the reference's CPU path) timed on this
+    box's host cores on a bounded sample of the same workload: ONE base pass of one image
+    (4 UNet sample-forwards of the 450 an image needs)."""
+    sys.path.insert(0, ROOT)
+    from oracle import sd_unet as OU
+    net = OU.UNet2DConditionModel(**cfg)
+    net.load_state_dict(sd_cpu)
+    net.eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 4, cfg["sample_size"], cfg["sample_size"], generator=g)
+    ctx = torch.randn(4, 77, cfg["cross_attention_dim"], generator=g)
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        net(x[:1], torch.tensor(481), encoder_hidden_states=ctx[:1])      # warm-up (1 sample-forward)
+        t0 = time.perf_counter()
+        net(x, torch.tensor(481), encoder_hidden_states=ctx)
+        dt = time.perf_counter() - t0
+    per_fwd = dt / 4
+    per_img = per_fwd * (4 + 5 * K) * T
+    return {"value": round(1.0 / per_img, 6), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 UNet call of 4 rows (4 of the {(4 + 5 * K) * T} sample-forwards of one image) by the "
+                      f"fp32 eager oracle on {threads} host threads = {dt:.2f} s; images/s extrapolated by "
+                      "sample-forward count",
+            "s_per_unet_sample_forward": round(per_fwd, 3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -99,6 +99,12 @@ struct hedit_unet {
   Attn mid_attn;
   int32_t* iota = nullptr;
   int iota_cap = 0;
+  // sampled launch timing (bench.py roofline): HIP event pairs on the launch stream
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_pool;
+  struct ProfRec { int kind; double flops; int e0, e1; };
+  std::vector<ProfRec> prof_recs;
+  size_t prof_next = 0;
 };
 
 namespace {
@@ -215,6 +221,28 @@ struct Fwd {
     if (!(f).dry()) TRY(expr);  \
   } while (0)
 
+// kernel classes of the sampled profiler
+enum { PK_CONV = 0, PK_LINEAR = 1, PK_SELF_ATTN = 2, PK_CROSS_ATTN = 3, PK_NORM = 4, PK_OTHER = 5, PK_COUNT = 6 };
+
+struct ProfScope {
+  hedit_unet* h;
+  hipStream_t st;
+  int rec = -1;
+  ProfScope(Fwd& f, int kind, double flops);
+  ~ProfScope() {
+    if (rec >= 0) (void)hipEventRecord(h->prof_pool[h->prof_recs[rec].e1], st);
+  }
+};
+
+ProfScope::ProfScope(Fwd& f, int kind, double flops) : h(f.h), st(f.st) {
+  if (f.dry() || !h->prof_on || h->prof_next + 2 > h->prof_pool.size()) return;
+  hedit_unet::ProfRec r{kind, flops, (int)h->prof_next, (int)h->prof_next + 1};
+  h->prof_next += 2;
+  h->prof_recs.push_back(r);
+  rec = (int)h->prof_recs.size() - 1;
+  (void)hipEventRecord(h->prof_pool[r.e0], st);
+}
+
 template <class T>
 int aalloc(Fwd& f, T** out, size_t n) {
   *out = reinterpret_cast<T*>(f.ar.alloc(n * sizeof(T)));
@@ -229,7 +257,10 @@ int run_gemm(Fwd& f, GemmParams p) {
   const int splits = gemm_pick_splits(p.M, p.N, p.K, 0);
   float* part = nullptr;
   if (splits > 1) TRY(aalloc(f, &part, (size_t)splits * p.M * p.N));
-  RUN(f, gemm_launch(p, splits, part, f.st));
+  {
+    ProfScope ps(f, p.mode == 0 ? PK_LINEAR : PK_CONV, 2.0 * p.M * p.N * p.K);
+    RUN(f, gemm_launch(p, splits, part, f.st));
+  }
   if (part) f.ar.free(part);
   return HEDIT_OK;
 }
@@ -257,7 +288,10 @@ int conv3x3(Fwd& f, const bf16_t* X, int Hin, int Win, int Cin, const bf16_t* W,
 int groupnorm(Fwd& f, const bf16_t* x, bf16_t* y, const float* g, const float* b, int HW, int C, float eps, int silu) {
   float* ws;
   TRY(aalloc(f, &ws, groupnorm_ws_bytes(f.B, HW, C) / sizeof(float)));
-  RUN(f, groupnorm_launch(x, y, g, b, f.B, HW, C, f.h->cfg.norm_num_groups, eps, silu, ws, f.st));
+  {
+    ProfScope ps(f, PK_NORM, 0.0);
+    RUN(f, groupnorm_launch(x, y, g, b, f.B, HW, C, f.h->cfg.norm_num_groups, eps, silu, ws, f.st));
+  }
   f.ar.free(ws);
   return HEDIT_OK;
 }
@@ -304,7 +338,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
 
   // ---- self-attention
   TRY(aalloc(f, &tn, M * C));
-  RUN(f, layernorm_launch(t0, tn, a.ln1g, a.ln1b, (long)M, C, 1e-5f, f.st));
+  { ProfScope ps(f, PK_NORM, 0.0); RUN(f, layernorm_launch(t0, tn, a.ln1g, a.ln1b, (long)M, C, 1e-5f, f.st)); }
   TRY(aalloc(f, &qk, M * 2 * C));
   TRY(linear(f, tn, (int)M, C, a.w_qk, 2 * C, nullptr, nullptr, qk, 2 * C));
   TRY(aalloc(f, &vt, M * C));
@@ -316,6 +350,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
     sp.q = qk; sp.ldq = 2 * C; sp.k = qk + C; sp.ldk = 2 * C; sp.vt = vt; sp.ldvt = (long)M;
     sp.out = ao; sp.ldo = C; sp.B = B; sp.N = N; sp.heads = heads; sp.d = d;
     sp.qk_src = (pl && pl->qk_src && N <= 1024) ? pl->qk_src : nullptr;
+    ProfScope ps(f, PK_SELF_ATTN, 4.0 * B * (double)N * N * C);
     RUN(f, self_attn_launch(sp, f.st));
   }
   f.ar.free(qk);
@@ -327,7 +362,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
 
   // ---- cross-attention (P2P edits + store happen inside the kernel)
   TRY(aalloc(f, &tn, M * C));
-  RUN(f, layernorm_launch(t1, tn, a.ln2g, a.ln2b, (long)M, C, 1e-5f, f.st));
+  { ProfScope ps(f, PK_NORM, 0.0); RUN(f, layernorm_launch(t1, tn, a.ln2g, a.ln2b, (long)M, C, 1e-5f, f.st)); }
   TRY(aalloc(f, &q2, M * C));
   TRY(linear(f, tn, (int)M, C, a.w_q2, C, nullptr, nullptr, q2, C));
   f.ar.free(tn);
@@ -351,6 +386,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
       cp.n_pairs = 0; cp.singles = f.h->iota; cp.n_single = B;
     }
     if (stored_layer) f.store_idx++;
+    ProfScope ps(f, PK_CROSS_ATTN, 4.0 * B * (double)N * HEDIT_MAXW * C);
     RUN(f, cross_attn_launch(cp, f.st));
   }
   f.ar.free(q2);
@@ -363,12 +399,12 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
 
   // ---- GEGLU feed-forward
   TRY(aalloc(f, &tn, M * C));
-  RUN(f, layernorm_launch(t2, tn, a.ln3g, a.ln3b, (long)M, C, 1e-5f, f.st));
+  { ProfScope ps(f, PK_NORM, 0.0); RUN(f, layernorm_launch(t2, tn, a.ln3g, a.ln3b, (long)M, C, 1e-5f, f.st)); }
   TRY(aalloc(f, &hf, M * 8 * C));
   TRY(linear(f, tn, (int)M, C, a.ff1, 8 * C, a.ff1_b, nullptr, hf, 8 * C));
   f.ar.free(tn);
   TRY(aalloc(f, &gf, M * 4 * C));
-  RUN(f, geglu_launch(hf, gf, (long)M, 4 * C, f.st));
+  { ProfScope ps(f, PK_OTHER, 0.0); RUN(f, geglu_launch(hf, gf, (long)M, 4 * C, f.st)); }
   f.ar.free(hf);
   TRY(aalloc(f, &t3, M * C));
   TRY(linear(f, gf, (int)M, 4 * C, a.ff2, C, a.ff2_b, t2, t3, C));
@@ -478,7 +514,7 @@ int forward_impl(hedit_unet* h, const float* x, float t, const float* ctx, int B
       bf16_t* cat;
       const size_t M = (size_t)B * H * W;
       TRY(aalloc(f, &cat, M * (cur_c + s.C)));
-      RUN(f, concat_launch(cur, cur_c, s.p, s.C, cat, (long)M, st));
+      { ProfScope ps(f, PK_OTHER, 0.0); RUN(f, concat_launch(cur, cur_c, s.p, s.C, cat, (long)M, st)); }
       f.ar.free(cur);
       f.ar.free(s.p);
       bf16_t* y;
@@ -628,6 +664,7 @@ int hedit_unet_create(const hedit_unet_cfg* cfg, hedit_unet** out) {
 void hedit_unet_destroy(hedit_unet* h) {
   if (!h) return;
   for (void* p : h->owned) (void)hipFree(p);
+  for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -701,6 +738,44 @@ int hedit_unet_forward(hedit_unet* h, const float* x, float t, const float* ctx,
   }
   return forward_impl(h, x, t, ctx, B, height, width, plan, eps_out, workspace, workspace_bytes,
                       reinterpret_cast<hipStream_t>(stream), false, nullptr);
+}
+
+int hedit_prof_enable(hedit_unet* h, int on, int max_records) {
+  ARG_CHECK(h, "null");
+  if (on && (int)h->prof_pool.size() < 2 * max_records) {
+    const size_t want = (size_t)2 * max_records;
+    while (h->prof_pool.size() < want) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      h->prof_pool.push_back(e);
+    }
+  }
+  h->prof_on = on != 0;
+  return HEDIT_OK;
+}
+
+int hedit_prof_reset(hedit_unet* h) {
+  ARG_CHECK(h, "null");
+  h->prof_recs.clear();
+  h->prof_next = 0;
+  return HEDIT_OK;
+}
+
+/* call after the stream has been synchronised */
+int hedit_prof_collect(hedit_unet* h, int kind, double* total_ms, double* total_flops, int64_t* count) {
+  ARG_CHECK(h && total_ms && total_flops && count && kind >= 0 && kind < PK_COUNT, "prof args");
+  double ms = 0, fl = 0;
+  int64_t n = 0;
+  for (auto& r : h->prof_recs) {
+    if (r.kind != kind) continue;
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, h->prof_pool[r.e0], h->prof_pool[r.e1]));
+    ms += t;
+    fl += r.flops;
+    ++n;
+  }
+  *total_ms = ms; *total_flops = fl; *count = n;
+  return HEDIT_OK;
 }
 
 static void store_layers(const hedit_unet* h, int height, int width, std::vector<std::pair<int, int>>& v) {

@@ -47,6 +47,10 @@ _SIGS = {
     "hedit_unet_num_store_layers": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "hedit_unet_store_layer_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                               C.POINTER(C.c_int)]),
+    "hedit_prof_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "hedit_prof_reset": (C.c_int, [C.c_void_p]),
+    "hedit_prof_collect": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_int64)]),
     "hedit_step_base": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                   C.c_int, C.POINTER(StepCoef), C.c_void_p]),
     "hedit_step_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,

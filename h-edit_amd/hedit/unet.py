@@ -210,6 +210,25 @@ class UNet2DConditionModel:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    # ---------------------------------------------------------------- sampled launch timing
+    PROF_KINDS = ("conv3x3_gemm", "linear_gemm", "self_attn", "cross_attn", "norm", "other")
+
+    def prof_enable(self, on, max_records=8192):
+        _lib.check(self._lib.hedit_prof_enable(self._h, int(on), max_records))
+
+    def prof_reset(self):
+        _lib.check(self._lib.hedit_prof_reset(self._h))
+
+    def prof_collect(self):
+        """{kind: (total_ms, total_flops, launches)}; synchronises the device first."""
+        torch.cuda.synchronize(self.device)
+        out = {}
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+        for i, k in enumerate(self.PROF_KINDS):
+            _lib.check(self._lib.hedit_prof_collect(self._h, i, C.byref(ms), C.byref(fl), C.byref(n)))
+            out[k] = (ms.value, fl.value, n.value)
+        return out
+
     # ---------------------------------------------------------------- forward
     def forward_raw(self, sample, t, ctx, plan=None, out=None):
         """sample fp32 (B,C,H,W) cuda, t python float, ctx fp32 (B,77,D) cuda, plan: _lib.P2PPlan."""

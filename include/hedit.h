@@ -105,6 +105,15 @@ int hedit_unet_num_store_layers(const hedit_unet* h, int height, int width);
 int hedit_unet_store_layer_info(const hedit_unet* h, int height, int width, int i, int* tokens,
                                 int* place /*0 down,1 mid,2 up*/);
 
+/* Sampled launch timing for bench.py's roofline: while enabled, every kernel launch of
+ * hedit_unet_forward is bracketed by a HIP event pair on the launch stream (up to max_records
+ * launches).  kind: 0 conv3x3 GEMM, 1 linear/1x1 GEMM, 2 self-attention, 3 cross-attention,
+ * 4 Group/LayerNorm, 5 other.  total_flops is the ALGORITHMIC count (2MNK; 4 B N Nk C for
+ * attention).  Call hedit_prof_collect only after synchronising the stream. */
+int hedit_prof_enable(hedit_unet* h, int on, int max_records);
+int hedit_prof_reset(hedit_unet* h);
+int hedit_prof_collect(hedit_unet* h, int kind, double* total_ms, double* total_flops, int64_t* count);
+
 /* ---- sampler steps ------------------------------------------------------------------------
  * Batched tensors are [row][image][elems]: for one image this is exactly the reference layout.
  *   eps of the base pass: rows = 4 -> [x_o|null, x_e|null, x_o|src, x_e|src] (P2P loops),

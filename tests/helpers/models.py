@@ -9,12 +9,17 @@ from hedit.text import ClipTextEncoder, WordTokenizer
 from hedit.unet import SD15_CONFIG, TINY_CONFIG, UNet2DConditionModel, random_state_dict
 
 
-def make_pair(config, num_steps, seed=0, device="cuda:0", text_layers=2):
-    """returns (hip_model, oracle_model, state_dict)"""
+def make_pair(config, num_steps, seed=0, device="cuda:0", text_layers=2, out_scale=1.0):
+    """returns (hip_model, oracle_model, state_dict).  out_scale damps the synthetic network's
+    output layer: a random-weight eps-network at full gain makes the sampler chain chaotic (any
+    perturbation grows ~2x per step), which says nothing about kernel correctness."""
     from oracle import sd_unet as OU
     cfg = dict(config)
     unet = UNet2DConditionModel(cfg, device=device)
     sd = random_state_dict(unet.param_shapes, seed)
+    if out_scale != 1.0:
+        sd["conv_out.weight"] = sd["conv_out.weight"] * out_scale
+        sd["conv_out.bias"] = sd["conv_out.bias"] * out_scale
     unet.load_state_dict(sd)
     tok = WordTokenizer()
     dim = cfg["cross_attention_dim"]

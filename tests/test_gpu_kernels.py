@@ -59,7 +59,8 @@ def test_gemm_conv3x3(lib, mode, B, H, Wd, Cin, Cout):
     bias = torch.randn(Cout, generator=g)
     xb = G.bf(x.permute(0, 2, 3, 1))                       # NHWC
     wq = torch.empty(Cout * 9 * Cin, dtype=torch.bfloat16, device=G.dev())
-    _lib.check(lib.hedit_k_pack_conv3x3(_lib.ptr(G.f32(w)), _lib.ptr(wq), Cout, Cin, None))
+    wd = G.f32(w)
+    _lib.check(lib.hedit_k_pack_conv3x3(_lib.ptr(wd), _lib.ptr(wq), Cout, Cin, None))
     xr = xb.float().permute(0, 3, 1, 2)
     wr = G.bf(w).float()
     if mode == 1:
@@ -239,8 +240,9 @@ def test_step_kernels_match_reference_vectors(lib, golden_dir):
                 coef = S.step_coef(t, max(t - 50, 0), eta, ddim, (1.0, 5.0, 7.5))
                 # rows [x_o|0, x_e|0, x_o|src, x_e|src] with w_src = 1 -> eps = conditional rows
                 e4 = G.f32(torch.cat([torch.zeros_like(eps), eps]))
+                xd, zd = G.f32(x), G.f32(z)            # keep the device copies alive across the launch
                 out = torch.zeros(2, *x.shape[1:], device=G.dev())
-                _lib.check(lib.hedit_step_base(_lib.ptr(e4), _lib.ptr(G.f32(x)), _lib.ptr(G.f32(z)), _lib.ptr(out), 1,
+                _lib.check(lib.hedit_step_base(_lib.ptr(e4), _lib.ptr(xd), _lib.ptr(zd), _lib.ptr(out), 1,
                                                elems, 4, C.byref(coef), None))
                 G.sync()
                 want = torch.from_numpy(g[f"prev_t{t}_eta{int(eta)}_ddim{int(ddim)}"])
@@ -255,9 +257,9 @@ def test_step_kernels_match_reference_vectors(lib, golden_dir):
     coef = S.step_coef(501, 451, 1.0, False, (1.0, 5.0, 7.5), w_rec=0.1)
     for k_gt0 in (0, 1):
         out = torch.zeros(n, el, device=G.dev())
-        ed = G.f32(e)
+        ed, xkd, xbd = G.f32(e), G.f32(xk), G.f32(xb)
         _lib.check(lib.hedit_step_update(_lib.ptr(ed[0]), _lib.ptr(ed[2]), _lib.ptr(ed[1]), _lib.ptr(ed[3]), el,
-                                         _lib.ptr(G.f32(xk)), _lib.ptr(G.f32(xb)), _lib.ptr(out), n, el, k_gt0,
+                                         _lib.ptr(xkd), _lib.ptr(xbd), _lib.ptr(out), n, el, k_gt0,
                                          C.byref(coef), None))
         G.sync()
         for i in range(n):
