@@ -90,50 +90,58 @@ __global__ __launch_bounds__(256) void self_attn_kernel(SelfAttnParams p) {
   constexpr int K_IT = (64 * H::DCH + 255) / 256;
   constexpr int V_IT = (D * 8 + 255) / 256;
   uint4 kreg[K_IT], vreg[V_IT];
-  const bf16_t* kbase = p.k + (long)bqk * p.N * p.ldk + h * D;
-  const bf16_t* vbase = p.vt + (long)h * D * p.ldvt + (long)b * p.N;
-
-  auto load_regs = [&](int kv0) {
+  // per-thread staging coordinates, fixed for the whole KV loop
+  const bf16_t* kptr[K_IT];
+  const bf16_t* vptr[V_IT];
+  int klds[K_IT], vlds[V_IT];
+  bool kok[K_IT], vok[V_IT];
+  {
+    const bf16_t* kbase = p.k + (long)bqk * p.N * p.ldk + h * D;
+    const bf16_t* vbase = p.vt + (long)h * D * p.ldvt + (long)b * p.N;
 #pragma unroll
     for (int i = 0; i < K_IT; ++i) {
       const int idx = tid + i * 256;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (idx < 64 * H::DCH) {
-        const int row = idx / H::DCH, c = idx - row * H::DCH;
-        v = *reinterpret_cast<const uint4*>(kbase + (long)(kv0 + row) * p.ldk + c * 8);
-      }
-      kreg[i] = v;
+      const int row = idx / H::DCH, c = idx - row * H::DCH;
+      kok[i] = idx < 64 * H::DCH;
+      kptr[i] = kbase + (long)row * p.ldk + c * 8;
+      klds[i] = row * H::KS + c * 8;
     }
 #pragma unroll
     for (int i = 0; i < V_IT; ++i) {
       const int idx = tid + i * 256;
+      const int row = idx >> 3, c = idx & 7;
+      vok[i] = idx < D * 8;
+      vptr[i] = vbase + (long)row * p.ldvt + c * 8;
+      vlds[i] = row * VS + c * 8;
+    }
+  }
+  const long kstep = 64L * p.ldk;
+
+  auto load_regs = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < K_IT; ++i) {
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (idx < D * 8) {
-        const int row = idx >> 3, c = idx & 7;
-        v = *reinterpret_cast<const uint4*>(vbase + (long)row * p.ldvt + kv0 + c * 8);
-      }
+      if (kok[i]) v = *reinterpret_cast<const uint4*>(kptr[i] + t * kstep);
+      kreg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < V_IT; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (vok[i]) v = *reinterpret_cast<const uint4*>(vptr[i] + t * 64);
       vreg[i] = v;
     }
   };
   auto store_lds = [&]() {
 #pragma unroll
-    for (int i = 0; i < K_IT; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < 64 * H::DCH) {
-        const int row = idx / H::DCH, c = idx - row * H::DCH;
-        *reinterpret_cast<uint4*>(sK + row * H::KS + c * 8) = kreg[i];
-      }
-    }
+    for (int i = 0; i < K_IT; ++i)
+      if (kok[i]) *reinterpret_cast<uint4*>(sK + klds[i]) = kreg[i];
 #pragma unroll
-    for (int i = 0; i < V_IT; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < D * 8) {
-        const int row = idx >> 3, c = idx & 7;
-        uint2* dst = reinterpret_cast<uint2*>(sV + row * VS + c * 8);
+    for (int i = 0; i < V_IT; ++i)
+      if (vok[i]) {
+        uint2* dst = reinterpret_cast<uint2*>(sV + vlds[i]);
         dst[0] = make_uint2(vreg[i].x, vreg[i].y);
         dst[1] = make_uint2(vreg[i].z, vreg[i].w);
       }
-    }
   };
 
   f32x16 o[H::DT];
@@ -149,8 +157,14 @@ __global__ __launch_bounds__(256) void self_attn_kernel(SelfAttnParams p) {
   store_lds();
   __syncthreads();
 
+  // Lazy rescale: the running maximum (log2 domain) is only raised -- and O, l rescaled -- when
+  // some row's tile maximum exceeds it by more than RESCALE_THR; until then probabilities are
+  // formed against the stale maximum and are bounded by 2^RESCALE_THR (bf16 has fp32's exponent
+  // range, fp32 accumulators: no precision is lost).  Saves an O-wide VALU pass on most tiles.
+  constexpr float RESCALE_THR = 10.0f;
+
   for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) load_regs((t + 1) * 64);
+    if (t + 1 < ntiles) load_regs(t + 1);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s;
@@ -165,18 +179,23 @@ __global__ __launch_bounds__(256) void self_attn_kernel(SelfAttnParams p) {
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = fast_exp2(m_run - m_new);
-      m_run = m_new;
+      if (!__all(mx - m_run <= RESCALE_THR)) {
+        // every P.V accumulated so far is complete at this point, so O and l are the only state
+        // still expressed against the old maximum
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = fast_exp2(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < H::DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      }
       float pr[16];
       float ls = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { pr[r] = fast_exp2(s[r] - m_new); ls += pr[r]; }
-      l_run = l_run * alpha + ls;
-#pragma unroll
-      for (int dt = 0; dt < H::DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      for (int r = 0; r < 16; ++r) { pr[r] = fast_exp2(s[r] - m_run); ls += pr[r]; }
+      l_run += ls;
       const bf16x8 pf0 = pack_p8(pr), pf1 = pack_p8(pr + 8);
 #pragma unroll
       for (int dt = 0; dt < H::DT; ++dt) {

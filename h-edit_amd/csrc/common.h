@@ -60,8 +60,12 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+// native conversion: lets the compiler emit v_cvt_pk_bf16_f32 (round-to-nearest-even)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  union { bf16x2_t v; uint32_t u; } x;
+  x.v = (bf16x2_t){(__bf16)lo, (__bf16)hi};
+  return x.u;
 }
 __device__ inline float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ inline float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

@@ -48,9 +48,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(GemmParams p) {
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
+  // XCD-aware tile order.  Workgroup b is observed to run on XCD b % 8 (speed only, never
+  // correctness): give every XCD one contiguous chunk of the tile sequence so that tiles which
+  // share an operand panel hit the same 4 MiB L2.  Within the sequence the n-tiles of one m-tile
+  // are adjacent when the activation operand is the big one (they re-use its rows), and the
+  // m-tiles of one n-tile are adjacent when the weight panel is the big one.
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int tile_m = blockIdx.x % tiles_m;
-  const int tile_n = blockIdx.x / tiles_m;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int v;
+  {
+    const int nb = tiles_m * tiles_n, bid = blockIdx.x;
+    const int xcd = bid & 7, seq = bid >> 3, q = nb >> 3, r = nb & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + seq;
+  }
+  const int tile_m = p.n_fastest ? v / tiles_n : v % tiles_m;
+  const int tile_n = p.n_fastest ? v % tiles_n : v / tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int split = blockIdx.y;
   const int kt_begin = split * p.kt_per_split;
@@ -100,7 +112,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(GemmParams p) {
   uint4 a_reg[A_CH], w_reg[W_CH];
 
   auto load_tile = [&](int kt) {
-    const int k0 = kt * BK;
+    // K-tile order.  linear: k0 = kt*64.  conv: the 9 taps of one 64-channel slab are visited
+    // back to back (tap = kt % 9, slab = kt / 9) so the shifted re-reads of the same input
+    // pixels are nine consecutive K-tiles apart at most -> they stay in L1/L2.
+    int k0 = kt * BK, tap = 0, ci0 = 0;
+    if (MODE != 0) {
+      tap = kt % 9;
+      ci0 = (kt / 9) * BK;
+      k0 = tap * p.Cin + ci0;
+    }
     if (MODE == 0) {
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
@@ -109,8 +129,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(GemmParams p) {
         a_reg[i] = v;
       }
     } else {
-      const int tap = k0 / p.Cin;
-      const int ci0 = k0 - tap * p.Cin;
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
@@ -194,35 +212,80 @@ __global__ __launch_bounds__(256) void igemm_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds rows n = nb + fq*4 + {0..3} of column m = mb + fr
+  // ---- epilogue.  A lane holds 4 consecutive n of column m = mb + fr.
+  if (p.partial) {
+    // split-K: fp32 slab, 16-byte stores
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + fq * 4;
+        if (n >= p.N) continue;
+        float* dst = p.partial + ((long)split * p.M + m) * p.N + n;
+        *reinterpret_cast<f32x4*>(dst) = acc[i][j];
+      }
+    }
+    return;
+  }
+  // bf16 output: stage the 128 x BN tile in LDS (the K loop is over, its buffers are free) and
+  // write it out as whole rows, 16 B per lane, so a wave store instruction covers >= 1 KiB of
+  // contiguous NHWC memory instead of sixteen 32-byte fragments.
+  constexpr int CS = BN + 8;                  // padded row stride (elements): 16-B aligned rows
+  bf16_t* sc = reinterpret_cast<bf16_t*>(smem);
+  static_assert(BM * CS * 2 <= S::TOTAL, "epilogue tile must fit the staging LDS");
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + fr;
-    if (m >= p.M) continue;
+    const int ml = wm * 64 + i * 16 + fr;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 16 + fq * 4;
-      if (n >= p.N) continue;   // N is a multiple of 4
+      const int nl = wn * (BN / 2) + j * 16 + fq * 4;
+      const int n = n0 + nl;
       f32x4 v = acc[i][j];
-      if (p.partial) {
-        float* dst = p.partial + ((long)split * p.M + m) * p.N + n;
-        *reinterpret_cast<f32x4*>(dst) = v;
-      } else {
-        if (p.bias) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-          v += b;
-        }
+      if (p.bias && n < p.N) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(sc + ml * CS + nl) = o;
+    }
+  }
+  __syncthreads();
+  constexpr int CHUNKS = BN / 8;              // 16-byte chunks per tile row
+  for (int idx = tid; idx < BM * CHUNKS; idx += 256) {
+    const int ml = idx / CHUNKS, c = idx - ml * CHUNKS;
+    const int m = m0 + ml, n = n0 + c * 8;
+    if (m >= p.M || n >= p.N) continue;
+    uint4 u = *reinterpret_cast<const uint4*>(sc + ml * CS + c * 8);
+    if (n + 8 <= p.N && (p.ldc & 7) == 0) {
+      if (p.residual) {
+        const uint4 r = *reinterpret_cast<const uint4*>(p.residual + (long)m * p.ldr + n);
+        u.x = pack_bf16x2(bf16_to_f32((bf16_t)(u.x & 0xffff)) + bf16_to_f32((bf16_t)(r.x & 0xffff)),
+                          bf16_to_f32((bf16_t)(u.x >> 16)) + bf16_to_f32((bf16_t)(r.x >> 16)));
+        u.y = pack_bf16x2(bf16_to_f32((bf16_t)(u.y & 0xffff)) + bf16_to_f32((bf16_t)(r.y & 0xffff)),
+                          bf16_to_f32((bf16_t)(u.y >> 16)) + bf16_to_f32((bf16_t)(r.y >> 16)));
+        u.z = pack_bf16x2(bf16_to_f32((bf16_t)(u.z & 0xffff)) + bf16_to_f32((bf16_t)(r.z & 0xffff)),
+                          bf16_to_f32((bf16_t)(u.z >> 16)) + bf16_to_f32((bf16_t)(r.z >> 16)));
+        u.w = pack_bf16x2(bf16_to_f32((bf16_t)(u.w & 0xffff)) + bf16_to_f32((bf16_t)(r.w & 0xffff)),
+                          bf16_to_f32((bf16_t)(u.w >> 16)) + bf16_to_f32((bf16_t)(r.w >> 16)));
+      }
+      *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = u;
+    } else {
+      // ragged right edge (N % 8 == 4) or 8-byte-aligned rows only: two 8-byte halves
+      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int nn = n + hh * 4;
+        if (nn >= p.N) continue;
+        uint2 o = make_uint2(w[hh * 2], w[hh * 2 + 1]);
         if (p.residual) {
-          const uint2 r = *reinterpret_cast<const uint2*>(p.residual + (long)m * p.ldr + n);
-          v[0] += bf16_to_f32((bf16_t)(r.x & 0xffff));
-          v[1] += bf16_to_f32((bf16_t)(r.x >> 16));
-          v[2] += bf16_to_f32((bf16_t)(r.y & 0xffff));
-          v[3] += bf16_to_f32((bf16_t)(r.y >> 16));
+          const uint2 r = *reinterpret_cast<const uint2*>(p.residual + (long)m * p.ldr + nn);
+          o.x = pack_bf16x2(bf16_to_f32((bf16_t)(o.x & 0xffff)) + bf16_to_f32((bf16_t)(r.x & 0xffff)),
+                            bf16_to_f32((bf16_t)(o.x >> 16)) + bf16_to_f32((bf16_t)(r.x >> 16)));
+          o.y = pack_bf16x2(bf16_to_f32((bf16_t)(o.y & 0xffff)) + bf16_to_f32((bf16_t)(r.y & 0xffff)),
+                            bf16_to_f32((bf16_t)(o.y >> 16)) + bf16_to_f32((bf16_t)(r.y >> 16)));
         }
-        uint2 o;
-        o.x = pack_bf16x2(v[0], v[1]);
-        o.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(p.C + (long)m * p.ldc + n) = o;
+        *reinterpret_cast<uint2*>(p.C + (long)m * p.ldc + nn) = o;
       }
     }
   }
@@ -281,8 +344,8 @@ int gemm_pick_splits(int M, int N, int K, int force) {
   const int bn = gemm_pick_bn(N);
   const long tiles = (long)cdiv(M, BM) * cdiv(N, bn);
   const int kt = K / BK;
-  if (tiles >= 192 || kt < 8) return 1;
-  int s = (int)((512 + tiles - 1) / tiles);     // aim at ~2 blocks per CU
+  if (tiles >= 384 || kt < 8) return 1;
+  int s = (int)((640 + tiles - 1) / tiles);     // aim at >= 2 resident blocks per CU
   int max_s = kt / 4;                            // keep >= 4 K-tiles per split
   if (s > max_s) s = max_s;
   if (s > 32) s = 32;
@@ -313,6 +376,12 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
     p.partial = nullptr;
   }
   const int bn = gemm_pick_bn(p.N);
+  {
+    // unique operand bytes: activations M x (K or Cin), weights N x K
+    const double a_bytes = (double)p.M * (p.mode == 0 ? p.K : p.Cin);
+    const double w_bytes = (double)p.N * p.K;
+    p.n_fastest = a_bytes >= w_bytes ? 1 : 0;
+  }
   int rc;
 #define DISPATCH(BNV)                                                     \
   switch (p.mode) {                                                       \

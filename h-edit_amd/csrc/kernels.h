@@ -17,6 +17,7 @@ struct GemmParams {
   int ldc;
   float* partial;    // set by gemm_launch
   int splits, kt_per_split;
+  int n_fastest;     // tile order, set by gemm_launch
 };
 int gemm_pick_bn(int N);
 int gemm_pick_splits(int M, int N, int K, int force);

@@ -85,34 +85,38 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
   }
 }
 
-// stage 2: fold slabs -> mean / rstd per group, then per-channel scale & shift for this batch
+// stage 2: fold slabs -> mean / rstd per group (one wave per group, lanes stride over slabs, fixed
+// summation order), then per-channel scale & shift for this batch item
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ ss,
                                                           int HW, int C, int G, int nslab, float eps) {
   __shared__ float mean[64], rstd[64];
   const int b = blockIdx.x;
-  if ((int)threadIdx.x < G) {
-    const int g = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int g = wave; g < G; g += 4) {
     float s = 0.f, q = 0.f;
-    for (int sl = 0; sl < nslab; ++sl) {
-      const float* src = part + (((long)b * nslab + sl) * G + g) * 2;
-      s += src[0];
-      q += src[1];
+    for (int sl = lane; sl < nslab; sl += 64) {
+      const float2 v = *reinterpret_cast<const float2*>(part + (((long)b * nslab + sl) * G + g) * 2);
+      s += v.x;
+      q += v.y;
     }
-    const float n = (float)HW * (float)(C / G);
-    const float m = s / n;
-    float var = q / n - m * m;
-    var = var < 0.f ? 0.f : var;
-    mean[g] = m;
-    rstd[g] = rsqrtf(var + eps);
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) {
+      const float n = (float)HW * (float)(C / G);
+      const float m = s / n;
+      float var = q / n - m * m;
+      var = var < 0.f ? 0.f : var;
+      mean[g] = m;
+      rstd[g] = rsqrtf(var + eps);
+    }
   }
   __syncthreads();
   const int cpg = C / G;
   for (int c = threadIdx.x; c < C; c += 256) {
     const int g = c / cpg;
     const float sc = rstd[g] * gamma[c];
-    ss[((long)b * C + c) * 2 + 0] = sc;
-    ss[((long)b * C + c) * 2 + 1] = beta[c] - mean[g] * sc;
+    *reinterpret_cast<float2*>(ss + ((long)b * C + c) * 2) = make_float2(sc, beta[c] - mean[g] * sc);
   }
 }
 
@@ -284,32 +288,48 @@ __global__ void timestep_embed_kernel(float t, float* out, int dim) {
 }
 
 // ------------------------------------------------------------------ conv_in (Cin <= 8, K = 9 Cin tiny -> VALU)
+// Block = 64 consecutive pixels x all output channels.  The 9*Cin input taps of the block's pixels
+// and the whole (transposed) weight matrix live in LDS; a thread produces 8 consecutive output
+// channels of one pixel -> 16-byte NHWC stores.
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                       bf16_t* __restrict__ y, int B, int Cin, int H, int Wd, int Cout) {
+  extern __shared__ float lds[];
+  const int K = Cin * 9;
+  float* sw = lds;                    // [K][Cout]   (k = ci*9 + tap)
+  float* sx = lds + (long)K * Cout;   // [64][K]
+  for (int i = threadIdx.x; i < K * Cout; i += 256) {
+    const int co = i / K, k = i - co * K;      // global layout [Cout][Cin][3][3] = [Cout][K]
+    sw[k * Cout + co] = w[i];
+  }
+  const long pix0 = (long)blockIdx.x * 64;
+  const long npix = (long)B * H * Wd;
+  for (int i = threadIdx.x; i < 64 * K; i += 256) {
+    const int pl = i / K, k = i - pl * K;
+    const long pix = pix0 + pl;
+    float v = 0.f;
+    if (pix < npix) {
+      const int ox = (int)(pix % Wd), oy = (int)((pix / Wd) % H), b = (int)(pix / ((long)Wd * H));
+      const int ci = k / 9, tap = k - ci * 9;
+      const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd) v = x[(((long)b * Cin + ci) * H + iy) * Wd + ix];
+    }
+    sx[pl * K + k] = v;
+  }
+  __syncthreads();
   const int CV = Cout / 8;
-  const long total = (long)B * H * Wd * CV;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    const long pix = i / CV;
-    const int ox = (int)(pix % Wd);
-    const int oy = (int)((pix / Wd) % H);
-    const int b = (int)(pix / ((long)Wd * H));
+  for (int i = threadIdx.x; i < 64 * CV; i += 256) {
+    const int pl = i / CV, cv = i - pl * CV;
+    const long pix = pix0 + pl;
+    if (pix >= npix) continue;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = bias[cv * 8 + j];
-    for (int ci = 0; ci < Cin; ++ci) {
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy + ky - 1;
-        if ((unsigned)iy >= (unsigned)H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-          const int ix = ox + kx - 1;
-          if ((unsigned)ix >= (unsigned)Wd) continue;
-          const float xv = x[(((long)b * Cin + ci) * H + iy) * Wd + ix];
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            acc[j] += xv * w[(((long)(cv * 8 + j) * Cin + ci) * 3 + ky) * 3 + kx];
-        }
-      }
+    for (int k = 0; k < K; ++k) {
+      const float xv = sx[pl * K + k];
+      const float4 w0 = *reinterpret_cast<const float4*>(sw + k * Cout + cv * 8);
+      const float4 w1 = *reinterpret_cast<const float4*>(sw + k * Cout + cv * 8 + 4);
+      acc[0] += xv * w0.x; acc[1] += xv * w0.y; acc[2] += xv * w0.z; acc[3] += xv * w0.w;
+      acc[4] += xv * w1.x; acc[5] += xv * w1.y; acc[6] += xv * w1.z; acc[7] += xv * w1.w;
     }
     *reinterpret_cast<uint4*>(y + pix * Cout + cv * 8) = pack8(acc);
   }
@@ -458,7 +478,9 @@ int timestep_embed_launch(float t, float* out, int dim, hipStream_t st) {
 int conv_in_launch(const float* x, const float* w, const float* bias, bf16_t* y, int B, int Cin, int H, int W,
                    int Cout, hipStream_t st) {
   ARG_CHECK(Cout % 8 == 0, "conv_in: Cout % 8");
-  hipLaunchKernelGGL(conv_in_kernel, dim3(ew_grid((long)B * H * W * (Cout / 8))), dim3(256), 0, st, x, w, bias, y, B, Cin, H, W, Cout);
+  const size_t lds = ((size_t)Cin * 9 * Cout + 64 * (size_t)Cin * 9) * sizeof(float);
+  ARG_CHECK(lds <= 64 * 1024, "conv_in: Cin*9*(Cout+64) floats must fit 64 KiB of LDS");
+  hipLaunchKernelGGL(conv_in_kernel, dim3(cdiv((long)B * H * W, 64)), dim3(256), lds, st, x, w, bias, y, B, Cin, H, W, Cout);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }
