@@ -21,6 +21,8 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // (not HIP's uint4 struct: aggregate
+                                                               //  copies become memcpy and defeat SROA)
 constexpr int BM = 128;
 constexpr int BK = 64;
 
@@ -35,7 +37,7 @@ struct Smem {
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 template <int BN, int MODE>
-__global__ __launch_bounds__(256) void igemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NI = BN / 32;      // 16-wide n sub-tiles per wave
   constexpr int MI = 4;            // 16-wide m sub-tiles per wave
@@ -70,102 +72,115 @@ __global__ __launch_bounds__(256) void igemm_kernel(GemmParams p) {
   const int kt_total = p.K / BK;
   if (kt_end > kt_total) kt_end = kt_total;
 
-  // ---- per-thread staging coordinates (fixed for the whole K loop)
-  long a_base[A_CH];   // linear: row*lda ; conv: b*Hin*Win (pixel index base)
+  // ---- per-thread staging state, fixed for the whole K loop.  Everything that can be decided
+  // once is decided here so that the K loop issues (almost) nothing but loads, LDS traffic and
+  // MFMAs: out-of-range rows / padded taps read a 16-byte zero page through a pointer select
+  // (no exec-mask branches), the conv gather is "centre pixel pointer + wave-uniform tap delta"
+  // gated by a 9-bit tap mask.
+  const bf16_t* const zero_page = p.zeros;
+  const bf16_t* a_ptr[A_CH];
+  unsigned a_mask[A_CH];     // conv: bit t = tap t is inside the image; linear: ~0 / 0
   int a_oy[A_CH], a_ox[A_CH];
-  bool a_ok[A_CH];
   int a_lds[A_CH];
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
-    int id = tid + i * 256;
-    int row = id >> 3, c = id & 7;
-    int m = m0 + row;
-    a_ok[i] = m < p.M;
+    const int id = tid + i * 256;
+    const int row = id >> 3, c = id & 7;
+    const int m = m0 + row;
+    const bool ok = m < p.M;
     a_lds[i] = swz(row, c);
+    a_oy[i] = a_ox[i] = 0;
     if (MODE == 0) {
-      a_base[i] = (long)m * p.lda + c * 8;
-      a_oy[i] = a_ox[i] = 0;
+      a_ptr[i] = ok ? p.A + (long)m * p.lda + c * 8 : zero_page;
+      a_mask[i] = ok ? ~0u : 0u;
     } else {
-      int hw = p.Hout * p.Wout;
-      int b = m / hw;
-      int r = m - b * hw;
-      int oy = r / p.Wout;
-      int ox = r - oy * p.Wout;
-      a_base[i] = (long)b * p.Hin * p.Win;
-      a_oy[i] = oy;
-      a_ox[i] = ox;
+      const int hw = p.Hout * p.Wout;
+      const int b = m / hw;
+      const int r = m - b * hw;
+      const int oy = r / p.Wout;
+      const int ox = r - oy * p.Wout;
+      if (MODE == 3) {
+        a_ptr[i] = p.A + (long)b * p.Hin * p.Win * p.Cin + c * 8;
+        a_oy[i] = oy;
+        a_ox[i] = ox;
+        a_mask[i] = ok ? 1u : 0u;
+      } else {
+        const int cy = MODE == 2 ? oy * 2 : oy, cx = MODE == 2 ? ox * 2 : ox;
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+          const unsigned in = (unsigned)ok & (unsigned)((unsigned)iy < (unsigned)p.Hin) & (unsigned)((unsigned)ix < (unsigned)p.Win);
+          mk |= in << t;
+        }
+        a_mask[i] = mk;
+        a_ptr[i] = p.A + (((long)b * p.Hin + cy) * p.Win + cx) * p.Cin + c * 8;
+      }
     }
   }
-  long w_base[W_CH];
+  const bf16_t* w_ptr[W_CH];
   bool w_ok[W_CH];
   int w_lds[W_CH];
 #pragma unroll
   for (int i = 0; i < W_CH; ++i) {
-    int id = tid + i * 256;
-    int row = id >> 3, c = id & 7;
-    int n = n0 + row;
+    const int id = tid + i * 256;
+    const int row = id >> 3, c = id & 7;
+    const int n = n0 + row;
     w_ok[i] = n < p.N;
     w_lds[i] = swz(row, c);
-    w_base[i] = (long)n * p.K + c * 8;
+    w_ptr[i] = p.W + (long)n * p.K + c * 8;
   }
 
-  uint4 a_reg[A_CH], w_reg[W_CH];
+  // two register stages: tile k+2 is requested while tile k is being multiplied, so every global
+  // load has two K-iterations to land (2 x 36 KB per block in flight)
+  u32x4 a_reg0[A_CH], w_reg0[W_CH], a_reg1[A_CH], w_reg1[W_CH];
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, u32x4* a_reg, u32x4* w_reg) __attribute__((always_inline)) {
     // K-tile order.  linear: k0 = kt*64.  conv: the 9 taps of one 64-channel slab are visited
     // back to back (tap = kt % 9, slab = kt / 9) so the shifted re-reads of the same input
     // pixels are nine consecutive K-tiles apart at most -> they stay in L1/L2.
-    int k0 = kt * BK, tap = 0, ci0 = 0;
-    if (MODE != 0) {
-      tap = kt % 9;
-      ci0 = (kt / 9) * BK;
-      k0 = tap * p.Cin + ci0;
-    }
+    int k0 = kt * BK;
     if (MODE == 0) {
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (a_ok[i]) v = *reinterpret_cast<const uint4*>(p.A + a_base[i] + k0);
-        a_reg[i] = v;
+        const bf16_t* src = a_mask[i] ? a_ptr[i] + k0 : zero_page;
+        a_reg[i] = *reinterpret_cast<const u32x4*>(src);
       }
     } else {
+      const int tap = kt % 9;
+      const int ci0 = (kt / 9) * BK;
+      k0 = tap * p.Cin + ci0;
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      if (MODE == 3) {
 #pragma unroll
-      for (int i = 0; i < A_CH; ++i) {
-        int c = (tid + i * 256) & 7;
-        int iy, ix;
-        bool ok = a_ok[i];
-        if (MODE == 1) {
-          iy = a_oy[i] + dy; ix = a_ox[i] + dx;
-          ok = ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-        } else if (MODE == 2) {
-          iy = a_oy[i] * 2 + dy; ix = a_ox[i] * 2 + dx;
-          ok = ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-        } else {
-          int uy = a_oy[i] + dy, ux = a_ox[i] + dx;
-          ok = ok && (unsigned)uy < (unsigned)(2 * p.Hin) && (unsigned)ux < (unsigned)(2 * p.Win);
-          iy = uy >> 1; ix = ux >> 1;
+        for (int i = 0; i < A_CH; ++i) {
+          const int uy = a_oy[i] + dy, ux = a_ox[i] + dx;
+          const bool ok = a_mask[i] && (unsigned)uy < (unsigned)(2 * p.Hin) && (unsigned)ux < (unsigned)(2 * p.Win);
+          const bf16_t* src = ok ? a_ptr[i] + ((long)(uy >> 1) * p.Win + (ux >> 1)) * p.Cin + ci0 : zero_page;
+          a_reg[i] = *reinterpret_cast<const u32x4*>(src);
         }
-        long off = (a_base[i] + (long)iy * p.Win + ix) * p.Cin + ci0 + c * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (ok) v = *reinterpret_cast<const uint4*>(p.A + off);
-        a_reg[i] = v;
+      } else {
+        const long delta = ((long)dy * p.Win + dx) * p.Cin + ci0;     // wave-uniform
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+          const bf16_t* src = ((a_mask[i] >> tap) & 1u) ? a_ptr[i] + delta : zero_page;
+          a_reg[i] = *reinterpret_cast<const u32x4*>(src);
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < W_CH; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (w_ok[i]) v = *reinterpret_cast<const uint4*>(p.W + w_base[i] + k0);
-      w_reg[i] = v;
+      const bf16_t* src = w_ok[i] ? w_ptr[i] + k0 : zero_page;
+      w_reg[i] = *reinterpret_cast<const u32x4*>(src);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const u32x4* a_reg, const u32x4* w_reg) __attribute__((always_inline)) {
     char* sa = smem + buf * S::STAGE;
     char* sw = sa + S::A_BYTES;
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) *reinterpret_cast<uint4*>(sa + a_lds[i]) = a_reg[i];
+    for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(sa + a_lds[i]) = a_reg[i];
 #pragma unroll
-    for (int i = 0; i < W_CH; ++i) *reinterpret_cast<uint4*>(sw + w_lds[i]) = w_reg[i];
+    for (int i = 0; i < W_CH; ++i) *reinterpret_cast<u32x4*>(sw + w_lds[i]) = w_reg[i];
   };
 
   f32x4 acc[MI][NI];
@@ -177,38 +192,51 @@ __global__ __launch_bounds__(256) void igemm_kernel(GemmParams p) {
   const int fr = lane & 15;   // fragment row within a 16-row sub-tile
   const int fq = lane >> 4;   // k-group (8 bf16 each) within a 32-deep MFMA step
 
-  if (kt_begin < kt_end) {
-    load_tile(kt_begin);
-    store_tile(0);
-  }
-  __syncthreads();
+  // fragment read offsets: (row & 7) == (fr & 7) for every sub-tile of this lane, and the second
+  // 32-deep k-step only flips chunk bit 2 (byte 64), so two base offsets + compile-time
+  // immediates (sub-tile i -> +i*2048 bytes) address all 18 ds_read_b128 of a K-tile
+  const int rd_x = ((fq ^ (fr & 7)) << 4);
+  const int a_rd = (wm * 64 + fr) * 128 + rd_x;
+  const int w_rd = (wn * (BN / 2) + fr) * 128 + rd_x;
 
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    const bool more = kt + 1 < kt_end;
-    if (more) load_tile(kt + 1);
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* sa = smem + buf * S::STAGE;
     const char* sw = sa + S::A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 xf[MI], wf[NI];
+      const char* pa = sa + (a_rd ^ (ks << 6));
+      const char* pw = sw + (w_rd ^ (ks << 6));
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        int row = wm * 64 + i * 16 + fr;
-        xf[i] = *reinterpret_cast<const bf16x8*>(sa + swz(row, ks * 4 + fq));
-      }
+      for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(pa + i * 2048);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        int row = wn * (BN / 2) + j * 16 + fr;
-        wf[j] = *reinterpret_cast<const bf16x8*>(sw + swz(row, ks * 4 + fq));
-      }
+      for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + j * 2048);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tile(buf ^ 1);
+  };
+
+  if (kt_begin < kt_end) {
+    load_tile(kt_begin, a_reg0, w_reg0);
+    store_tile(0, a_reg0, w_reg0);
+  }
+  if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1, a_reg1, w_reg1);
+  __syncthreads();
+
+  for (int kt = kt_begin; kt < kt_end; kt += 2) {
+    // even step: tile kt is in LDS buffer 0, tile kt+1 is in flight in register set 1
+    if (kt + 2 < kt_end) load_tile(kt + 2, a_reg0, w_reg0);
+    compute(0);
+    if (kt + 1 < kt_end) store_tile(1, a_reg1, w_reg1);
+    __syncthreads();
+    if (kt + 1 >= kt_end) break;
+    // odd step: tile kt+1 is in LDS buffer 1, tile kt+2 is in flight in register set 0
+    if (kt + 3 < kt_end) load_tile(kt + 3, a_reg1, w_reg1);
+    compute(1);
+    if (kt + 2 < kt_end) store_tile(0, a_reg0, w_reg0);
     __syncthreads();
   }
 
@@ -356,7 +384,25 @@ size_t gemm_partial_bytes(int M, int N, int splits) {
   return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 
+static const bf16_t* zero_page_device() {
+  static bf16_t* z = nullptr;
+  if (!z) {
+    void* ptr = nullptr;
+    if (hipMalloc(&ptr, 256) != hipSuccess) return nullptr;
+    if (hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
+    z = reinterpret_cast<bf16_t*>(ptr);
+  }
+  return z;
+}
+
+int gemm_prepare() { return zero_page_device() ? HEDIT_OK : HEDIT_ERR_HIP; }
+
 int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
+  p.zeros = zero_page_device();
+  if (!p.zeros) {
+    hedit_set_error("gemm: could not allocate the zero page");
+    return HEDIT_ERR_HIP;
+  }
   ARG_CHECK(p.K % BK == 0, "gemm: K must be a multiple of 64");
   ARG_CHECK(p.N % 4 == 0, "gemm: N must be a multiple of 4");
   ARG_CHECK(p.mode >= 0 && p.mode <= 3, "gemm: mode");

@@ -18,7 +18,9 @@ struct GemmParams {
   float* partial;    // set by gemm_launch
   int splits, kt_per_split;
   int n_fastest;     // tile order, set by gemm_launch
+  const bf16_t* zeros;   // 16-byte-aligned zero page (>= 16 B), set by gemm_launch
 };
+int gemm_prepare();   // allocates the zero page (call once outside any timed / captured region)
 int gemm_pick_bn(int N);
 int gemm_pick_splits(int M, int N, int K, int force);
 size_t gemm_partial_bytes(int M, int N, int splits);

@@ -568,6 +568,7 @@ int hedit_unet_create(const hedit_unet_cfg* cfg, hedit_unet** out) {
     const int d = cfg->block_out_channels[i] / cfg->heads;
     ARG_CHECK(d == 32 || d == 40 || d == 64 || d == 80 || d == 160, "head dim must be one of 32,40,64,80,160");
   }
+  TRY(gemm_prepare());
   hedit_unet* h = new hedit_unet();
   h->cfg = *cfg;
   const int* ch = cfg->block_out_channels;
