@@ -56,7 +56,7 @@ __device__ __forceinline__ bf16x8 read_perm_frag(const bf16_t* base, int row, in
 
 // ============================================================================ self-attention
 template <int D>
-__global__ __launch_bounds__(256) void self_attn_kernel(SelfAttnParams p) {
+__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfAttnParams p) {
   using H = HeadCfg<D>;
   constexpr int VS = 68;
   __shared__ __attribute__((aligned(16))) bf16_t sK[64 * H::KS];
@@ -244,7 +244,7 @@ struct CrossSmem {
 };
 
 template <int D>
-__global__ __launch_bounds__(256) void cross_attn_kernel(CrossAttnParams p) {
+__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void cross_attn_kernel(CrossAttnParams p) {
   using H = HeadCfg<D>;
   using S = CrossSmem<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];

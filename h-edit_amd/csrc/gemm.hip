@@ -257,6 +257,43 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
     }
     return;
   }
+  if (p.geglu) {
+    // FF1 with the GEGLU fused: weight rows were interleaved at load time so that sub-tiles
+    // (j, j+1) of a wave are (value, gate) of the same 16 output columns:
+    // out[m][c] = (v + bv) * gelu(g + bg).  The block writes a 128 x BN/2 tile.
+    if constexpr ((NI & 1) == 0) {
+      constexpr int ON = BN / 2, CSG = ON + 8;
+      bf16_t* sg = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int ml = wm * 64 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < NI; j += 2) {
+          const int nv = n0 + wn * (BN / 2) + j * 16 + fq * 4;      // interleaved column of the value
+          f32x4 v = acc[i][j], g = acc[i][j + 1];
+          if (p.bias && nv + 16 < p.N + 16) {
+            v += *reinterpret_cast<const f32x4*>(p.bias + nv);
+            g += *reinterpret_cast<const f32x4*>(p.bias + nv + 16);
+          }
+          const int ol = wn * (ON / 2) + (j / 2) * 16 + fq * 4;      // output column inside the tile
+          uint2 o;
+          o.x = pack_bf16x2(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1]));
+          o.y = pack_bf16x2(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]));
+          *reinterpret_cast<uint2*>(sg + ml * CSG + ol) = o;
+        }
+      }
+      __syncthreads();
+      constexpr int GCH = ON / 8;
+      const int on0 = n0 / 2;
+      for (int idx = tid; idx < BM * GCH; idx += 256) {
+        const int ml = idx / GCH, c = idx - ml * GCH;
+        const int m = m0 + ml, n = on0 + c * 8;
+        if (m >= p.M || n >= p.N / 2) continue;
+        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = *reinterpret_cast<const uint4*>(sg + ml * CSG + c * 8);
+      }
+    }
+    return;
+  }
   // bf16 output: stage the 128 x BN tile in LDS (the K loop is over, its buffers are free) and
   // write it out as whole rows, 16 B per lane, so a wave store instruction covers >= 1 KiB of
   // contiguous NHWC memory instead of sixteen 32-byte fragments.
@@ -361,6 +398,9 @@ int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
 
 }  // namespace
 
+int gemm_pick_bn(int N);
+static int pick_bn(const GemmParams& p) { return p.geglu ? 128 : gemm_pick_bn(p.N); }
+
 int gemm_pick_bn(int N) {
   // smallest padded width wins; ties go to the wider tile
   long w160 = (long)cdiv(N, 160) * 160, w128 = (long)cdiv(N, 128) * 128;
@@ -421,7 +461,11 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
   } else {
     p.partial = nullptr;
   }
-  const int bn = gemm_pick_bn(p.N);
+  const int bn = pick_bn(p);
+  if (p.geglu) {
+    ARG_CHECK(p.N % 32 == 0 && p.mode == 0 && p.residual == nullptr && p.ldc % 8 == 0, "gemm: geglu epilogue needs N % 32 == 0, linear mode, no residual");
+    splits = 1;
+  }
   {
     // unique operand bytes: activations M x (K or Cin), weights N x K
     const double a_bytes = (double)p.M * (p.mode == 0 ? p.K : p.Cin);

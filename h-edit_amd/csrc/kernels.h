@@ -19,6 +19,7 @@ struct GemmParams {
   int splits, kt_per_split;
   int n_fastest;     // tile order, set by gemm_launch
   const bf16_t* zeros;   // 16-byte-aligned zero page (>= 16 B), set by gemm_launch
+  int geglu;             // FF1: rows interleaved (value16|gate16), output [M][N/2] = v * gelu(g)
 };
 int gemm_prepare();   // allocates the zero page (call once outside any timed / captured region)
 int gemm_pick_bn(int N);
@@ -54,6 +55,8 @@ int conv_out_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* 
 // weight packing (fp32 source tensors in torch layouts -> bf16 GEMM layouts), optional scale
 int pack_linear_launch(const float* w, bf16_t* out, long n, float scale, hipStream_t st);
 int pack_conv3x3_launch(const float* w_oihw, bf16_t* out, int O, int I, hipStream_t st);
+// GEGLU row interleave: out row t*32+u <- in row (u<16 ? t*16+u : half + t*16+u-16); K = 1 for the bias
+int pack_geglu_rows_launch(const float* w, bf16_t* out_bf16, float* out_f32, int rows, int K, hipStream_t st);
 
 // ---------------------------------------------------------------- attn.hip
 struct SelfAttnParams {

@@ -254,6 +254,22 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restri
   }
 }
 
+// rows of the FF1 projection interleaved so that (value, gate) of 16 output columns are adjacent
+__global__ __launch_bounds__(256) void pack_geglu_rows_kernel(const float* __restrict__ w, bf16_t* __restrict__ ob, float* __restrict__ of,
+                                                              int rows, int K) {
+  const long total = (long)rows * K;
+  const int half = rows / 2;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int k = (int)(idx % K);
+    const int r = (int)(idx / K);
+    const int t = r >> 5, u = r & 31;
+    const int src = u < 16 ? t * 16 + u : half + t * 16 + (u - 16);
+    const float v = w[(long)src * K + k];
+    if (ob) ob[idx] = f32_to_bf16(v);
+    if (of) of[idx] = v;
+  }
+}
+
 // ------------------------------------------------------------------ GEMV (time-embedding chain)
 __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W, const float* __restrict__ x, const float* __restrict__ b0,
                                                    const float* __restrict__ b1, float* __restrict__ out, int N, int K, int silu) {
@@ -457,6 +473,13 @@ int pack_linear_launch(const float* w, bf16_t* out, long n, float scale, hipStre
 
 int pack_conv3x3_launch(const float* w, bf16_t* out, int O, int I, hipStream_t st) {
   hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(ew_grid((long)O * 9 * I)), dim3(256), 0, st, w, out, O, I);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int pack_geglu_rows_launch(const float* w, bf16_t* out_bf16, float* out_f32, int rows, int K, hipStream_t st) {
+  ARG_CHECK(rows % 32 == 0, "geglu pack: rows % 32");
+  hipLaunchKernelGGL(pack_geglu_rows_kernel, dim3(ew_grid((long)rows * K)), dim3(256), 0, st, w, out_bf16, out_f32, rows, K);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }

@@ -23,7 +23,8 @@ namespace {
 
 struct Slot {
   std::string name;
-  int kind;        // 0 fp32 copy, 1 linear -> bf16 (scaled), 2 conv3x3 OIHW -> bf16 [O][9][I]
+  int kind;        // 0 fp32 copy, 1 linear -> bf16 (scaled), 2 conv3x3 OIHW -> bf16 [O][9][I],
+                   // 3 / 4: FF1 weight / bias with GEGLU (value16|gate16) row interleave
   void* dst;
   size_t numel;
   int O, I;
@@ -195,7 +196,9 @@ Attn make_attn(hedit_unet* h, const std::string& pre, int C) {
   a.ln3g = f32p(h, tb + ".norm3.weight", C);
   a.ln3b = f32p(h, tb + ".norm3.bias", C);
   a.ff1 = linp(h, tb + ".ff.net.0.proj.weight", 8 * C, C);
+  h->slots.back().kind = 3;
   a.ff1_b = f32p(h, tb + ".ff.net.0.proj.bias", 8 * C);
+  h->slots.back().kind = 4;
   a.ff2 = linp(h, tb + ".ff.net.2.weight", C, 4 * C);
   a.ff2_b = f32p(h, tb + ".ff.net.2.bias", C);
   a.pout = linp(h, pre + ".proj_out.weight", C, C);
@@ -400,12 +403,16 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   // ---- GEGLU feed-forward
   TRY(aalloc(f, &tn, M * C));
   { ProfScope ps(f, PK_NORM, 0.0); RUN(f, layernorm_launch(t2, tn, a.ln3g, a.ln3b, (long)M, C, 1e-5f, f.st)); }
-  TRY(aalloc(f, &hf, M * 8 * C));
-  TRY(linear(f, tn, (int)M, C, a.ff1, 8 * C, a.ff1_b, nullptr, hf, 8 * C));
-  f.ar.free(tn);
+  (void)hf;
   TRY(aalloc(f, &gf, M * 4 * C));
-  { ProfScope ps(f, PK_OTHER, 0.0); RUN(f, geglu_launch(hf, gf, (long)M, 4 * C, f.st)); }
-  f.ar.free(hf);
+  {
+    GemmParams gp{};
+    gp.A = tn; gp.W = a.ff1; gp.M = (int)M; gp.N = 8 * C; gp.K = C; gp.lda = C; gp.mode = 0;
+    gp.bias = a.ff1_b; gp.residual = nullptr; gp.ldr = 0; gp.C = gf; gp.ldc = 4 * C; gp.geglu = 1;
+    ProfScope ps(f, PK_LINEAR, 2.0 * gp.M * gp.N * gp.K);
+    RUN(f, gemm_launch(gp, 1, nullptr, f.st));
+  }
+  f.ar.free(tn);
   TRY(aalloc(f, &t3, M * C));
   TRY(linear(f, gf, (int)M, 4 * C, a.ff2, C, a.ff2_b, t2, t3, C));
   f.ar.free(gf);
@@ -699,6 +706,10 @@ int hedit_unet_load(hedit_unet* h, const char* name, const float* w, size_t nume
     HIP_TRY(hipMemcpyAsync(s.dst, w, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
   } else if (s.kind == 1) {
     TRY(pack_linear_launch(w, reinterpret_cast<bf16_t*>(s.dst), (long)numel, s.scale, st));
+  } else if (s.kind == 3) {
+    TRY(pack_geglu_rows_launch(w, reinterpret_cast<bf16_t*>(s.dst), nullptr, s.O, s.I, st));
+  } else if (s.kind == 4) {
+    TRY(pack_geglu_rows_launch(w, nullptr, reinterpret_cast<float*>(s.dst), (int)numel, 1, st));
   } else {
     TRY(pack_conv3x3_launch(w, reinterpret_cast<bf16_t*>(s.dst), s.O, s.I, st));
   }
