@@ -9,7 +9,8 @@ bridge sampling loop of BASELINE.json configs[1] (text-guided h_Edit_p2p_implici
 random-init UNet, 64x64 latents, 50 DDIM steps, K_opt = 1 implicit "Langevin" step, P2P
 Replace/Refine + Reweight + LocalBlend) for `--images` independent images per GPU run in
 lock-step: 50 x (1 base pass of 4n rows + 1 source pass of n rows + 1 P2P pass of 4n rows) =
-450 UNet sample-forwards per image, exactly the reference's call pattern.  Inputs (weights,
+450 UNet sample-forwards per image, the reference's evaluations one for one (by default the n source
+rows ride along in the P2P pass as un-edited rows; --no-fuse-src issues them as their own call).  Inputs (weights,
 inverted latents x_T, noise maps z_t, text embeddings) are resident in HBM before the timed
 region; DDPM inversion is outside it (it is the step BEFORE the path).
 
@@ -53,6 +54,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-every", type=int, default=25, help="bracket every n-th UNet call with HIP events")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny network instead of SD-1.5 shape")
+    ap.add_argument("--no-fuse-src", action="store_true",
+                    help="issue the source-prompt pass as its own UNet call like the reference instead of "
+                         "as n extra rows of the P2P pass (same arithmetic either way)")
+    ap.add_argument("--force-dist", action="store_true", help="init the RCCL process group even for one rank")
     return ap.parse_args()
 
 
@@ -67,10 +72,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from hedit.engine import HEditEngine
@@ -88,18 +94,16 @@ def main():
     # ---- weights: rank 0 creates them, RCCL broadcast to the other GPUs (no steady-state traffic)
     t_w0 = time.time()
     sd_cpu = None
-    if world == 1:
+    if dist is None:
         sd_cpu = random_state_dict(unet.param_shapes, seed=0)
         unet.load_state_dict(sd_cpu)
     else:
-        names = list(unet.param_shapes.keys())
+        from hedit import dist as HD
         if rank == 0:
             sd_cpu = random_state_dict(unet.param_shapes, seed=0)
-        for name in names:
-            shape = unet.param_shapes[name]
-            buf = sd_cpu[name].to(dev) if rank == 0 else torch.empty(shape, dtype=torch.float32, device=dev)
-            dist.broadcast(buf, src=0)
-            unet.load_state_dict({name: buf}, strict=False)
+        sd_dev = HD.broadcast_state_dict(unet.param_shapes, sd_cpu, src=0, device=dev)   # RCCL over xGMI
+        unet.load_state_dict(sd_dev)
+        del sd_dev
         assert unet._lib.hedit_unet_missing(unet._h) == 0
     t_weights = time.time() - t_w0
 
@@ -164,7 +168,7 @@ def main():
         cb = make_batch_controller()
         register_attention_control(model, cb)
         return eng.run(xT, zs, prompt_pairs, cfg_scales, cb, eta=1.0, p2p=True, implicit=True, K=K, w_rec=0.1,
-                       after_skip_steps=T, ddim_inv=False, ctx=(null, src, tar))
+                       after_skip_steps=T, ddim_inv=False, ctx=(null, src, tar), fuse_src_pass=not args.no_fuse_src)
 
     for _ in range(args.warmup):
         one_step()
@@ -184,9 +188,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        from hedit import dist as HD
+        elapsed = HD.max_over_ranks(elapsed, device=dev)
     calls["prof"] = False
     unet_calls = calls["n"]
 

@@ -1,0 +1,55 @@
+"""Multi-GPU plumbing: one process per GPU, independent images sharded across ranks.
+
+The reference has no distributed code (one process, one GPU, one image at a time,
+text-guided/main_p2p.py:87,110).  Images are independent, so the build shards the image list and
+needs exactly one collective: a broadcast of the weights from rank 0 at start-up (RCCL over xGMI
+on MI355X: backend "nccl"; the same code runs on "gloo" for the CPU tests).  No steady-state
+traffic; timings are max-reduced over ranks.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def shard(n_items, rank, world):
+    """Contiguous, balanced partition: the indices of `range(n_items)` owned by `rank`."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return list(range(start, start + base + (1 if rank < extra else 0)))
+
+
+def broadcast_state_dict(shapes, sd, src=0, device="cpu", group=None):
+    """Every rank returns the full {name: tensor} dict that rank `src` holds in `sd` (other ranks
+    pass None).  One broadcast per tensor, fp32, in the deterministic order of `shapes`."""
+    rank = dist.get_rank(group)
+    out = {}
+    for name, shape in shapes.items():
+        if rank == src:
+            t = sd[name].to(device=device, dtype=torch.float32).contiguous()
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"{name}: shape {tuple(t.shape)} != {tuple(shape)}")
+        else:
+            t = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+        dist.broadcast(t, src=src, group=group)
+        out[name] = t
+    return out
+
+
+def max_over_ranks(value, device="cpu", group=None):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def gather_counts(count, device="cpu", group=None):
+    """Sum of per-rank processed-unit counts (whole-job throughput numerator)."""
+    t = torch.tensor([float(count)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item())

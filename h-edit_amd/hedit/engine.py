@@ -104,9 +104,12 @@ class HEditEngine:
     # ------------------------------------------------------------------ the loop
     @torch.no_grad()
     def run(self, xT, zs, prompt_pairs, cfg_scales, controller=None, eta=1.0, p2p=True, implicit=True,
-            K=1, w_rec=0.1, after_skip_steps=None, ddim_inv=False, ctx=None):
+            K=1, w_rec=0.1, after_skip_steps=None, ddim_inv=False, ctx=None, fuse_src_pass=False):
         """xT: (n,C,H,W); zs: (T',n,C,H,W) or None; prompt_pairs: n x [src, tar].
         ctx: optional precomputed (null, src, tar) embeddings ((1|n,77,D), (n,77,D), (n,77,D)).
+        fuse_src_pass: evaluate eps(x^k, t-1, src) (the reference's separate n-row call,
+        p2p_h_edit.py:644) as n extra un-edited rows of the P2P pass (5n rows): same arithmetic and
+        FLOPs, one UNet launch sequence fewer per inner step.
         Returns (edit (n,C,H,W), recon (n,C,H,W))."""
         sch = self.model.scheduler
         S = Schedule(sch)
@@ -129,6 +132,7 @@ class HEditEngine:
         ctx_base2 = torch.cat([nulln, src]).contiguous()
         ctx_edit = torch.cat([nulln, nulln, src, tar]).contiguous()
         ctx_src = src.contiguous()
+        ctx_edit5 = torch.cat([nulln, nulln, src, tar, src]).contiguous() if fuse_src_pass else None
 
         ts = [int(v) for v in sch.timesteps]
         op = ts[-after_skip_steps:]
@@ -138,8 +142,9 @@ class HEditEngine:
         off = None
 
         def p2p_pass(x_in, t, save):
-            plan = controller._plan(self.unet, 4 * n, x_in.shape[2], x_in.shape[3], save)
-            e = self.unet.forward_raw(x_in, t, ctx_edit, plan)
+            rows = x_in.shape[0]
+            plan = controller._plan(self.unet, rows, x_in.shape[2], x_in.shape[3], save)
+            e = self.unet.forward_raw(x_in, t, ctx_edit5 if rows == 5 * n else ctx_edit, plan)
             controller._after_pass(save)
             return e
 
@@ -183,9 +188,13 @@ class HEditEngine:
                     new = torch.empty_like(x_k)
                     if p2p:
                         save = not (k < K - 1 and K > 1)
-                        e_src = self.unet.forward_raw(x_k, tt, ctx_src, off)
-                        e = p2p_pass(torch.cat([x_orig, x_k, x_orig, x_k]), tt, save)
-                        self.step_update(e[n:2 * n], e_src, e[n:2 * n], e[3 * n:], x_k, x_base, new, n, k > 0, coef)
+                        if fuse_src_pass:
+                            e = p2p_pass(torch.cat([x_orig, x_k, x_orig, x_k, x_k]), tt, save)
+                            e_src = e[4 * n:]
+                        else:
+                            e_src = self.unet.forward_raw(x_k, tt, ctx_src, off)
+                            e = p2p_pass(torch.cat([x_orig, x_k, x_orig, x_k]), tt, save)
+                        self.step_update(e[n:2 * n], e_src, e[n:2 * n], e[3 * n:4 * n], x_k, x_base, new, n, k > 0, coef)
                     else:
                         e = self.unet.forward_raw(torch.cat([x_k] * 4), tt, ctx_edit, off)
                         self.step_update(e[0:n], e[2 * n:3 * n], e[n:2 * n], e[3 * n:], x_k, x_base, new, n, k > 0, coef)

@@ -132,16 +132,20 @@ class _PlanState:
 
     def __init__(self, members, unet, B, H, W):
         n = len(members)
-        if B != 4 * n:
+        if B < 4 * n:
             raise ValueError(f"a P2P pass over {n} image(s) expects a batch of {4 * n} rows laid out "
-                             f"[x_orig|null]*n, [x_edit|null]*n, [x_orig|src]*n, [x_edit|tar]*n; got {B}")
+                             f"[x_orig|null]*n, [x_edit|null]*n, [x_orig|src]*n, [x_edit|tar]*n "
+                             f"(+ optional extra un-edited rows); got {B}")
         dev = unet.device
         self.key = (id(unet), B, H, W)
         self.n = n
         ar = torch.arange(B, dtype=torch.int32)
         self.pair_src = ar[2 * n:3 * n].contiguous().to(dev)
         self.pair_tar = ar[3 * n:4 * n].contiguous().to(dev)
-        self.singles = ar[:2 * n].contiguous().to(dev)
+        # rows outside the conditional (src,tar) quarter pairs are never edited: the unconditional
+        # half and any extra rows appended after the 4n block (e.g. the source-prompt pass)
+        self.singles = torch.cat([ar[:2 * n], ar[4 * n:]]).contiguous().to(dev)
+        self.n_single = int(self.singles.numel())
         qk = ar.clone()
         qk[3 * n:4 * n] = ar[2 * n:3 * n]
         self.qk_src = qk.to(dev)
@@ -172,7 +176,7 @@ class _PlanState:
         p.pair_src = self.pair_src.data_ptr()
         p.pair_tar = self.pair_tar.data_ptr()
         p.singles = self.singles.data_ptr()
-        p.n_single = 2 * self.n
+        p.n_single = self.n_single
         in_window = edit and self_window[0] <= cur_step < self_window[1]
         p.qk_src = self.qk_src.data_ptr() if in_window else None
         s = min(cur_step, self.mixT.shape[0] - 1)
