@@ -16,6 +16,8 @@
 //     reads and ds_write_b128 staging writes are both bank-conflict free.
 //   * split-K (grid.y) for the low-resolution, weight-heavy layers: fp32 partial slabs + a
 //     reduce/epilogue kernel.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -36,7 +38,7 @@ struct Smem {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <int BN, int MODE>
+template <int BN, int MODE, bool GLDS>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NI = BN / 32;      // 16-wide n sub-tiles per wave
@@ -84,11 +86,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
   int a_lds[A_CH];
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
+    // register staging: thread -> (row, chunk) = (id>>3, id&7), written to the swizzled slot.
+    // LDS-DMA staging: one wave instruction fills 8 rows x 128 B linearly (lane L -> row L>>3,
+    // slot L&7), so the swizzle is applied on the SOURCE side: slot p of row r must receive
+    // chunk p ^ (r & 7)  (same involution the fragment reads use).
     const int id = tid + i * 256;
-    const int row = id >> 3, c = id & 7;
+    const int row = GLDS ? (wave * A_CH + i) * 8 + (lane >> 3) : id >> 3;
+    const int c = GLDS ? ((lane & 7) ^ (lane >> 3)) : id & 7;
     const int m = m0 + row;
     const bool ok = m < p.M;
-    a_lds[i] = swz(row, c);
+    a_lds[i] = GLDS ? (wave * A_CH + i) * 1024 : swz(row, c);
     a_oy[i] = a_ox[i] = 0;
     if (MODE == 0) {
       a_ptr[i] = ok ? p.A + (long)m * p.lda + c * 8 : zero_page;
@@ -124,16 +131,61 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
 #pragma unroll
   for (int i = 0; i < W_CH; ++i) {
     const int id = tid + i * 256;
-    const int row = id >> 3, c = id & 7;
+    const int row = GLDS ? (wave * W_CH + i) * 8 + (lane >> 3) : id >> 3;
+    const int c = GLDS ? ((lane & 7) ^ (lane >> 3)) : id & 7;
     const int n = n0 + row;
     w_ok[i] = n < p.N;
-    w_lds[i] = swz(row, c);
+    w_lds[i] = GLDS ? (wave * W_CH + i) * 1024 : swz(row, c);
     w_ptr[i] = p.W + (long)n * p.K + c * 8;
   }
 
   // two register stages: tile k+2 is requested while tile k is being multiplied, so every global
   // load has two K-iterations to land (2 x 36 KB per block in flight)
   u32x4 a_reg0[A_CH], w_reg0[W_CH], a_reg1[A_CH], w_reg1[W_CH];
+
+  // direct-to-LDS DMA of one K-tile into stage `buf` (no VGPR round trip, no ds_write)
+  auto issue_glds = [&](int kt, int buf) __attribute__((always_inline)) {
+    char* sa = smem + buf * S::STAGE;
+    char* sw = sa + S::A_BYTES;
+    int k0 = kt * BK;
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const bf16_t* src = a_mask[i] ? a_ptr[i] + k0 : zero_page;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sa + a_lds[i]), 16, 0, 0);
+      }
+    } else {
+      const int tap = kt % 9;
+      const int ci0 = (kt / 9) * BK;
+      k0 = tap * p.Cin + ci0;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      if (MODE == 3) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+          const int uy = a_oy[i] + dy, ux = a_ox[i] + dx;
+          const bool ok = a_mask[i] && (unsigned)uy < (unsigned)(2 * p.Hin) && (unsigned)ux < (unsigned)(2 * p.Win);
+          const bf16_t* src = ok ? a_ptr[i] + ((long)(uy >> 1) * p.Win + (ux >> 1)) * p.Cin + ci0 : zero_page;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(sa + a_lds[i]), 16, 0, 0);
+        }
+      } else {
+        const long delta = ((long)dy * p.Win + dx) * p.Cin + ci0;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+          const bf16_t* src = ((a_mask[i] >> tap) & 1u) ? a_ptr[i] + delta : zero_page;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(sa + a_lds[i]), 16, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i) {
+      const bf16_t* src = w_ok[i] ? w_ptr[i] + k0 : zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sw + w_lds[i]), 16, 0, 0);
+    }
+  };
 
   auto load_tile = [&](int kt, u32x4* a_reg, u32x4* w_reg) __attribute__((always_inline)) {
     // K-tile order.  linear: k0 = kt*64.  conv: the 9 taps of one 64-channel slab are visited
@@ -219,6 +271,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
     }
   };
 
+  if constexpr (GLDS) {
+    // two LDS stages: the DMA of tile k+1 runs under the MFMAs of tile k; a wave waits for its
+    // own DMA (vmcnt) and the barrier then makes every wave's part of the stage visible and
+    // guarantees nobody still reads the stage that is about to be overwritten.
+    if (kt_begin < kt_end) issue_glds(kt_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int cur = (kt - kt_begin) & 1;
+      if (kt + 1 < kt_end) issue_glds(kt + 1, cur ^ 1);
+      compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
   if (kt_begin < kt_end) {
     load_tile(kt_begin, a_reg0, w_reg0);
     store_tile(0, a_reg0, w_reg0);
@@ -239,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
     if (kt + 2 < kt_end) store_tile(0, a_reg0, w_reg0);
     __syncthreads();
   }
+  }   // !GLDS
 
   // ---- epilogue.  A lane holds 4 consecutive n of column m = mb + fr.
   if (p.partial) {
@@ -381,19 +449,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   *reinterpret_cast<uint2*>(p.C + (long)m * p.ldc + n) = o;
 }
 
-template <int BN, int MODE>
-int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
+template <int BN, int MODE, bool GLDS>
+int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
   using S = Smem<BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BN, MODE>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BN, MODE, GLDS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, S::TOTAL));
     attr_set = true;
   }
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), splits);
-  hipLaunchKernelGGL((igemm_kernel<BN, MODE>), grid, dim3(256), S::TOTAL, st, p);
+  hipLaunchKernelGGL((igemm_kernel<BN, MODE, GLDS>), grid, dim3(256), S::TOTAL, st, p);
   LAUNCH_CHECK();
   return HEDIT_OK;
+}
+
+// operand staging: direct-to-LDS DMA by default; HEDIT_GEMM_STAGING=regs selects the
+// register-staged pipeline (kept for A/B measurements)
+static bool use_glds() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("HEDIT_GEMM_STAGING");
+    v = (e && std::string(e) == "regs") ? 0 : 1;
+  }
+  return v == 1;
+}
+
+template <int BN, int MODE>
+int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
+  return use_glds() ? launch_igemm_impl<BN, MODE, true>(p, splits, st) : launch_igemm_impl<BN, MODE, false>(p, splits, st);
 }
 
 }  // namespace
