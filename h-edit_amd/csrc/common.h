@@ -69,6 +69,22 @@ __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ inline float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ inline float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-GELU with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output
+// resolution of 2^-9): one v_rcp + one v_exp + a 5-term Horner chain instead of libm's erff
+__device__ inline float gelu_erf_fast(float x) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  float poly = 1.061405429f;
+  poly = poly * t - 1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t - 0.284496736f;
+  poly = poly * t + 0.254829592f;
+  poly *= t;
+  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+  const float erf_abs = 1.0f - poly * e;
+  const float erfv = copysignf(erf_abs, x);
+  return 0.5f * x * (1.0f + erfv);
+}
 
 __device__ inline float wave_sum(float v) {
 #pragma unroll

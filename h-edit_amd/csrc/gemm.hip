@@ -345,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
           }
           const int ol = wn * (ON / 2) + (j / 2) * 16 + fq * 4;      // output column inside the tile
           uint2 o;
-          o.x = pack_bf16x2(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1]));
-          o.y = pack_bf16x2(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]));
+          o.x = pack_bf16x2(v[0] * gelu_erf_fast(g[0]), v[1] * gelu_erf_fast(g[1]));
+          o.y = pack_bf16x2(v[2] * gelu_erf_fast(g[2]), v[3] * gelu_erf_fast(g[3]));
           *reinterpret_cast<uint2*>(sg + ml * CSG + ol) = o;
         }
       }
