@@ -249,3 +249,49 @@ class HEditEngine:
             zs[idx] = z
             xts[idx] = mu + sig * z
         return zs, xts
+
+    # ------------------------------------------------------------------ DDIM inversion (h-Edit-D)
+    @torch.no_grad()
+    def ddim_inversion(self, w0, prompts, cfg_scale):
+        """Deterministic DDIM inversion for n images + the per-step corrections u_t replayed by
+        h-Edit-D (text-guided/inversion/ddim_inversion.py:54-131; two passes of T UNet calls with
+        2n rows each).  w0 (n,C,H,W).  Returns (latent_T (n,..), zs (T,n,..), latents (T+1,n,..))."""
+        sch = self.model.scheduler
+        S = Schedule(sch)
+        T = sch.num_inference_steps
+        step = S.n_train // T
+        dev = self.dev
+        lat = w0.to(device=dev, dtype=torch.float32).clone()
+        n = lat.shape[0]
+        ts = [int(v) for v in sch.timesteps]
+        null = self.encode([""]).expand(n, -1, -1)
+        ctx = torch.cat([null, self.encode(list(prompts))]).contiguous()
+        ab = S.ab
+
+        def eps(x, t):
+            e = self.unet.forward_raw(torch.cat([x, x]), t, ctx)
+            return e[:n] + cfg_scale * (e[n:] - e[:n])
+
+        lats = torch.zeros(T + 1, *lat.shape, device=dev)
+        lats[0] = lat
+        for i in range(T):
+            t = ts[len(ts) - i - 1]
+            e = eps(lat, t)
+            cur = min(t - step, 999)
+            a_cur = ab[cur] if cur >= 0 else S.final
+            a_next = ab[t]
+            x0 = (lat - _f((1 - a_cur) ** 0.5) * e) / _f(a_cur ** 0.5)
+            lat = _f(a_next ** 0.5) * x0 + _f((1 - a_next) ** 0.5) * e
+            lats[i + 1] = lat
+        zs = torch.zeros(T, *lat.shape, device=dev)
+        for i, t in enumerate(ts):
+            idx = T - i - 1
+            xt = lats[idx + 1]
+            e = eps(xt, t)
+            x0 = (xt - _f((1 - ab[t]) ** 0.5) * e) / _f(ab[t] ** 0.5)
+            a_p = S.ab_prev(t)
+            mu = _f(a_p ** 0.5) * x0 + _f((1 - a_p) ** 0.5) * e
+            z = lats[idx] - mu
+            zs[idx] = z
+            lats[idx] = mu + z
+        return lat, zs, lats

@@ -3,6 +3,7 @@
 Restates, against the same duck-typed ``model`` object the reference uses:
   encode_text                   text-guided/inversion/inversion_utils.py:13-35
   sample_xts / ddpm_inversion   text-guided/inversion/ddpm_inversion.py:5-52, 54-167
+  ddim_inversion                text-guided/inversion/ddim_inversion.py:7-131
   h_edit_r_explicit             text-guided/inversion/p2p_h_edit.py:21-156
   h_edit_r_implicit             text-guided/inversion/p2p_h_edit.py:162-362
   h_edit_p2p_explicit           text-guided/inversion/p2p_h_edit.py:380-523
@@ -71,6 +72,49 @@ def ddpm_inversion(model, x0, eta=1.0, prompt="", cfg_src=1.0, T=50):
         zs[i] = z
         xts[i] = mu + (eta * var ** 0.5) * z                      # re-anchor (:160-162)
     return zs, xts, noise
+
+
+def ddim_inversion(model, w0, prompt, cfg_scale):
+    """Deterministic DDIM inversion + the per-step corrections u_t that make the eta=1 chain of
+    h-Edit-D reproduce it (text-guided/inversion/ddim_inversion.py: next_step :7-28,
+    get_noise_pred :30-52, ddim_inversion :54-131).  Returns (latent_T, zs[T], latents[T+1])."""
+    sch = model.scheduler
+    ab = sch.alphas_cumprod
+    T = sch.num_inference_steps
+    step = sch.config.num_train_timesteps // T
+    ctx = torch.cat([encode_text(model, ""), encode_text(model, prompt)])
+
+    def eps(x, t):
+        with torch.no_grad():
+            e = model.unet(torch.cat([x] * 2), t, encoder_hidden_states=ctx)["sample"]
+        e_u, e_c = e.chunk(2)
+        return e_u + cfg_scale * (e_c - e_u)
+
+    lat = w0.clone().detach()
+    lats = [lat]
+    for i in range(T):
+        t = sch.timesteps[len(sch.timesteps) - i - 1]
+        e = eps(lat, t)
+        cur = min(t - step, 999)
+        a_cur = ab[cur] if cur >= 0 else sch.final_alpha_cumprod
+        a_next = ab[t]
+        x0 = (lat - (1 - a_cur) ** 0.5 * e) / a_cur ** 0.5
+        lat = a_next ** 0.5 * x0 + (1 - a_next) ** 0.5 * e
+        lats.append(lat)
+    c, sz = model.unet.in_channels, model.unet.sample_size
+    zs = torch.zeros(T, c, sz, sz)
+    pos = {int(v): k for k, v in enumerate(sch.timesteps)}
+    for t in sch.timesteps:
+        idx = T - pos[int(t)] - 1
+        xt = lats[idx + 1]
+        e = eps(xt, t)
+        x0 = (xt - (1 - ab[t]) ** 0.5 * e) / (ab[t] ** 0.5)
+        a_p = S._abar_prev(sch, t)
+        mu = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * e
+        z = lats[idx] - mu
+        zs[idx] = z
+        lats[idx] = mu + z
+    return lat, zs, lats
 
 
 # --------------------------------------------------------------------------- loops

@@ -48,6 +48,7 @@ def import_reference():
     sys.path.insert(0, REF)
     import inversion.inversion_utils as iu
     import inversion.ddpm_inversion as di
+    import inversion.ddim_inversion as dd
     import inversion.p2p_h_edit as he
     import p2p.ptp_utils as pu
     import p2p.ptp_classes as pc
@@ -56,7 +57,8 @@ def import_reference():
     # tqdm progress bars off
     he.tqdm = lambda x, *a, **k: x
     di.tqdm = lambda x, *a, **k: x
-    return types.SimpleNamespace(iu=iu, di=di, he=he, pu=pu, pc=pc, sa=sa, pcu=pcu)
+    dd.tqdm = lambda x, *a, **k: x
+    return types.SimpleNamespace(iu=iu, di=di, dd=dd, he=he, pu=pu, pc=pc, sa=sa, pcu=pcu)
 
 
 def npy(t):
@@ -109,6 +111,7 @@ def gen_scheduler(ref, out):
 
 # --------------------------------------------------------------------------- G4 / G5 tables+controller
 def build_ref_controller(ref, model, pair, num_steps, xa=0.4, sa=0.35, eq_val=2.0):
+    # (sa = 0.6 is the reference's self-replace fraction for h-Edit-D, main_p2p.py:70)
     src, tar, blend, is_replace = pair
     prompts = [src, tar]
     blend_word = ((blend[0],), (blend[1],)) if blend else None
@@ -333,6 +336,46 @@ def gen_loops(ref, out):
         json.dump(meta, f, indent=0)
 
 
+def gen_ddim(ref, out):
+    """h-Edit-D: DDIM inversion (eta = 0 scheduler of main_p2p.py:139-141: steps_offset 0) and the
+    P2P loops run on its outputs with is_ddim_inversion=True, eta=1."""
+    from helpers.tiny import make_tiny_model, PROMPT_PAIRS, ddim_tables
+    T = 10
+    d = {}
+    meta = {"T": T, "cases": []}
+
+    def fresh():
+        m = make_tiny_model(T)
+        m.scheduler = ddim_tables(T, steps_offset=0)
+        return m
+
+    torch.manual_seed(99)
+    w0 = torch.randn(1, 4, 16, 16) * 0.8
+    d["w0"] = npy(w0)
+    for pi, cfg_src in ((0, 1.0), (2, 3.0)):
+        model = fresh()
+        lat, zs, lats = ref.dd.ddim_inversion(model, w0, PROMPT_PAIRS[pi][0], cfg_src)
+        d[f"inv{pi}_zs"] = npy(zs)
+        d[f"inv{pi}_lats"] = np.stack([npy(l)[0] for l in lats])
+        for fn_name, K, skip in (("h_Edit_p2p_implicit", 1, 0), ("h_Edit_p2p_implicit", 2, 3), ("h_Edit_p2p_explicit", 1, 2)):
+            model = fresh()
+            after = T - skip
+            ctrl = build_ref_controller(ref, model, PROMPT_PAIRS[pi], after, sa=0.6)
+            ref.pu.register_attention_control(model, ctrl)
+            kw = dict(eta=1.0, prompts=[PROMPT_PAIRS[pi][0], PROMPT_PAIRS[pi][1]], cfg_scales=[cfg_src, 5.0, 7.5],
+                      prog_bar=False, zs=zs[:after], controller=ctrl, after_skip_steps=after, is_ddim_inversion=True)
+            if "implicit" in fn_name:
+                kw.update(weight_reconstruction=0.1, optimization_steps=K)
+            edit, recon = getattr(ref.he, fn_name)(model, xT=lats[after], **kw)
+            name = f"p{pi}_{fn_name}_k{K}_s{skip}"
+            d[name + "_edit"] = npy(edit)
+            d[name + "_recon"] = npy(recon)
+            meta["cases"].append({"name": name, "fn": fn_name, "pair": pi, "cfg_src": cfg_src, "K": K, "skip": skip})
+    np.savez_compressed(os.path.join(out, "g7_ddim.npz"), **d)
+    with open(os.path.join(out, "g7_ddim.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+
+
 def main():
     torch.set_num_threads(4)
     torch.set_grad_enabled(True)
@@ -343,6 +386,7 @@ def main():
     gen_local_blend(ref, out)
     gen_processor(ref, out)
     gen_loops(ref, out)
+    gen_ddim(ref, out)
     for f in sorted(os.listdir(out)):
         if f.endswith((".npz", ".json")):
             print(f"{f:32s} {os.path.getsize(os.path.join(out, f)) / 1024:9.1f} KiB")

@@ -185,3 +185,41 @@ def test_fused_source_pass_is_equivalent(setup):
     G.sync()
     assert G.rel_err(outs[1][0], outs[0][0]) < 3e-2
     assert G.rel_err(outs[1][1], outs[0][1]) < 1e-2
+
+
+def test_h_edit_d_ddim_inversion_end_to_end():
+    """h-Edit-D (main_p2p.py --mode h_edit_D_p2p): eta = 0 scheduler (steps_offset 0), DDIM inversion on
+    the HIP UNet, then the P2P implicit loop with is_ddim_inversion=True -- against the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import loops as OL
+    from hedit.inversion.ddim_inversion import ddim_inversion
+    from hedit.inversion import p2p_h_edit as HE
+    from hedit.scheduler import DDIMScheduler
+    TT = 6
+    hip, om, _ = make_pair(TINY_CONFIG, TT, out_scale=0.3)
+    for m in (hip, om):
+        m.scheduler = DDIMScheduler(steps_offset=0)
+        m.scheduler.set_timesteps(TT)
+    pi = 0
+    src, tar = PROMPT_PAIRS[pi][0], PROMPT_PAIRS[pi][1]
+    torch.manual_seed(5)
+    w0 = torch.randn(1, 4, 32, 32) * 0.8
+    lat_o, zs_o, lats_o = OL.ddim_inversion(om, w0, src, 1.0)
+    lat_h, zs_h, lats_h = ddim_inversion(hip, G.f32(w0), src, 1.0)
+    G.sync()
+    assert len(lats_h) == TT + 1 and lats_h[0].shape == (1, 4, 32, 32)
+    assert G.rel_err(torch.stack(lats_h), torch.stack(lats_o)) < 2e-2
+    after = 4
+    hc, oc = controllers(hip, om, pi, after, True)
+    kw = dict(eta=1.0, prompts=[src, tar], cfg_scales=[1.0, 5.0, 7.5], weight_reconstruction=0.1, optimization_steps=1,
+              after_skip_steps=after, is_ddim_inversion=True)
+    with torch.no_grad():
+        e_o, r_o = OL.h_edit_p2p_implicit(om, xT=lats_o[after], zs=zs_o[:after], controller=oc, **kw)
+    e_h, r_h = HE.h_Edit_p2p_implicit(hip, xT=lats_h[after], zs=zs_h[:after], controller=hc, **kw)
+    G.sync()
+    tol_edit, _ = tol(after)
+    assert G.rel_err(e_h, e_o) < tol_edit
+    # each side replays its OWN inversion: the x^orig branch returns the input latent
+    assert G.rel_err(r_h, w0) < 1e-2
+    assert G.rel_err(r_o, w0) < 1e-3

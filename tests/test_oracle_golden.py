@@ -239,3 +239,40 @@ def test_loops(loops_golden, ci):
     # the inverted input (up to the toy network's error amplification)
     if case["p2p"] and not case["ddim"]:
         close(recon[0], g["w0"][0], 2e-2)
+
+
+# --------------------------------------------------------------------------- G7 DDIM inversion / h-Edit-D
+def test_ddim_inversion_and_h_edit_d(golden_dir):
+    g = _npz(golden_dir, "g7_ddim.npz")
+    meta = _json(golden_dir, "g7_ddim.json")
+    T = meta["T"]
+    w0 = torch.from_numpy(g["w0"])
+    inv = {}
+    for case in meta["cases"]:
+        pi = case["pair"]
+        if pi not in inv:
+            model = make_tiny_model(T)
+            model.scheduler = ddim_tables(T, steps_offset=0)
+            lat, zs, lats = OL.ddim_inversion(model, w0, PROMPT_PAIRS[pi][0], case["cfg_src"])
+            close(zs, g[f"inv{pi}_zs"], 2e-5)
+            close(torch.stack([l[0] for l in lats]), g[f"inv{pi}_lats"], 2e-5)
+            inv[pi] = (zs, lats)
+        zs, lats = inv[pi]
+        model = make_tiny_model(T)
+        model.scheduler = ddim_tables(T, steps_offset=0)
+        after = T - case["skip"]
+        src, tar, blend, is_replace = PROMPT_PAIRS[pi]
+        bw = ((blend[0],), (blend[1],)) if blend else None
+        eq = {"words": (blend[1],), "values": (2.0,)} if blend else None
+        c = OP.make_controller([src, tar], is_replace, 0.4, 0.6, blend_word=bw, eq_params=eq, num_steps=after,
+                               tok=model.tokenizer)
+        OP.register(model, c)
+        kw = dict(eta=1.0, prompts=[src, tar], cfg_scales=[case["cfg_src"], 5.0, 7.5], zs=zs[:after], controller=c,
+                  after_skip_steps=after, is_ddim_inversion=True)
+        if "implicit" in case["fn"]:
+            kw.update(weight_reconstruction=0.1, optimization_steps=case["K"])
+        edit, recon = LOOP_FNS[case["fn"]](model, xT=lats[after], **kw)
+        close(edit, g[case["name"] + "_edit"], 2e-4)
+        close(recon, g[case["name"] + "_recon"], 2e-4)
+        # the x^orig branch replays the deterministic inversion exactly
+        close(recon, w0, 2e-3)
