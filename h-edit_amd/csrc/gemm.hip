@@ -107,10 +107,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
       const int oy = r / p.Wout;
       const int ox = r - oy * p.Wout;
       if (MODE == 3) {
-        a_ptr[i] = p.A + (long)b * p.Hin * p.Win * p.Cin + c * 8;
-        a_oy[i] = oy;
-        a_ox[i] = ox;
-        a_mask[i] = ok ? 1u : 0u;
+        // 3x3 on the 2x nearest-upsampled image: tap (dy,dx) of output pixel (oy,ox) reads input
+        // pixel ((oy+dy)>>1, (ox+dx)>>1) = (oy>>1, ox>>1) + (fy, fx) with fy = -1/0 for even oy
+        // (dy = -1 / else) and 0/+1 for odd oy (else / dy = +1): the gather is again "centre
+        // pointer + small offset", only the offset depends on the pixel's parity bits.
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int uy = oy + t / 3 - 1, ux = ox + t % 3 - 1;
+          const unsigned in = (unsigned)ok & (unsigned)((unsigned)uy < (unsigned)(2 * p.Hin)) & (unsigned)((unsigned)ux < (unsigned)(2 * p.Win));
+          mk |= in << t;
+        }
+        a_mask[i] = mk;
+        a_ptr[i] = p.A + (((long)b * p.Hin + (oy >> 1)) * p.Win + (ox >> 1)) * p.Cin + c * 8;
+        a_oy[i] = oy & 1;
+        a_ox[i] = ox & 1;
       } else {
         const int cy = MODE == 2 ? oy * 2 : oy, cx = MODE == 2 ? ox * 2 : ox;
         unsigned mk = 0;
@@ -163,9 +174,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
       if (MODE == 3) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
-          const int uy = a_oy[i] + dy, ux = a_ox[i] + dx;
-          const bool ok = a_mask[i] && (unsigned)uy < (unsigned)(2 * p.Hin) && (unsigned)ux < (unsigned)(2 * p.Win);
-          const bf16_t* src = ok ? a_ptr[i] + ((long)(uy >> 1) * p.Win + (ux >> 1)) * p.Cin + ci0 : zero_page;
+          const int fy = (a_oy[i] + dy) >> 1, fx = (a_ox[i] + dx) >> 1;      // in {-1, 0, +1}
+          const bool ok = (a_mask[i] >> tap) & 1u;
+          const bf16_t* src = ok ? a_ptr[i] + (fy * p.Win + fx) * p.Cin + ci0 : zero_page;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                            (__attribute__((address_space(3))) void*)(sa + a_lds[i]), 16, 0, 0);
         }
@@ -206,9 +217,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
       if (MODE == 3) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
-          const int uy = a_oy[i] + dy, ux = a_ox[i] + dx;
-          const bool ok = a_mask[i] && (unsigned)uy < (unsigned)(2 * p.Hin) && (unsigned)ux < (unsigned)(2 * p.Win);
-          const bf16_t* src = ok ? a_ptr[i] + ((long)(uy >> 1) * p.Win + (ux >> 1)) * p.Cin + ci0 : zero_page;
+          const int fy = (a_oy[i] + dy) >> 1, fx = (a_ox[i] + dx) >> 1;      // in {-1, 0, +1}
+          const bool ok = (a_mask[i] >> tap) & 1u;
+          const bf16_t* src = ok ? a_ptr[i] + (fy * p.Win + fx) * p.Cin + ci0 : zero_page;
           a_reg[i] = *reinterpret_cast<const u32x4*>(src);
         }
       } else {
