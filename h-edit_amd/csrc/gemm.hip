@@ -25,32 +25,40 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // (not HIP's uint4 struct: aggregate
                                                                //  copies become memcpy and defeat SROA)
-constexpr int BM = 128;
+constexpr int BM0 = 128;   // row tile of the 4-wave kernel (also used by the host heuristics)
 constexpr int BK = 64;
 
-template <int BN>
+// BM = 128: 256 threads (2x2 waves), 2 LDS stages, 2 blocks per CU.
+// BM = 256: 512 threads (4x2 waves), 3 LDS stages (LDS-DMA only), 1 block per CU: 28 % less
+//           operand traffic per MFMA and two K-tiles in flight.
+template <int BM, int BN>
 struct Smem {
   static constexpr int A_BYTES = BM * BK * 2;
   static constexpr int W_BYTES = BN * BK * 2;
   static constexpr int STAGE = A_BYTES + W_BYTES;
-  static constexpr int TOTAL = 2 * STAGE;
+  static constexpr int STAGES = BM == 256 ? 3 : 2;
+  static constexpr int TOTAL = STAGES * STAGE;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <int BN, int MODE, bool GLDS>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
+template <int BM, int BN, int MODE, bool GLDS>
+__global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = BM * 2;       // threads: 4 or 8 waves, each owning a 64 x BN/2 sub-tile
+  constexpr int NW = NT / 64;
   constexpr int NI = BN / 32;      // 16-wide n sub-tiles per wave
   constexpr int MI = 4;            // 16-wide m sub-tiles per wave
-  constexpr int A_CH = BM * 8 / 256;
-  constexpr int W_CH = BN * 8 / 256;
-  using S = Smem<BN>;
+  constexpr int A_CH = BM * 8 / NT;                    // 16-byte chunks (or 8-row DMA groups) per thread / wave
+  constexpr int W_GROUPS = BN / 8;
+  constexpr int W_CH = (W_GROUPS + NW - 1) / NW;       // 8 waves x 3 > 20 groups: the surplus re-loads the last group
+  static_assert(GLDS || BM == 128, "the 256-row tile exists for LDS-DMA staging only");
+  using S = Smem<BM, BN>;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 1, wn = wave & 1;      // (BM/64) x 2 waves
 
   // XCD-aware tile order.  Workgroup b is observed to run on XCD b % 8 (speed only, never
   // correctness): give every XCD one contiguous chunk of the tile sequence so that tiles which
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
     // LDS-DMA staging: one wave instruction fills 8 rows x 128 B linearly (lane L -> row L>>3,
     // slot L&7), so the swizzle is applied on the SOURCE side: slot p of row r must receive
     // chunk p ^ (r & 7)  (same involution the fragment reads use).
-    const int id = tid + i * 256;
+    const int id = tid + i * NT;
     const int row = GLDS ? (wave * A_CH + i) * 8 + (lane >> 3) : id >> 3;
     const int c = GLDS ? ((lane & 7) ^ (lane >> 3)) : id & 7;
     const int m = m0 + row;
@@ -141,12 +149,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
   int w_lds[W_CH];
 #pragma unroll
   for (int i = 0; i < W_CH; ++i) {
-    const int id = tid + i * 256;
-    const int row = GLDS ? (wave * W_CH + i) * 8 + (lane >> 3) : id >> 3;
+    const int id = tid + i * NT;
+    int wg = wave * W_CH + i;
+    if (wg > W_GROUPS - 1) wg = W_GROUPS - 1;
+    const int row = GLDS ? wg * 8 + (lane >> 3) : id >> 3;
     const int c = GLDS ? ((lane & 7) ^ (lane >> 3)) : id & 7;
     const int n = n0 + row;
     w_ok[i] = n < p.N;
-    w_lds[i] = GLDS ? (wave * W_CH + i) * 1024 : swz(row, c);
+    w_lds[i] = GLDS ? wg * 1024 : swz(row, c);
     w_ptr[i] = p.W + (long)n * p.K + c * 8;
   }
 
@@ -282,7 +292,26 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
     }
   };
 
-  if constexpr (GLDS) {
+  if constexpr (GLDS && S::STAGES == 3) {
+    // three LDS stages, two K-tiles of DMA in flight.  A wave waits (counted vmcnt: everything
+    // except its A_CH + W_CH newest DMA instructions) for ITS part of tile k, the raw barrier then
+    // publishes every wave's part and proves that nobody still reads the stage tile k+2 is about
+    // to overwrite (it was consumed in iteration k-1).  __syncthreads() would drain vmcnt to 0.
+    constexpr int NDMA = A_CH + W_CH;
+    const int nk = kt_end - kt_begin;
+    if (nk > 0) issue_glds(kt_begin, 0);
+    if (nk > 1) issue_glds(kt_begin + 1, 1);
+    int cur = 0, nxt = 2;
+    for (int i = 0; i < nk; ++i) {
+      if (i + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (i + 2 < nk) issue_glds(kt_begin + i + 2, nxt);
+      compute(cur);
+      cur = cur == 2 ? 0 : cur + 1;
+      nxt = nxt == 2 ? 0 : nxt + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the epilogue
+  } else if constexpr (GLDS) {
     // two LDS stages: the DMA of tile k+1 runs under the MFMAs of tile k; a wave waits for its
     // own DMA (vmcnt) and the barrier then makes every wave's part of the stage visible and
     // guarantees nobody still reads the stage that is about to be overwritten.
@@ -364,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
       __syncthreads();
       constexpr int GCH = ON / 8;
       const int on0 = n0 / 2;
-      for (int idx = tid; idx < BM * GCH; idx += 256) {
+      for (int idx = tid; idx < BM * GCH; idx += NT) {
         const int ml = idx / GCH, c = idx - ml * GCH;
         const int m = m0 + ml, n = on0 + c * 8;
         if (m >= p.M || n >= p.N / 2) continue;
@@ -396,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GemmParams p) {
   }
   __syncthreads();
   constexpr int CHUNKS = BN / 8;              // 16-byte chunks per tile row
-  for (int idx = tid; idx < BM * CHUNKS; idx += 256) {
+  for (int idx = tid; idx < BM * CHUNKS; idx += NT) {
     const int ml = idx / CHUNKS, c = idx - ml * CHUNKS;
     const int m = m0 + ml, n = n0 + c * 8;
     if (m >= p.M || n >= p.N) continue;
@@ -460,19 +489,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   *reinterpret_cast<uint2*>(p.C + (long)m * p.ldc + n) = o;
 }
 
-template <int BN, int MODE, bool GLDS>
+template <int BM, int BN, int MODE, bool GLDS>
 int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
-  using S = Smem<BN>;
+  using S = Smem<BM, BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BN, MODE, GLDS>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, GLDS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, S::TOTAL));
     attr_set = true;
   }
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), splits);
-  hipLaunchKernelGGL((igemm_kernel<BN, MODE, GLDS>), grid, dim3(256), S::TOTAL, st, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, GLDS>), grid, dim3(BM * 2), S::TOTAL, st, p);
   LAUNCH_CHECK();
   return HEDIT_OK;
+}
+
+// HEDIT_GEMM_BM=256 selects the 8-wave 256-row / 3-stage variant for every launch that has at least
+// 480 such tiles; measured on MI355X it ties the default 128-row kernel within +-3 % (both sit at
+// the ceiling of the two-barrier-per-K-tile structure), so it is off by default.
+static int big_tile_mode() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("HEDIT_GEMM_BM");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
 }
 
 // operand staging: direct-to-LDS DMA by default; HEDIT_GEMM_STAGING=regs selects the
@@ -488,7 +529,11 @@ static bool use_glds() {
 
 template <int BN, int MODE>
 int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
-  return use_glds() ? launch_igemm_impl<BN, MODE, true>(p, splits, st) : launch_igemm_impl<BN, MODE, false>(p, splits, st);
+  if (!use_glds()) return launch_igemm_impl<128, BN, MODE, false>(p, splits, st);
+  const long big_tiles = (long)cdiv(p.M, 256) * cdiv(p.N, BN);
+  const int mode = big_tile_mode();
+  const bool big = mode == 256 && splits == 1 && big_tiles >= 480;
+  return big ? launch_igemm_impl<256, BN, MODE, true>(p, splits, st) : launch_igemm_impl<128, BN, MODE, true>(p, splits, st);
 }
 
 }  // namespace
@@ -505,7 +550,7 @@ int gemm_pick_bn(int N) {
 int gemm_pick_splits(int M, int N, int K, int force) {
   if (force > 0) return force;
   const int bn = gemm_pick_bn(N);
-  const long tiles = (long)cdiv(M, BM) * cdiv(N, bn);
+  const long tiles = (long)cdiv(M, BM0) * cdiv(N, bn);
   const int kt = K / BK;
   if (tiles >= 384 || kt < 8) return 1;
   int s = (int)((640 + tiles - 1) / tiles);     // aim at >= 2 resident blocks per CU
