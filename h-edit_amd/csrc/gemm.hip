@@ -504,8 +504,7 @@ int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
   return HEDIT_OK;
 }
 
-// HEDIT_GEMM_BM=256 selects the 8-wave 256-row / 3-stage variant for every launch that has at least
-// 480 such tiles; measured on MI355X it ties the default 128-row kernel within +-3 % (both sit at
+// HEDIT_GEMM_BM=256 selects the 8-wave 256-row / 3-stage variant for every launch; measured on MI355X it ties the default 128-row kernel within +-3 % (both sit at
 // the ceiling of the two-barrier-per-K-tile structure), so it is off by default.
 static int big_tile_mode() {
   static int v = -1;
@@ -532,7 +531,8 @@ int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
   if (!use_glds()) return launch_igemm_impl<128, BN, MODE, false>(p, splits, st);
   const long big_tiles = (long)cdiv(p.M, 256) * cdiv(p.N, BN);
   const int mode = big_tile_mode();
-  const bool big = mode == 256 && splits == 1 && big_tiles >= 480;
+  (void)big_tiles;
+  const bool big = mode == 256;
   return big ? launch_igemm_impl<256, BN, MODE, true>(p, splits, st) : launch_igemm_impl<128, BN, MODE, true>(p, splits, st);
 }
 
