@@ -104,12 +104,19 @@ class HEditEngine:
     # ------------------------------------------------------------------ the loop
     @torch.no_grad()
     def run(self, xT, zs, prompt_pairs, cfg_scales, controller=None, eta=1.0, p2p=True, implicit=True,
-            K=1, w_rec=0.1, after_skip_steps=None, ddim_inv=False, ctx=None, fuse_src_pass=False):
+            K=1, w_rec=0.1, after_skip_steps=None, ddim_inv=False, ctx=None, fuse_src_pass=False,
+            reuse_orig_eps=False):
         """xT: (n,C,H,W); zs: (T',n,C,H,W) or None; prompt_pairs: n x [src, tar].
         ctx: optional precomputed (null, src, tar) embeddings ((1|n,77,D), (n,77,D), (n,77,D)).
         fuse_src_pass: evaluate eps(x^k, t-1, src) (the reference's separate n-row call,
         p2p_h_edit.py:644) as n extra un-edited rows of the P2P pass (5n rows): same arithmetic and
         FLOPs, one UNet launch sequence fewer per inner step.
+        reuse_orig_eps (implicit P2P loop only, OFF by default): the P2P pass at t-1 evaluates
+        eps(x^orig_{t-1}, t-1, null) and eps(x^orig_{t-1}, t-1, src) -- rows the controller never
+        edits (ptp_classes.py:96-98,213-220) -- and the reference's next base pass
+        (p2p_h_edit.py:604-616) recomputes exactly these two.  Reusing them evaluates 2n instead of
+        4n rows in every base pass but the first: 7 instead of 9 sample-forwards per step at K=1.
+        Same mathematics, fewer UNet evaluations than the reference issues.
         Returns (edit (n,C,H,W), recon (n,C,H,W))."""
         sch = self.model.scheduler
         S = Schedule(sch)
@@ -148,6 +155,8 @@ class HEditEngine:
             controller._after_pass(save)
             return e
 
+        carry = None      # (eps(x_orig, t, null), eps(x_orig, t, src)) from the previous P2P pass
+        reuse = reuse_orig_eps and p2p and implicit
         for i, t in enumerate(op):
             idx = T - i - (T - after_skip_steps + 1)
             z = zs[idx] if zs is not None else None
@@ -164,7 +173,11 @@ class HEditEngine:
                 xt = torch.cat([xt[:n], new]).contiguous()
 
             # ---- base pass -> x_{t-1}^orig, x_{t-1}^base
-            if p2p:
+            if p2p and reuse and carry is not None:
+                e2 = self.unet.forward_raw(torch.cat([xt[n:], xt[n:]]), t, ctx_base2, off)
+                e = torch.cat([carry[0], e2[:n], carry[1], e2[n:]])
+                self.step_base(e, xt, z, x_prev, n, 4, coef)
+            elif p2p:
                 e = self.unet.forward_raw(torch.cat([xt, xt]), t, ctx_base4, off)
                 self.step_base(e, xt, z, x_prev, n, 4, coef)
             else:
@@ -195,6 +208,8 @@ class HEditEngine:
                             e_src = self.unet.forward_raw(x_k, tt, ctx_src, off)
                             e = p2p_pass(torch.cat([x_orig, x_k, x_orig, x_k]), tt, save)
                         self.step_update(e[n:2 * n], e_src, e[n:2 * n], e[3 * n:4 * n], x_k, x_base, new, n, k > 0, coef)
+                        if reuse:
+                            carry = (e[0:n], e[2 * n:3 * n])
                     else:
                         e = self.unet.forward_raw(torch.cat([x_k] * 4), tt, ctx_edit, off)
                         self.step_update(e[0:n], e[2 * n:3 * n], e[n:2 * n], e[3 * n:], x_k, x_base, new, n, k > 0, coef)

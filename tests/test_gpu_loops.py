@@ -173,18 +173,19 @@ def test_fused_source_pass_is_equivalent(setup):
     zs, wts, _ = inv[0]
     A = 4
     outs = []
-    for fuse in (False, True):
+    for fuse, reuse in ((False, False), (True, False), (True, True)):
         src, tar, blend, is_replace = PROMPT_PAIRS[0]
         c = PCU.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=((blend[0],), (blend[1],)),
                                 equilizer_params={"words": (blend[1],), "values": (1.25,)}, num_steps=A,
                                 tokenizer=hip.tokenizer, device=hip.device)
         register_attention_control(hip, c)
         outs.append(eng.run(G.f32(wts[A][None]), G.f32(zs[:A, None]), [[src, tar]], [1.0, 5.0, 7.5], c, K=2,
-                            w_rec=0.1, after_skip_steps=A, fuse_src_pass=fuse))
+                            w_rec=0.1, after_skip_steps=A, fuse_src_pass=fuse, reuse_orig_eps=reuse))
         assert c.cur_step == A
     G.sync()
-    assert G.rel_err(outs[1][0], outs[0][0]) < 3e-2
-    assert G.rel_err(outs[1][1], outs[0][1]) < 1e-2
+    for o in outs[1:]:
+        assert G.rel_err(o[0], outs[0][0]) < 3e-2
+        assert G.rel_err(o[1], outs[0][1]) < 1e-2
 
 
 def test_h_edit_d_ddim_inversion_end_to_end():
