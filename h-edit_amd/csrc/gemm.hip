@@ -402,21 +402,44 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     }
     return;
   }
-  // bf16 output: stage the 128 x BN tile in LDS (the K loop is over, its buffers are free) and
+  // bf16 output: stage the BM x BN tile in LDS (the K loop is over, its buffers are free) and
   // write it out as whole rows, 16 B per lane, so a wave store instruction covers >= 1 KiB of
-  // contiguous NHWC memory instead of sixteen 32-byte fragments.
+  // contiguous NHWC memory instead of sixteen 32-byte fragments.  The residual rows and the bias
+  // are requested FIRST, all at once, so their latency hides under the staging pass instead of
+  // costing one dependent round trip per 16-byte piece.
   constexpr int CS = BN + 8;                  // padded row stride (elements): 16-B aligned rows
+  constexpr int CHUNKS = BN / 8;              // 16-byte chunks per tile row
+  constexpr int ITER = BM * CHUNKS / NT;
+  static_assert(BM * CHUNKS % NT == 0, "tile rows must divide evenly over the block");
   bf16_t* sc = reinterpret_cast<bf16_t*>(smem);
   static_assert(BM * CS * 2 <= S::TOTAL, "epilogue tile must fit the staging LDS");
+  const bool aligned8 = (p.N % 8 == 0) && (p.ldc % 8 == 0) && (p.residual == nullptr || p.ldr % 8 == 0);
+
+  u32x4 resid[ITER];
+  if (aligned8 && p.residual) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * NT;
+      const int ml = idx / CHUNKS, c = idx - ml * CHUNKS;
+      const int m = m0 + ml, n = n0 + c * 8;
+      const bf16_t* src = (m < p.M && n < p.N) ? p.residual + (long)m * p.ldr + n : zero_page;
+      resid[it] = *reinterpret_cast<const u32x4*>(src);
+    }
+  }
+  f32x4 biasv[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wn * (BN / 2) + j * 16 + fq * 4;
+    biasv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) biasv[j] = *reinterpret_cast<const f32x4*>(p.bias + n);
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int ml = wm * 64 + i * 16 + fr;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int nl = wn * (BN / 2) + j * 16 + fq * 4;
-      const int n = n0 + nl;
-      f32x4 v = acc[i][j];
-      if (p.bias && n < p.N) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      const f32x4 v = acc[i][j] + biasv[j];
       uint2 o;
       o.x = pack_bf16x2(v[0], v[1]);
       o.y = pack_bf16x2(v[2], v[3]);
@@ -424,42 +447,39 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     }
   }
   __syncthreads();
-  constexpr int CHUNKS = BN / 8;              // 16-byte chunks per tile row
-  for (int idx = tid; idx < BM * CHUNKS; idx += NT) {
-    const int ml = idx / CHUNKS, c = idx - ml * CHUNKS;
-    const int m = m0 + ml, n = n0 + c * 8;
-    if (m >= p.M || n >= p.N) continue;
-    uint4 u = *reinterpret_cast<const uint4*>(sc + ml * CS + c * 8);
-    if (n + 8 <= p.N && (p.ldc & 7) == 0) {
-      if (p.residual) {
-        const uint4 r = *reinterpret_cast<const uint4*>(p.residual + (long)m * p.ldr + n);
-        u.x = pack_bf16x2(bf16_to_f32((bf16_t)(u.x & 0xffff)) + bf16_to_f32((bf16_t)(r.x & 0xffff)),
-                          bf16_to_f32((bf16_t)(u.x >> 16)) + bf16_to_f32((bf16_t)(r.x >> 16)));
-        u.y = pack_bf16x2(bf16_to_f32((bf16_t)(u.y & 0xffff)) + bf16_to_f32((bf16_t)(r.y & 0xffff)),
-                          bf16_to_f32((bf16_t)(u.y >> 16)) + bf16_to_f32((bf16_t)(r.y >> 16)));
-        u.z = pack_bf16x2(bf16_to_f32((bf16_t)(u.z & 0xffff)) + bf16_to_f32((bf16_t)(r.z & 0xffff)),
-                          bf16_to_f32((bf16_t)(u.z >> 16)) + bf16_to_f32((bf16_t)(r.z >> 16)));
-        u.w = pack_bf16x2(bf16_to_f32((bf16_t)(u.w & 0xffff)) + bf16_to_f32((bf16_t)(r.w & 0xffff)),
-                          bf16_to_f32((bf16_t)(u.w >> 16)) + bf16_to_f32((bf16_t)(r.w >> 16)));
-      }
-      *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = u;
-    } else {
-      // ragged right edge (N % 8 == 4) or 8-byte-aligned rows only: two 8-byte halves
-      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+  auto add2 = [](uint32_t a, uint32_t b) __attribute__((always_inline)) {
+    return pack_bf16x2(bf16_to_f32((bf16_t)(a & 0xffff)) + bf16_to_f32((bf16_t)(b & 0xffff)),
+                       bf16_to_f32((bf16_t)(a >> 16)) + bf16_to_f32((bf16_t)(b >> 16)));
+  };
+  if (aligned8) {
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int nn = n + hh * 4;
-        if (nn >= p.N) continue;
-        uint2 o = make_uint2(w[hh * 2], w[hh * 2 + 1]);
-        if (p.residual) {
-          const uint2 r = *reinterpret_cast<const uint2*>(p.residual + (long)m * p.ldr + nn);
-          o.x = pack_bf16x2(bf16_to_f32((bf16_t)(o.x & 0xffff)) + bf16_to_f32((bf16_t)(r.x & 0xffff)),
-                            bf16_to_f32((bf16_t)(o.x >> 16)) + bf16_to_f32((bf16_t)(r.x >> 16)));
-          o.y = pack_bf16x2(bf16_to_f32((bf16_t)(o.y & 0xffff)) + bf16_to_f32((bf16_t)(r.y & 0xffff)),
-                            bf16_to_f32((bf16_t)(o.y >> 16)) + bf16_to_f32((bf16_t)(r.y >> 16)));
-        }
-        *reinterpret_cast<uint2*>(p.C + (long)m * p.ldc + nn) = o;
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * NT;
+      const int ml = idx / CHUNKS, c = idx - ml * CHUNKS;
+      const int m = m0 + ml, n = n0 + c * 8;
+      if (m >= p.M || n >= p.N) continue;
+      u32x4 u = *reinterpret_cast<const u32x4*>(sc + ml * CS + c * 8);
+      if (p.residual) {
+        u[0] = add2(u[0], resid[it][0]);
+        u[1] = add2(u[1], resid[it][1]);
+        u[2] = add2(u[2], resid[it][2]);
+        u[3] = add2(u[3], resid[it][3]);
       }
+      *reinterpret_cast<u32x4*>(p.C + (long)m * p.ldc + n) = u;
+    }
+  } else {
+    // ragged right edge (N % 8 == 4) or rows that are only 8-byte aligned: 8-byte pieces
+    for (int idx = tid; idx < BM * CHUNKS * 2; idx += NT) {
+      const int ml = idx / (CHUNKS * 2), h = idx - ml * (CHUNKS * 2);
+      const int m = m0 + ml, n = n0 + h * 4;
+      if (m >= p.M || n >= p.N) continue;
+      uint2 o = *reinterpret_cast<const uint2*>(sc + ml * CS + h * 4);
+      if (p.residual) {
+        const uint2 r = *reinterpret_cast<const uint2*>(p.residual + (long)m * p.ldr + n);
+        o.x = add2(o.x, r.x);
+        o.y = add2(o.y, r.y);
+      }
+      *reinterpret_cast<uint2*>(p.C + (long)m * p.ldc + n) = o;
     }
   }
 }
