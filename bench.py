@@ -58,6 +58,7 @@ def parse():
                     help="issue the source-prompt pass as its own UNet call like the reference instead of "
                          "as n extra rows of the P2P pass (same arithmetic either way)")
     ap.add_argument("--force-dist", action="store_true", help="init the RCCL process group even for one rank")
+    ap.add_argument("--no-single", action="store_true", help="skip the auxiliary one-image latency measurement")
     ap.add_argument("--reuse-orig-eps", action="store_true",
                     help="opt-in: reuse eps(x_orig, t-1, {null,src}) of the P2P pass in the next base pass "
                          "(7 instead of 9 sample-forwards per step; NOT the reference's evaluation count)")
@@ -197,6 +198,27 @@ def main():
     calls["prof"] = False
     unet_calls = calls["n"]
 
+    # auxiliary (outside the timed region): BASELINE configs[1] read literally = ONE image; latency
+    single_s = None
+    if not args.no_single:
+        def one_image():
+            c1 = PCU.make_controller(prompts=list(prompt_pairs[0]), is_replace_controller=pairs[0][3],
+                                     cross_replace_steps=0.4, self_replace_steps=0.35,
+                                     blend_word=((pairs[0][2][0],), (pairs[0][2][1],)),
+                                     equilizer_params={"words": (pairs[0][2][1],), "values": (2.0 if K == 1 else 1.25,)},
+                                     num_steps=T, tokenizer=tok, device=dev)
+            register_attention_control(model, c1)
+            return eng.run(xT[:1], zs[:, :1].contiguous(), prompt_pairs[:1], cfg_scales, c1, eta=1.0, p2p=True,
+                           implicit=True, K=K, w_rec=0.1, after_skip_steps=T, ddim_inv=False,
+                           ctx=(null, src[:1], tar[:1]), fuse_src_pass=not args.no_fuse_src,
+                           reuse_orig_eps=args.reuse_orig_eps)
+        one_image()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one_image()
+        torch.cuda.synchronize()
+        single_s = time.perf_counter() - t1
+
     finite = bool(torch.isfinite(edit).all())
     recon_err = float(((recon - w0).norm() / w0.norm()).item())
     prof = unet.prof_collect()
@@ -255,6 +277,9 @@ def main():
         "mfma_frac_whole_loop": round(total_flops / elapsed / 1e12 / world / MFMA_PEAK_TFLOPS, 4),
         "ms_per_unet_sample_forward": round(1e3 * elapsed * world / (imgs * evaluated_per_img), 4),
         "roofline": roof, "kernels_sampled": kernels, "cpu_baseline": cpu,
+        "single_image": None if single_s is None else {"latency_s": round(single_s, 4), "images_per_s": round(1.0 / single_s, 4),
+                                                        "note": "configs[1] read literally (1 image, 450 sample-forwards), "
+                                                                "measured after the timed region"},
         "finite": finite, "recon_rel_err": round(recon_err, 5),
         "setup_s": {"weights_create_broadcast_load": round(t_weights, 1), "ddpm_inversion_untimed": round(t_inversion, 2)},
     }

@@ -121,3 +121,62 @@ def test_sd15_unet_forward_full_size():
     assert err < TOL_SD, err
     assert len(hip.unet.attn_processors) == 32
     assert sum(int(torch.tensor(s).prod()) for s in hip.unet.param_shapes.values()) == 859520964
+
+
+def test_tiny_unet_rectangular_latent(tiny):
+    """H != W (64 x 32 latent): conv gathers, attention token counts and the up/down sampling use
+    separate H and W everywhere."""
+    hip, om, _ = tiny
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 4, 64, 32, generator=g)
+    ctx = torch.randn(2, 77, TINY_CONFIG["cross_attention_dim"], generator=g)
+    with torch.no_grad():
+        want = om.unet(x, torch.tensor(301), encoder_hidden_states=ctx).sample
+    got = hip.unet(G.f32(x), 301, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"use_controller": False}).sample
+    G.sync()
+    assert got.shape == want.shape
+    assert G.rel_err(got, want) < TOL_TINY
+
+
+def test_rows_are_independent_of_batch_position(tiny):
+    """a sample's eps does not depend on what else is in the batch (the engine relies on it when it
+    folds passes together); differences come only from split-K / tile choices, i.e. fp32 summation order"""
+    hip, _, _ = tiny
+    x, ctx = _inputs(5, TINY_CONFIG, 33)
+    kw = {"use_controller": False}
+    full = hip.unet(G.f32(x), 401, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs=kw).sample
+    one = hip.unet(G.f32(x[3:4]), 401, encoder_hidden_states=G.f32(ctx[3:4]), cross_attention_kwargs=kw).sample
+    G.sync()
+    assert G.rel_err(full[3:4], one) < 1e-2
+
+
+def test_c_abi_error_paths(tiny):
+    import ctypes as C
+    from hedit import _lib
+    hip, _, _ = tiny
+    lib = _lib.lib()
+    u = hip.unet
+    x, ctx = _inputs(2, TINY_CONFIG, 2)
+    xd, cd = G.f32(x), G.f32(ctx)
+    out = torch.empty_like(xd)
+    small = torch.empty(4096, dtype=torch.uint8, device=G.dev())
+    rc = lib.hedit_unet_forward(u._h, _lib.ptr(xd), C.c_float(1.0), _lib.ptr(cd), 2, 32, 32, None, _lib.ptr(out),
+                                _lib.ptr(small), small.numel(), None)
+    assert rc != 0 and b"workspace" in lib.hedit_last_error()
+    rc = lib.hedit_unet_forward(u._h, _lib.ptr(xd), C.c_float(1.0), _lib.ptr(cd), 2, 30, 32, None, _lib.ptr(out),
+                                _lib.ptr(small), small.numel(), None)
+    assert rc != 0 and b"divisible" in lib.hedit_last_error()
+    rc = lib.hedit_unet_load(u._h, b"no.such.weight", _lib.ptr(xd), 4, None)
+    assert rc != 0 and b"unknown parameter" in lib.hedit_last_error()
+    rc = lib.hedit_unet_load(u._h, b"conv_in.bias", _lib.ptr(xd), 3, None)
+    assert rc != 0 and b"size mismatch" in lib.hedit_last_error()
+    # an unsupported architecture is refused at creation, with a message
+    bad = _lib.UnetCfg()
+    bad.in_channels, bad.out_channels, bad.sample_size, bad.n_levels = 4, 4, 32, 2
+    bad.block_out_channels[0], bad.block_out_channels[1] = 64, 96          # 96/2 heads = 48: no kernel
+    bad.down_has_attn[0] = 1
+    bad.up_has_attn[1] = 1
+    bad.layers_per_block, bad.cross_attention_dim, bad.heads, bad.norm_num_groups = 1, 64, 2, 32
+    h = C.c_void_p()
+    assert lib.hedit_unet_create(C.byref(bad), C.byref(h)) != 0
+    assert b"head dim" in lib.hedit_last_error() or b"block_out_channels" in lib.hedit_last_error()
