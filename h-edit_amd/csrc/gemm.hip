@@ -275,21 +275,27 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* sa = smem + buf * S::STAGE;
     const char* sw = sa + S::A_BYTES;
+    // all 18 fragment reads of the K-tile are issued up front (fragments of both 32-deep k-steps
+    // live in registers), so the second k-step's LDS latency hides under the first one's MFMAs
+    bf16x8 xf[2][MI], wf[2][NI];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 xf[MI], wf[NI];
       const char* pa = sa + (a_rd ^ (ks << 6));
       const char* pw = sw + (w_rd ^ (ks << 6));
 #pragma unroll
-      for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(pa + i * 2048);
+      for (int i = 0; i < MI; ++i) xf[ks][i] = *reinterpret_cast<const bf16x8*>(pa + i * 2048);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + j * 2048);
+      for (int j = 0; j < NI; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(pw + j * 2048);
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], xf[ks][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
   };
 
   if constexpr (GLDS && S::STAGES == 3) {
