@@ -16,6 +16,10 @@ OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "hedit", "libhedit_hip.so")
 UNITS = ["gemm.hip", "norm.hip", "attn.hip", "step.hip", "unet.hip", "c_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+# per-unit extras.  attn.hip: the row-max chains run on raw MFMA results; without the no-NaN promise
+# every fmaxf operand is first canonicalised (v_max x,x), tripling the instruction count of the
+# softmax's max pass.  (NaN inputs propagate to NaN outputs either way.)
+UNIT_FLAGS = {"attn.hip": ["-fno-honor-nans"]}
 
 
 def _deps_mtime():
@@ -37,7 +41,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + UNIT_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

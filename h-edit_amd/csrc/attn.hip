@@ -22,8 +22,11 @@
 //   asked, and finishes with P.V for both rows.
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // (not HIP's uint4 struct, which SROA handles badly)
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -55,178 +58,474 @@ __device__ __forceinline__ bf16x8 read_perm_frag(const bf16_t* base, int row, in
 }
 
 // ============================================================================ self-attention
+// Flash attention over 64-row KV tiles, organised around what limits it on CDNA4: per 32x32 score
+// block a lane has ~55 VALU instructions of softmax work (sub, exp2, max, bf16 pack) against
+// 3 + 4 MFMAs (d = 40), and a wave issues in order -- an MFMA queued behind a busy matrix pipe
+// blocks the VALU work after it.  So:
+//   * KV tiles go global -> LDS by DMA (global_load_lds, no staging VGPRs, no ds_write) into three
+//     stages, issued two tiles ahead; one barrier per tile.  Tiles are dense (no row padding): the
+//     source chunk each lane fetches is XOR-swizzled so that the b128 fragment reads are
+//     conflict-free for every head dim.
+//   * the work is cut into "units" (32 kv rows x 32 queries) and software-pipelined across them:
+//     block U issues P.V of unit U-1, QK^T of unit U+2 and the row max of unit U+1 around the
+//     exp/pack work of unit U.  All MFMAs in a block are independent of its VALU work, so they
+//     interleave instead of serialising.
+//   * two accumulator streams per wave alternate between units, which keeps the lazy max rescale
+//     of a stream away from the P.V still in flight for it.  QG = 2: the streams are two groups of
+//     32 queries (K / V^T fragments are shared by the pair); QG = 1 (large head dims): one query
+//     group, the streams are the two 32-row halves of every KV tile, merged at the end.
+//   * the S^T rows of a half tile are visited in a permuted order (kv_perm) chosen so that the 8
+//     probabilities a lane packs for the P.V B-operand belong to 8 CONSECUTIVE kv rows: the V^T
+//     A-fragment is then a single b128 read of the natural layout.
+//   * when the head dim leaves pad rows in the last 32-row V^T tile, pad row D holds ones: the P.V
+//     MFMA also produces the softmax denominator and the per-element VALU add disappears.
 template <int D>
-__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfAttnParams p) {
-  using H = HeadCfg<D>;
-  constexpr int VS = 68;
-  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * H::KS];
-  __shared__ __attribute__((aligned(16))) bf16_t sV[H::DT * 32 * VS];
+__device__ __forceinline__ int k_swz(int row) {
+  if (D == 32 || D == 160) return (row >> 2) & 3;
+  if (D == 64) return (row >> 1) & 7;
+  if (D == 80) return (row >> 4) & 1;
+  return 0;   // 80-byte rows (d = 40) are conflict-free as they are
+}
+__device__ __forceinline__ int v_swz(int row) { return (row >> 1) & 7; }
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <int D, int QG>
+struct SelfCfg {
+  using H = HeadCfg<D>;
+  static constexpr int DCH = D / 8;                    // 16-byte chunks per K row
+  static constexpr int K_BYTES = 64 * DCH * 16;
+  static constexpr int V_ROWS = H::DT * 32;
+  static constexpr int V_BYTES = V_ROWS * 128;
+  static constexpr int STAGE = K_BYTES + V_BYTES;
+  static constexpr int TOTAL = 3 * STAGE;
+  static constexpr int KI = DCH, VI = D / 8;           // 1 KiB DMA instructions per tile (K, V^T)
+  static constexpr int TI = KI + VI, NI = (TI + 3) / 4;
+  static constexpr int UT = 2 * QG;                    // units per KV tile
+};
+
+template <int D, int QG, int NS>
+__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfAttnParams p) {
+  static_assert(QG == 1 || NS == 2, "two query groups are two streams");
+  using H = HeadCfg<D>;
+  using C = SelfCfg<D, QG>;
+  constexpr bool ONES = H::DT * 32 > D;
+  constexpr int DK = H::DK, DT = H::DT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 31, hi = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
   const int bqk = p.qk_src ? p.qk_src[b] : b;
-  const int q_row = blockIdx.x * 128 + wave * 32 + ql;
-  const bool q_ok = q_row < p.N;
+  const int q_base = blockIdx.x * (128 * QG) + wave * (32 * QG) + ql;
 
-  // zero LDS once: pad columns of K (>= D) and pad rows of V^T (>= D) must be finite zeros
-  for (int i = tid; i < 64 * H::KS / 8; i += 256) reinterpret_cast<uint4*>(sK)[i] = make_uint4(0, 0, 0, 0);
-  for (int i = tid; i < H::DT * 32 * VS / 4; i += 256) reinterpret_cast<uint2*>(sV)[i] = make_uint2(0, 0);
+  // zero LDS once (pad rows of V^T must be finite zeros), then the row of ones
+  for (int i = tid; i < C::TOTAL / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  if (ONES) {
+    for (int i = tid; i < 3 * 64; i += 256)
+      reinterpret_cast<bf16_t*>(smem + (i >> 6) * C::STAGE + C::K_BYTES + D * 128)[i & 63] = (bf16_t)0x3F80;
+  }
 
-  // Q fragments (B operand): lane holds Q[q][ks*16 + hi*8 .. +8]
-  bf16x8 qf[H::DK];
-  {
+  // Q fragments (B operand): lane holds Q[q][ks*16 + hi*8 .. +8]; zero beyond D, so whatever the
+  // K fragment read picks up in the pad columns (the next row's data) never contributes
+  bf16x8 qf[QG][DK];
+#pragma unroll
+  for (int g = 0; g < QG; ++g) {
+    const int q_row = q_base + g * 32;
+    const bool q_ok = q_row < p.N;
     const bf16_t* qp = p.q + ((long)bqk * p.N + (q_ok ? q_row : 0)) * p.ldq + h * D;
 #pragma unroll
-    for (int ks = 0; ks < H::DK; ++ks) {
+    for (int ks = 0; ks < DK; ++ks) {
       const int c = ks * 16 + hi * 8;
-      union { uint4 u; bf16x8 v; } x;
-      x.u = make_uint4(0, 0, 0, 0);
-      if (q_ok && c < D) x.u = *reinterpret_cast<const uint4*>(qp + c);
-      qf[ks] = x.v;
+      union { u32x4 u; bf16x8 v; } x;
+      x.u = (u32x4){0, 0, 0, 0};
+      if (q_ok && c < D) x.u = *reinterpret_cast<const u32x4*>(qp + c);
+      qf[g][ks] = x.v;
     }
   }
 
-  constexpr int K_IT = (64 * H::DCH + 255) / 256;
-  constexpr int V_IT = (D * 8 + 255) / 256;
-  uint4 kreg[K_IT], vreg[V_IT];
-  // per-thread staging coordinates, fixed for the whole KV loop
-  const bf16_t* kptr[K_IT];
-  const bf16_t* vptr[V_IT];
-  int klds[K_IT], vlds[V_IT];
-  bool kok[K_IT], vok[V_IT];
-  {
-    const bf16_t* kbase = p.k + (long)bqk * p.N * p.ldk + h * D;
-    const bf16_t* vbase = p.vt + (long)h * D * p.ldvt + (long)b * p.N;
+  // ---- DMA plan: instruction i = wave + 4n moves 1 KiB (64 lanes x 16 B) of the tile
+  unsigned dma_off[C::NI];
 #pragma unroll
-    for (int i = 0; i < K_IT; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / H::DCH, c = idx - row * H::DCH;
-      kok[i] = idx < 64 * H::DCH;
-      kptr[i] = kbase + (long)row * p.ldk + c * 8;
-      klds[i] = row * H::KS + c * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < V_IT; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx >> 3, c = idx & 7;
-      vok[i] = idx < D * 8;
-      vptr[i] = vbase + (long)row * p.ldvt + c * 8;
-      vlds[i] = row * VS + c * 8;
+  for (int n = 0; n < C::NI; ++n) {
+    const int i = wave + 4 * n;
+    if (i < C::KI) {
+      const int s = i * 64 + lane;
+      const int row = s / C::DCH, cs = s - row * C::DCH;
+      dma_off[n] = (unsigned)(row * p.ldk + (cs ^ k_swz<D>(row)) * 8) * 2u;
+    } else {
+      const int s = (i - C::KI) * 64 + lane;
+      const int row = s >> 3, cs = s & 7;
+      dma_off[n] = (unsigned)((long)row * p.ldvt + (cs ^ v_swz(row)) * 8) * 2u;
     }
   }
-  const long kstep = 64L * p.ldk;
-
-  auto load_regs = [&](int t) {
+  const char* const kbase = reinterpret_cast<const char*>(p.k + (long)bqk * p.N * p.ldk + h * D);
+  const char* const vbase = reinterpret_cast<const char*>(p.vt + (long)h * D * p.ldvt + (long)b * p.N);
+  const long kstep = 128L * p.ldk;   // bytes per 64-row KV tile
+  auto dma_tile = [&](int t, int stage) __attribute__((always_inline)) {
+    char* sb = smem + stage * C::STAGE;
 #pragma unroll
-    for (int i = 0; i < K_IT; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kok[i]) v = *reinterpret_cast<const uint4*>(kptr[i] + t * kstep);
-      kreg[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < V_IT; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (vok[i]) v = *reinterpret_cast<const uint4*>(vptr[i] + t * 64);
-      vreg[i] = v;
-    }
-  };
-  auto store_lds = [&]() {
-#pragma unroll
-    for (int i = 0; i < K_IT; ++i)
-      if (kok[i]) *reinterpret_cast<uint4*>(sK + klds[i]) = kreg[i];
-#pragma unroll
-    for (int i = 0; i < V_IT; ++i)
-      if (vok[i]) {
-        uint2* dst = reinterpret_cast<uint2*>(sV + vlds[i]);
-        dst[0] = make_uint2(vreg[i].x, vreg[i].y);
-        dst[1] = make_uint2(vreg[i].z, vreg[i].w);
+    for (int n = 0; n < C::NI; ++n) {
+      const int i = wave + 4 * n;
+      if (i < C::TI) {
+        const bool is_k = i < C::KI;
+        const char* src = (is_k ? kbase + t * kstep : vbase + t * 128) + dma_off[n];
+        char* dst = sb + (is_k ? i * 1024 : C::K_BYTES + (i - C::KI) * 1024);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
+    }
   };
 
-  f32x16 o[H::DT];
+  // ---- fragment addressing
+  // K-tile row read by lane ql for S^T row ql of a half tile (see header): kv_perm
+  const int kv_perm = 16 * (ql >> 4) + 8 * ((ql >> 2) & 1) + 4 * ((ql >> 3) & 1) + (ql & 3);
+  // byte offset (inside a stage) of the K fragment (sub, ks): the swizzle only touches the low
+  // bits of the chunk index, so NPAR per-lane bases + compile-time offsets cover every ks
+  constexpr int RS = C::DCH * 16;                       // K row stride
+  constexpr int NPAR = D == 64 ? 4 : 2;
+  int k_lane[NPAR];
 #pragma unroll
-  for (int t = 0; t < H::DT; ++t)
+  for (int par = 0; par < NPAR; ++par) {
+    const int c = par * 2 + hi;
+    k_lane[par] = kv_perm * RS + ((c ^ k_swz<D>(kv_perm)) * 16);
+  }
+  auto k_addr = [&](int sub, int ks) __attribute__((always_inline)) {
+    return k_lane[ks % NPAR] + (ks / NPAR) * (NPAR * 32) + sub * 32 * RS;
+  };
+  // V^T fragment (dt, half) of sub: row dt*32+ql, chunk sub*4 + half*2 + hi
+  int v_lane[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+      v_lane[sub][half] = C::K_BYTES + ql * 128 + (((sub * 4 + half * 2 + hi) ^ v_swz(ql)) * 16);
+  auto v_addr = [&](int sub, int dt, int half) __attribute__((always_inline)) {
+    return v_lane[sub][half] + dt * 4096;      // v_swz(dt*32 + ql) == v_swz(ql)
+  };
+
+  f32x16 o[NS][DT];
+  float m_run[NS], l_run[NS];
+#pragma unroll
+  for (int a = 0; a < NS; ++a) {
+    m_run[a] = -1e30f;
+    l_run[a] = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[a][t][r] = 0.f;
+  }
 
   const int ntiles = p.N / 64;
-  __syncthreads();          // zero-fill done
-  load_regs(0);
-  store_lds();
-  __syncthreads();
+  const int TU = ntiles * C::UT;
+  __syncthreads();          // zero / ones fill done
+  dma_tile(0, 0);
+  if (ntiles > 1) dma_tile(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
-  // Lazy rescale: the running maximum (log2 domain) is only raised -- and O, l rescaled -- when
-  // some row's tile maximum exceeds it by more than RESCALE_THR; until then probabilities are
-  // formed against the stale maximum and are bounded by 2^RESCALE_THR (bf16 has fp32's exponent
-  // range, fp32 accumulators: no precision is lost).  Saves an O-wide VALU pass on most tiles.
+  // Lazy rescale: the running maximum (log2 domain) of a stream is only raised -- and O, l
+  // rescaled -- when some row's block maximum exceeds it by more than RESCALE_THR; until then
+  // probabilities are formed against the stale maximum and are bounded by 2^RESCALE_THR (bf16 has
+  // fp32's exponent range, fp32 accumulators: no precision is lost).
   constexpr float RESCALE_THR = 10.0f;
 
-  for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) load_regs(t + 1);
+  // FOLD (head dims with pad columns in the QK^T contraction, i.e. d = 40): K gets a column of
+  // ones and Q the column -m_run, so the MFMA delivers S - m_run directly and the 16 subtractions
+  // per unit disappear.  m_run is kept bf16-representable so the shift is exact, and softmax is
+  // invariant to WHICH shift a row uses as long as numerator and denominator share it.
+  constexpr bool FOLD = H::DP > D;
+  constexpr int KS_P = FOLD ? D / 16 : 0, HI_P = (D % 16) / 8;   // fragment / lane half holding column D
+  static_assert(D % 8 == 0, "head dim must be a multiple of 8");
+
+  f32x16 S[4];
+  bf16x8 kf[DK], vf[DT][2], pfa[2], pfb[2];
+  float mx_next;          // row max of the unit whose softmax comes next
+  pfa[0] = pfa[1] = pfb[0] = pfb[1] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      f32x16 s;
+  for (int dt = 0; dt < DT; ++dt) vf[dt][0] = vf[dt][1] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  if (FOLD) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < H::DK; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (sub * 32 + ql) * H::KS + ks * 16 + hi * 8);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-      }
-      float mx = s[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      if (!__all(mx - m_run <= RESCALE_THR)) {
-        // every P.V accumulated so far is complete at this point, so O and l are the only state
-        // still expressed against the old maximum
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = fast_exp2(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < H::DT; ++dt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-      }
-      float pr[16];
-      float ls = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { pr[r] = fast_exp2(s[r] - m_run); ls += pr[r]; }
-      l_run += ls;
-      const bf16x8 pf0 = pack_p8(pr), pf1 = pack_p8(pr + 8);
-#pragma unroll
-      for (int dt = 0; dt < H::DT; ++dt) {
-        const bf16x8 v0 = read_perm_frag(sV, dt * 32 + ql, VS, sub * 32 + 4 * hi);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf0, o[dt], 0, 0, 0);
-        const bf16x8 v1 = read_perm_frag(sV, dt * 32 + ql, VS, sub * 32 + 16 + 4 * hi);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf1, o[dt], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    if (t + 1 < ntiles) store_lds();
-    __syncthreads();
+    for (int a = 0; a < NS; ++a) m_run[a] = 0.f;         // Q's pad column is 0: S - 0
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  if (q_ok) {
-    bf16_t* op = p.out + ((long)b * p.N + q_row) * p.ldo + h * D;
+  // unit U -> (tile, sub, stream a, query group g)
+  auto unit_tile = [&](int U) __attribute__((always_inline)) { return QG == 2 ? (U >> 2) : (U >> 1); };
+  auto stage_of = [&](int U) __attribute__((always_inline)) { return smem + (unit_tile(U) % 3) * C::STAGE; };
+
+  auto read_kf = [&](const char* st, int sub) __attribute__((always_inline)) {
 #pragma unroll
-    for (int dt = 0; dt < H::DT; ++dt)
+    for (int ks = 0; ks < DK; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(st + k_addr(sub, ks));
+  };
+  // FOLD: column D of K := 1 (the lanes of half HI_P read the next row's data there).  Applied
+  // right before the fragment's first use so the LDS latency of read_kf stays covered.
+  auto fix_kf = [&]() __attribute__((always_inline)) {
+    union { u32x4 u; bf16x8 v; } x;
+    x.v = kf[KS_P];
+    const bool padl = hi == HI_P;
+    x.u[0] = padl ? 0x00003F80u : x.u[0];
+    x.u[1] = padl ? 0u : x.u[1];
+    x.u[2] = padl ? 0u : x.u[2];
+    x.u[3] = padl ? 0u : x.u[3];
+    kf[KS_P] = x.v;
+  };
+  auto set_q_shift = [&](int g, float m) __attribute__((always_inline)) {   // Q[:, D] := -m (bf16-exact)
+    union { u32x4 u; bf16x8 v; } x;
+    x.v = qf[g][KS_P];
+    const uint32_t bits = (__float_as_uint(-m) >> 16);
+    x.u[0] = (hi == HI_P) ? bits : x.u[0];
+    qf[g][KS_P] = x.v;
+  };
+  auto read_vf = [&](const char* st, int sub) __attribute__((always_inline)) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = dt * 32 + 8 * g + 4 * hi;
-        if (d0 < D) {
-          uint2 w;
-          w.x = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
-          w.y = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
-          *reinterpret_cast<uint2*>(op + d0) = w;
-        }
-      }
+    for (int dt = 0; dt < DT; ++dt) {
+      vf[dt][0] = *reinterpret_cast<const bf16x8*>(st + v_addr(sub, dt, 0));
+      vf[dt][1] = *reinterpret_cast<const bf16x8*>(st + v_addr(sub, dt, 1));
+    }
+  };
+  auto do_qk = [&](f32x16& s, int g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < DK; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[g][ks], s, 0, 0, 0);
+  };
+  // running max over 4 more values of a score block (v_max3 x2; a plain fmaxf chain picks up
+  // canonicalising v_max x,x pairs on the MFMA results)
+  auto max4 = [&](float& m, const f32x16& sn, int c) __attribute__((always_inline)) {
+    m = fmaxf(fmaxf(fmaxf(fmaxf(m, sn[4 * c + 0]), sn[4 * c + 1]), sn[4 * c + 2]), sn[4 * c + 3]);   // 2 x v_max3
+    asm volatile("" : "+v"(m));     // pins the two v_max3 between the surrounding MFMAs
+  };
+  auto max_halves = [&](float mxa, float mxb) __attribute__((always_inline)) {
+    float mx;
+    mx = fmaxf(mxa, mxb);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  };
+
+  // prologue: scores of units 0 and 1, max of unit 0
+  {
+    read_kf(smem, 0);
+    if (FOLD) fix_kf();
+    do_qk(S[0], 0);
+    if (QG == 1) { read_kf(smem, 1); if (FOLD) fix_kf(); }
+    do_qk(S[1], QG == 2 ? 1 : 0);
+    float mxa = -1e30f, mxb = -1e30f;
+    max4(mxa, S[0], 0); max4(mxa, S[0], 1); max4(mxb, S[0], 2); max4(mxb, S[0], 3);
+    mx_next = max_halves(mxa, mxb);
   }
+
+  // one pipelined block; J = U mod 4 is compile-time
+  auto block = [&](auto jc, auto guard, int U) __attribute__((always_inline)) {
+    constexpr int J = decltype(jc)::value;
+    constexpr bool GUARD = decltype(guard)::value;        // tail iteration: units U+1, U+2 may not exist
+    constexpr int JJ = QG == 2 ? J : (J & 1);             // index inside the tile
+    constexpr int SUB = QG == 2 ? (JJ >> 1) : JJ;
+    constexpr int A = NS == 2 ? (J & 1) : 0;              // stream of unit U
+    constexpr int AP = NS == 2 ? (A ^ 1) : 0;             // stream of unit U-1
+    constexpr int JN = (J + 2) & 3;                       // unit U+2
+    constexpr int SUBN = QG == 2 ? (JN >> 1) : (JN & 1);
+    constexpr int GN = QG == 2 ? (JN & 1) : 0;
+    bf16x8 (&pf_prev)[2] = (J & 1) ? pfa : pfb;           // P of unit U-1
+    bf16x8 (&pf_cur)[2] = (J & 1) ? pfb : pfa;
+    const char* st_cur = stage_of(U);
+
+    // An MFMA issued at raised priority keeps the matrix pipe fed while the VALU work written
+    // between the MFMAs (this wave's and the co-resident wave's) fills the 32-cycle gaps; s_setprio
+    // is also a scheduling boundary, so the interleaving below is what the hardware sees.
+    // (measured, tools/ubench/overlap.hip: [MFMA + 6 VALU] x2 on a 2-wave SIMD = 88 cycles flat,
+    // 70 with the MFMA at priority 1; the MFMAs alone are 65)
+    auto mfma_hi = [&](const bf16x8& x, const bf16x8& y, f32x16& acc) __attribute__((always_inline)) {
+      __builtin_amdgcn_s_setprio(1);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    constexpr int NPV = 2 * DT;
+    // with a single stream the P.V of unit U-1 (formed against the old maximum) has to be
+    // accumulated before the rescale for unit U
+    if (NS == 1) {
+#pragma unroll
+      for (int i = 0; i < NPV; ++i) mfma_hi(vf[i % DT][i / DT], pf_prev[i / DT], o[AP][i % DT]);
+    }
+    // 1. lazy rescale of stream A for unit U.  mx_next: FOLD ? max(S - m_run) : max(S)
+    {
+      const float over = FOLD ? mx_next : mx_next - m_run[A];
+      const bool first = FOLD && U < 2;                   // pins the shift to the first block's max
+      if (first || !__all(over <= RESCALE_THR)) {
+        float alpha;
+        if (FOLD) {
+          const float m_new = (float)(__bf16)(m_run[A] + fmaxf(over, first ? -1e30f : 0.f));
+          const float delta = m_new - m_run[A];
+          alpha = fast_exp2(-delta);
+          m_run[A] = m_new;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) S[J][r] -= delta;
+          set_q_shift(QG == 2 ? A : 0, m_new);
+        } else {
+          const float m_new = fmaxf(m_run[A], mx_next);
+          alpha = fast_exp2(m_run[A] - m_new);
+          m_run[A] = m_new;
+        }
+        l_run[A] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[A][dt][r] *= alpha;
+      }
+    }
+    const bool has2 = !GUARD || U + 2 < TU;
+    const bool has1 = !GUARD || U + 1 < TU;
+    // 2. K fragments of unit U+2 (shared by a pair of units when QG == 2)
+    if (has2 && (QG == 1 || (JN & 1) == 0)) read_kf(stage_of(U + 2), SUBN);
+
+    // 3. the block's MFMAs -- P.V of unit U-1 (other stream) and QK^T of unit U+2, merged so
+    // that no MFMA directly follows the one it depends on -- with the exp/pack work of unit U and
+    // the row max of unit U+1 cut into 8 chunks and spread over the gaps
+    union { uint32_t u[4]; bf16x8 v; } pk[2];
+    float ls = 0.f, mxa = -1e30f, mxb = -1e30f;
+    // piece i of 8: probabilities 2i, 2i+1 of unit U (2 exp + 1 pack) and, for odd i, 4 more
+    // values of the row max of unit U+1.  The empty volatile asm after each piece keeps it where
+    // it is written (the compiler would otherwise collect this pure work behind the last MFMA of
+    // the block).  NOTE: the VALU work itself must stay compiler-visible -- instructions inside
+    // inline asm get none of the software-managed MFMA hazard padding (XDL result read / source
+    // overwrite), which showed up as run-to-run differences when these pieces were asm.
+    auto valu_piece = [&](int i) __attribute__((always_inline)) {
+      const float e0 = fast_exp2(FOLD ? S[J][2 * i] : S[J][2 * i] - m_run[A]);
+      const float e1 = fast_exp2(FOLD ? S[J][2 * i + 1] : S[J][2 * i + 1] - m_run[A]);
+      uint32_t p0 = pack_bf16x2(e0, e1);
+      asm volatile("" : "+v"(p0));
+      if (!ONES) ls += e0 + e1;
+      pk[i >> 2].u[i & 3] = p0;
+      if ((i & 1) && has1) max4((i >> 1) < 2 ? mxa : mxb, S[(J + 1) & 3], i >> 1);
+    };
+    constexpr int NPVS = NS == 2 ? NPV : 0;                // P.V MFMAs still to issue here
+    constexpr int NM = NPVS + DK;
+    if (has2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[JN][r] = 0.f;
+    }
+#pragma unroll
+    for (int sl = 0; sl < NM; ++sl) {
+      const int qk_before = (sl * DK) / NM, qk_after = ((sl + 1) * DK) / NM;
+      if (qk_after > qk_before) {
+        if (has2) {
+          if (FOLD && qk_before == KS_P && (QG == 1 || (JN & 1) == 0)) fix_kf();
+          mfma_hi(kf[qk_before], qf[GN][qk_before], S[JN]);
+        }
+      } else {
+        const int i = sl - qk_before;                      // index among the P.V MFMAs
+        mfma_hi(vf[i % DT][i / DT], pf_prev[i / DT], o[AP][i % DT]);
+        // V^T fragments of unit U (kept for the pair when QG == 2) once the last P.V is issued
+        if (i == NPVS - 1 && (QG == 1 || (JJ & 1) == 0)) read_vf(st_cur, SUB);
+      }
+#pragma unroll
+      for (int c = (sl * 8) / NM; c < ((sl + 1) * 8) / NM; ++c) valu_piece(c);
+    }
+    if (NS == 1 && (QG == 1 || (JJ & 1) == 0)) read_vf(st_cur, SUB);
+    if (!ONES) l_run[A] += ls;
+    pf_cur[0] = pk[0].v;
+    pf_cur[1] = pk[1].v;
+    // keep the exp/pack work HERE: its only consumer is the P.V in the next block, and LLVM
+    // would otherwise sink it across the rescale branch right in front of those MFMAs
+    asm volatile("" : "+v"(pf_cur[0]), "+v"(pf_cur[1]));
+    if (has1) {
+      mx_next = max_halves(mxa, mxb);
+      asm volatile("" : "+v"(mx_next));
+    }
+  };
+
+  // tile hand-over before the block that first touches tile tn: everyone's DMA for it has landed,
+  // and nobody reads tile tn-2 any more -> its stage takes tile tn+1
+  auto hand_over = [&](int tn) __attribute__((always_inline)) {
+    if (tn < ntiles) {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tn + 1 < ntiles) dma_tile(tn + 1, (tn + 1) % 3);
+    }
+  };
+
+  using std::integral_constant;
+  using std::false_type;
+  using std::true_type;
+  int U = 0;
+  for (; U + 6 <= TU; U += 4) {      // every unit up to U+5 exists: no guards inside
+    if (QG == 1) hand_over((U >> 1) + 1);
+    block(integral_constant<int, 0>{}, false_type{}, U);
+    block(integral_constant<int, 1>{}, false_type{}, U + 1);
+    if (QG == 2) hand_over((U >> 2) + 1); else hand_over((U >> 1) + 2);
+    block(integral_constant<int, 2>{}, false_type{}, U + 2);
+    block(integral_constant<int, 3>{}, false_type{}, U + 3);
+  }
+  {                                  // tail: the last 2 or 4 units
+    if (QG == 1) hand_over((U >> 1) + 1);
+    block(integral_constant<int, 0>{}, true_type{}, U);
+    block(integral_constant<int, 1>{}, true_type{}, U + 1);
+    if (U + 2 < TU) {
+      if (QG == 2) hand_over((U >> 2) + 1); else hand_over((U >> 1) + 2);
+      block(integral_constant<int, 2>{}, true_type{}, U + 2);
+      block(integral_constant<int, 3>{}, true_type{}, U + 3);
+    }
+  }
+  // drain: P.V of the last unit (stream 1; TU is even)
+  {
+    bf16x8 (&pf_last)[2] = pfb;    // the last unit is odd: its block packed into pfb
+    constexpr int AL = NS - 1;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[AL][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][0], pf_last[0], o[AL][dt], 0, 0, 0);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[AL][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][1], pf_last[1], o[AL][dt], 0, 0, 0);
+  }
+
+  constexpr int dl = D - (DT - 1) * 32;            // pad row D inside the last tile (ONES)
+  constexpr int r1 = (dl & 3) + 4 * (dl >> 3);
+  constexpr int h1 = (dl >> 2) & 1;
+  auto denom = [&](int a) __attribute__((always_inline)) {
+    if (ONES) return __shfl(o[a][DT - 1][ONES ? r1 : 0], ql + 32 * h1, 64);
+    return l_run[a] + __shfl_xor(l_run[a], 32, 64);
+  };
+  auto write_out = [&](const f32x16 (&acc)[DT], float inv, int q_row) __attribute__((always_inline)) {
+    if (q_row < p.N) {
+      bf16_t* op = p.out + ((long)b * p.N + q_row) * p.ldo + h * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          const int d0 = dt * 32 + 8 * gg + 4 * hi;
+          if (d0 < D) {
+            uint2 w;
+            w.x = pack_bf16x2(acc[dt][gg * 4 + 0] * inv, acc[dt][gg * 4 + 1] * inv);
+            w.y = pack_bf16x2(acc[dt][gg * 4 + 2] * inv, acc[dt][gg * 4 + 3] * inv);
+            *reinterpret_cast<uint2*>(op + d0) = w;
+          }
+        }
+    }
+  };
+  if (QG == 2) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) write_out(o[g], 1.0f / denom(g), q_base + g * 32);
+  } else {
+    if (NS == 2) {   // merge the two KV-half streams
+      const float m = fmaxf(m_run[0], m_run[NS - 1]);
+      const float f0 = fast_exp2(m_run[0] - m), f1 = fast_exp2(m_run[NS - 1] - m);
+      if (!ONES) l_run[0] = l_run[0] * f0 + l_run[NS - 1] * f1;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[0][dt][r] = o[0][dt][r] * f0 + o[NS - 1][dt][r] * f1;
+    }
+    write_out(o[0], 1.0f / denom(0), q_base);
+  }
+}
+
+template <int D, int QG, int NS>
+int launch_self(const SelfAttnParams& p, hipStream_t st) {
+  using C = SelfCfg<D, QG>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_kernel<D, QG, NS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(p.N, 128 * QG), p.heads, p.B);
+  hipLaunchKernelGGL((self_attn_kernel<D, QG, NS>), grid, dim3(256), C::TOTAL, st, p);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
 }
 
 // ============================================================================ cross-attention
@@ -453,17 +752,16 @@ int launch_cross(const CrossAttnParams& p, hipStream_t st) {
 int self_attn_launch(const SelfAttnParams& p, hipStream_t st) {
   ARG_CHECK(p.N % 64 == 0, "self_attn: N must be a multiple of 64");
   ARG_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldvt % 8 == 0 && p.ldo % 4 == 0, "self_attn: strides");
-  dim3 grid(cdiv(p.N, 128), p.heads, p.B);
-#define SA(DV) case DV: hipLaunchKernelGGL((self_attn_kernel<DV>), grid, dim3(256), 0, st, p); break;
   switch (p.d) {
-    SA(32) SA(40) SA(64) SA(80) SA(160)
+    case 32: return launch_self<32, 2, 2>(p, st);
+    case 40: return launch_self<40, 2, 2>(p, st);
+    case 64: return launch_self<64, 2, 2>(p, st);
+    case 80: return launch_self<80, 1, 1>(p, st);
+    case 160: return launch_self<160, 1, 1>(p, st);
     default:
       hedit_set_error("self_attn: unsupported head dim " + std::to_string(p.d) + " (32,40,64,80,160)");
       return HEDIT_ERR_ARG;
   }
-#undef SA
-  LAUNCH_CHECK();
-  return HEDIT_OK;
 }
 
 int cross_attn_launch(const CrossAttnParams& p, hipStream_t st) {
