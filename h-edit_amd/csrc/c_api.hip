@@ -64,6 +64,29 @@ int hedit_k_gemm(const void* A, const void* W, const float* bias, const void* re
   return gemm_launch(p, s, reinterpret_cast<float*>(partial_ws), S(stream));
 }
 
+int hedit_k_pack_geglu(const float* w, const float* bias, void* w_packed_bf16, float* bias_packed, int inner, int K,
+                       void* stream) {
+  ARG_CHECK(w && w_packed_bf16, "pack_geglu args");
+  int rc = pack_geglu_rows_launch(w, reinterpret_cast<bf16_t*>(w_packed_bf16), nullptr, 2 * inner, K, S(stream));
+  if (rc != HEDIT_OK || !bias) return rc;
+  ARG_CHECK(bias_packed, "pack_geglu: bias_packed");
+  return pack_geglu_rows_launch(bias, nullptr, bias_packed, 2 * inner, 1, S(stream));
+}
+
+int hedit_k_gemm_geglu(const void* A, const void* w_packed, const float* bias_packed, void* C, int M, int inner, int K,
+                       int lda, int ldc, void* stream) {
+  ARG_CHECK(A && w_packed && C, "gemm_geglu args");
+  GemmParams p{};
+  p.A = reinterpret_cast<const bf16_t*>(A);
+  p.W = reinterpret_cast<const bf16_t*>(w_packed);
+  p.M = M; p.N = 2 * inner; p.K = K; p.lda = lda; p.mode = 0;
+  p.bias = bias_packed;
+  p.C = reinterpret_cast<bf16_t*>(C);
+  p.ldc = ldc;
+  p.geglu = 1;
+  return gemm_launch(p, 1, nullptr, S(stream));
+}
+
 size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C) { return groupnorm_ws_bytes(B, HW, C); }
 
 int hedit_k_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G,

@@ -391,8 +391,15 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
           }
           const int ol = wn * (ON / 2) + (j / 2) * 16 + fq * 4;      // output column inside the tile
           uint2 o;
+#ifdef GEGLU_SCALAR
           o.x = pack_bf16x2(v[0] * gelu_erf_fast(g[0]), v[1] * gelu_erf_fast(g[1]));
           o.y = pack_bf16x2(v[2] * gelu_erf_fast(g[2]), v[3] * gelu_erf_fast(g[3]));
+#else
+          const f32x2 r0 = mul_gelu2((f32x2){v[0], v[1]}, (f32x2){g[0], g[1]});
+          const f32x2 r1 = mul_gelu2((f32x2){v[2], v[3]}, (f32x2){g[2], g[3]});
+          o.x = pack_bf16x2(r0[0], r0[1]);
+          o.y = pack_bf16x2(r1[0], r1[1]);
+#endif
           *reinterpret_cast<uint2*>(sg + ml * CSG + ol) = o;
         }
       }

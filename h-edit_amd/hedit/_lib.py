@@ -61,6 +61,9 @@ _SIGS = {
     "hedit_k_gemm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "hedit_k_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 13 +
                      [C.c_void_p, C.c_void_p]),
+    "hedit_k_pack_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "hedit_k_gemm_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_void_p]),
     "hedit_k_groupnorm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "hedit_k_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),

@@ -141,6 +141,15 @@ size_t hedit_k_gemm_ws_bytes(int M, int N, int K, int splits);
 int hedit_k_gemm(const void* A, const void* W, const float* bias, const void* residual, void* C,
                  int M, int N, int K, int lda, int ldc, int ldr, int mode, int Hin, int Win,
                  int Cin, int Hout, int Wout, int splits, void* partial_ws, void* stream);
+/* FF1 of the transformer feed-forward with the GEGLU fused into the GEMM epilogue (diffusers
+ * GEGLU.forward: hidden, gate = proj(x).chunk(2, -1); out = hidden * gelu(gate)).
+ * hedit_k_pack_geglu interleaves the fp32 [2*inner][K] projection weight (and [2*inner] bias) of the
+ * checkpoint layout into the row order the kernel wants; hedit_k_gemm_geglu then computes
+ * C[M][inner] (bf16) from A[M][K] (bf16).  inner % 16 == 0, K % 8 == 0. */
+int hedit_k_pack_geglu(const float* w, const float* bias, void* w_packed_bf16, float* bias_packed,
+                       int inner, int K, void* stream);
+int hedit_k_gemm_geglu(const void* A, const void* w_packed, const float* bias_packed, void* C, int M,
+                       int inner, int K, int lda, int ldc, void* stream);
 size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C);
 int hedit_k_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW,
                       int C, int G, float eps, int silu, void* ws, void* stream);

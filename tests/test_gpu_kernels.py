@@ -111,6 +111,29 @@ def test_layernorm_geglu(lib, rows, Cc):
     assert G.rel_err(z.float(), h * F.gelu(gt)) < 5e-3
 
 
+@pytest.mark.parametrize("M,inner,K", [(256, 1280, 320), (1000, 160, 64), (128, 5120, 1280), (4096, 2560, 640)])
+def test_gemm_geglu_fused(lib, M, inner, K):
+    """FF1 + GEGLU in one kernel == gelu-gated product of the two halves of the plain projection
+    (diffusers GEGLU: hidden, gate = proj(x).chunk(2, -1); hidden * gelu(gate), exact erf GELU)."""
+    g = torch.Generator().manual_seed(M + inner)
+    x = G.bf(torch.randn(M, K, generator=g))
+    w = torch.randn(2 * inner, K, generator=g) / math.sqrt(K)
+    b = torch.randn(2 * inner, generator=g) * 0.5
+    wd, bd = G.f32(w), G.f32(b)
+    wp = torch.empty(2 * inner, K, dtype=torch.bfloat16, device=G.dev())
+    bp = torch.empty(2 * inner, dtype=torch.float32, device=G.dev())
+    _lib.check(lib.hedit_k_pack_geglu(_lib.ptr(wd), _lib.ptr(bd), _lib.ptr(wp), _lib.ptr(bp), inner, K, None))
+    out = torch.zeros(M, inner, dtype=torch.bfloat16, device=G.dev())
+    _lib.check(lib.hedit_k_gemm_geglu(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bp), _lib.ptr(out), M, inner, K, K, inner, None))
+    G.sync()
+    proj = x.float() @ wd.to(torch.bfloat16).float().t() + bd
+    h, gate = proj.chunk(2, dim=-1)
+    want = h * F.gelu(gate)
+    assert G.rel_err(out.float(), want) < 6e-3
+    # pointwise: within one bf16 ulp of the exactly computed value (plus the fp32 accumulation noise)
+    assert ((out.float() - want).abs() <= want.abs() * 2 ** -7 + 2e-3).all()
+
+
 def attn_ref(q, k, v, heads):
     """q (B,N,C) pre-scaled in log2 units, k (B,M,C), v (B,M,C) -> probs (B,h,N,M), out (B,N,C)"""
     B, N, Cc = q.shape

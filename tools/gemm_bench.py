@@ -37,6 +37,16 @@ def gemm(M, N, K, mode=0, conv=None, name=""):
     return us
 
 
+def gemm_geglu(M, inner, K, name):
+    A = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    W = (torch.randn(2 * inner, K, device=dev) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(2 * inner, device=dev)
+    out = torch.empty(M, inner, device=dev, dtype=torch.bfloat16)
+    f = lambda: _lib.check(lib.hedit_k_gemm_geglu(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out), M, inner, K, K, inner, None))
+    us = timeit(f)
+    print(f"{name:28s} M={M:7d} N={2 * inner:5d} K={K:6d} geglu  {us:9.1f} us  {4.0 * M * inner * K / us / 1e6:8.1f} TF/s")
+
+
 tot = 0
 for lvl, (hw, c) in enumerate([(64, 320), (32, 640), (16, 1280), (8, 1280)]):
     M = B * hw * hw
@@ -47,6 +57,8 @@ for lvl, (hw, c) in enumerate([(64, 320), (32, 640), (16, 1280), (8, 1280)]):
         tot += gemm(c, M, c, 0, None, f"L{lvl} v^T (swapped)")
         tot += gemm(M, 8 * c, c, 0, None, f"L{lvl} ff1 C->8C")
         tot += gemm(M, c, 4 * c, 0, None, f"L{lvl} ff2 4C->C")
+for lvl, (hw, c) in enumerate([(64, 320), (32, 640), (16, 1280)]):
+    gemm_geglu(B * hw * hw, 4 * c, c, f"L{lvl} ff1+geglu fused")
 gemm(B * 64 * 64, 320, 9 * 960, 1, (64, 64, 960, 64, 64, B * 64 * 64), "up3 conv 960->320")
 gemm(B * 16 * 16, 1280, 9 * 2560, 1, (16, 16, 2560, 16, 16, B * 256), "up1 conv 2560->1280")
 
