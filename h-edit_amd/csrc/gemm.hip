@@ -131,7 +131,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
         a_oy[i] = oy & 1;
         a_ox[i] = ox & 1;
       } else {
-        const int cy = MODE == 2 ? oy * 2 : oy, cx = MODE == 2 ? ox * 2 : ox;
+        const int cy = MODE == 2 ? oy * 2 + p.asym : oy, cx = MODE == 2 ? ox * 2 + p.asym : ox;
         unsigned mk = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -628,7 +628,12 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
   p.kt_per_split = cdiv(kt, splits);
   p.splits = cdiv(kt, p.kt_per_split);
   splits = p.splits;
-  if (splits > 1) {
+  if (p.raw_f32) {
+    ARG_CHECK(!p.geglu, "gemm: raw fp32 output excludes the GEGLU epilogue");
+    p.splits = splits = 1;
+    p.kt_per_split = kt;
+    p.partial = p.raw_f32;      // the split-K slab path with one split IS the fp32 product
+  } else if (splits > 1) {
     ARG_CHECK(partial_ws != nullptr, "gemm: split-K needs a partial workspace");
     p.partial = partial_ws;
   } else {

@@ -20,6 +20,9 @@ struct GemmParams {
   int n_fastest;     // tile order, set by gemm_launch
   const bf16_t* zeros;   // 16-byte-aligned zero page (>= 16 B), set by gemm_launch
   int geglu;             // FF1: rows interleaved (value16|gate16), output [M][N/2] = v * gelu(g)
+  int asym;              // mode 2 only: 1 = pad (0,1,0,1) instead of 1 all round (the VAE encoder's
+                         // Downsample2D(padding=0): taps at rows 2oy .. 2oy+2)
+  float* raw_f32;        // if set: write the plain fp32 products [M][N] here (no bias / residual / bf16 C)
 };
 int gemm_prepare();   // allocates the zero page (call once outside any timed / captured region)
 int gemm_pick_bn(int N);
@@ -52,6 +55,12 @@ int conv_in_launch(const float* x, const float* w, const float* bias, bf16_t* y,
 // conv_out: x NHWC bf16 [B][H][W][C], w bf16 [Cout<=4][9][C] -> y fp32 NCHW [B][Cout][H][W]
 int conv_out_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* y, int B, int H,
                     int W, int C, int Cout, hipStream_t st);
+// VAE helpers: row softmax of fp32 scores (p = softmax(scale * s), bf16), 1x1 channel mixing of a
+// small fp32 NCHW tensor (x scaled by pre_scale first), encoder tail (first Cout channels of quant_conv)
+int softmax_rows_launch(const float* s, bf16_t* p, long rows, int N, float scale, hipStream_t st);
+int mix1x1_nchw_launch(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, long HW,
+                       float pre_scale, hipStream_t st);
+int quant_mean_launch(const bf16_t* h, const float* w, const float* bias, float* y, int B, long HW, int Cm, int Cout, hipStream_t st);
 // weight packing (fp32 source tensors in torch layouts -> bf16 GEMM layouts), optional scale
 int pack_linear_launch(const float* w, bf16_t* out, long n, float scale, hipStream_t st);
 int pack_conv3x3_launch(const float* w_oihw, bf16_t* out, int O, int I, hipStream_t st);

@@ -502,7 +502,14 @@ int conv_in_launch(const float* x, const float* w, const float* bias, bf16_t* y,
                    int Cout, hipStream_t st) {
   ARG_CHECK(Cout % 8 == 0, "conv_in: Cout % 8");
   const size_t lds = ((size_t)Cin * 9 * Cout + 64 * (size_t)Cin * 9) * sizeof(float);
-  ARG_CHECK(lds <= 64 * 1024, "conv_in: Cin*9*(Cout+64) floats must fit 64 KiB of LDS");
+  ARG_CHECK(lds <= 160 * 1024, "conv_in: Cin*9*(Cout+64) floats must fit 160 KiB of LDS");
+  if (lds > 64 * 1024) {
+    static size_t attr_set = 0;
+    if (lds > attr_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_in_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = lds;
+    }
+  }
   hipLaunchKernelGGL(conv_in_kernel, dim3(cdiv((long)B * H * W, 64)), dim3(256), lds, st, x, w, bias, y, B, Cin, H, W, Cout);
   LAUNCH_CHECK();
   return HEDIT_OK;
@@ -512,6 +519,90 @@ int conv_out_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* 
                     int Cout, hipStream_t st) {
   ARG_CHECK(C % 8 == 0 && Cout <= 4, "conv_out: C % 8, Cout <= 4");
   hipLaunchKernelGGL(conv_out_kernel, dim3(cdiv((long)B * H * W, 4)), dim3(256), 0, st, x, w, bias, y, B, H, W, C, Cout);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+// ------------------------------------------------------------------ VAE helpers
+// softmax over the rows of an fp32 score matrix, bf16 probabilities out: one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p, long rows, int N, float scale_log2e) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* sr = s + row * N;
+  float mx = -3.0e38f;
+  for (int i = lane * 4; i < N; i += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(sr + i);
+    mx = fmaxf(fmaxf(fmaxf(mx, v[0]), fmaxf(v[1], v[2])), v[3]);
+  }
+  mx = wave_max(mx) * scale_log2e;
+  float sum = 0.f;
+  for (int i = lane * 4; i < N; i += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(sr + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += __builtin_amdgcn_exp2f(v[j] * scale_log2e - mx);
+  }
+  const float inv = 1.0f / wave_sum(sum);
+  bf16_t* pr = p + row * N;
+  for (int i = lane * 4; i < N; i += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(sr + i);
+    uint2 o;
+    o.x = pack_bf16x2(__builtin_amdgcn_exp2f(v[0] * scale_log2e - mx) * inv, __builtin_amdgcn_exp2f(v[1] * scale_log2e - mx) * inv);
+    o.y = pack_bf16x2(__builtin_amdgcn_exp2f(v[2] * scale_log2e - mx) * inv, __builtin_amdgcn_exp2f(v[3] * scale_log2e - mx) * inv);
+    *reinterpret_cast<uint2*>(pr + i) = o;
+  }
+}
+
+int softmax_rows_launch(const float* s, bf16_t* p, long rows, int N, float scale, hipStream_t st) {
+  ARG_CHECK(N % 4 == 0, "softmax_rows: N % 4");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s, p, rows, N, scale * 1.4426950408889634f);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+// per-pixel channel mixing of a small fp32 NCHW tensor: y[b][co] = sum_ci w[co][ci] x[b][ci] + bias[co]  (1x1 conv, C <= 8)
+__global__ __launch_bounds__(256) void mix1x1_nchw_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int B, int Cin, int Cout, long HW, float pre_scale) {
+  const long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / HW, px = i - b * HW;
+    float xv[8];
+    for (int ci = 0; ci < Cin; ++ci) xv[ci] = x[(b * Cin + ci) * HW + px] * pre_scale;
+    for (int co = 0; co < Cout; ++co) {
+      float a = bias ? bias[co] : 0.f;
+      for (int ci = 0; ci < Cin; ++ci) a += w[co * Cin + ci] * xv[ci];
+      y[(b * Cout + co) * HW + px] = a;
+    }
+  }
+}
+
+int mix1x1_nchw_launch(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, long HW,
+                       float pre_scale, hipStream_t st) {
+  ARG_CHECK(Cin <= 8 && Cout <= 8, "mix1x1: at most 8 channels");
+  hipLaunchKernelGGL(mix1x1_nchw_kernel, dim3(ew_grid((long)B * HW)), dim3(256), 0, st, x, w, bias, y, B, Cin, Cout, HW, pre_scale);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+// encoder tail: moments h [M][Cm] (bf16 NHWC) -> first Cout channels of quant_conv(h), fp32 NCHW
+__global__ __launch_bounds__(256) void quant_mean_kernel(const bf16_t* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ y, int B, long HW, int Cm, int Cout) {
+  const long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / HW, px = i - b * HW;
+    float hv[16];
+    for (int c = 0; c < Cm; ++c) hv[c] = bf16_to_f32(h[i * Cm + c]);
+    for (int co = 0; co < Cout; ++co) {
+      float a = bias[co];
+      for (int c = 0; c < Cm; ++c) a += w[co * Cm + c] * hv[c];
+      y[(b * Cout + co) * HW + px] = a;
+    }
+  }
+}
+
+int quant_mean_launch(const bf16_t* h, const float* w, const float* bias, float* y, int B, long HW, int Cm, int Cout, hipStream_t st) {
+  ARG_CHECK(Cm <= 16 && Cout <= Cm, "quant_mean: channels");
+  hipLaunchKernelGGL(quant_mean_kernel, dim3(ew_grid((long)B * HW)), dim3(256), 0, st, h, w, bias, y, B, HW, Cm, Cout);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }

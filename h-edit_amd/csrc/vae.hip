@@ -1,0 +1,585 @@
+// The SD-1.x image autoencoder (diffusers AutoencoderKL) as a native executor on the kernels of
+// gemm.hip / norm.hip: the steps either side of the editing loop -- `vae.encode(img).latent_dist
+// .mode()` before the inversion (reference text-guided/main_p2p.py:159) and `vae.decode(latents)`
+// after it (main_p2p.py:263).  Same conventions as unet.hip:
+// parameters are loaded by their diffusers state_dict names, activations are NHWC bf16 in a
+// caller-provided workspace, one C call per pass.
+//
+// Architecture (diffusers 0.18 `AutoencoderKL`, `Encoder` / `Decoder`, `UNetMidBlock2D` with one
+// single-head `Attention`, `DownEncoderBlock2D` / `UpDecoderBlock2D`, resnet eps 1e-6, no time
+// embedding).  The encoder's Downsample2D(padding=0) pads (0,1,0,1) -> GemmParams.asym.
+//
+// Mid-block attention (one head of C = 512 channels over h*w tokens) does not fit the flash
+// kernel's head sizes; it runs once per image per pass, so it is done with the GEMM kernel:
+// fp32 scores S = Q K^T, a row-softmax pass, O = P V with V^T from a swapped-operand GEMM.  Two
+// exact simplifications: the key bias adds a per-row constant to S (softmax-invariant) and is
+// dropped; the value bias passes through P (rows sum to 1) and is folded into the output bias.
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hedit.h"
+#include "common.h"
+#include "exec.h"
+#include "kernels.h"
+
+#define TRY(expr)                        \
+  do {                                   \
+    int _rc = (expr);                    \
+    if (_rc != HEDIT_OK) return _rc;     \
+  } while (0)
+
+namespace {
+
+struct VSlot {
+  std::string name;
+  int kind;        // 0 fp32 copy, 1 linear / 1x1 -> bf16, 2 conv3x3 OIHW -> bf16 [O][9][I]
+  void* dst;
+  size_t numel;
+  int O, I;
+  bool loaded;
+  int ndim;
+  int dims[4];
+};
+
+struct VRes {
+  int cin, cout;
+  float *n1g, *n1b, *n2g, *n2b, *c1b, *c2b, *sc_b;
+  bf16_t *conv1, *conv2, *sc_w;
+};
+
+struct VAttn {
+  int C;
+  float *gn_g, *gn_b, *q_b, *k_b, *v_b, *o_b;
+  bf16_t *w_q, *w_k, *w_v, *w_o;
+};
+
+struct VMid {
+  VRes r0, r1;
+  VAttn at;
+};
+
+struct VStage {
+  std::vector<VRes> res;
+  bf16_t* samp_w = nullptr;   // down: stride-2 conv; up: conv after the 2x nearest upsample
+  float* samp_b = nullptr;
+  int ch = 0;
+};
+
+}  // namespace
+
+struct hedit_vae {
+  hedit_vae_cfg cfg;
+  bool alloc_failed = false;
+  std::vector<void*> owned;
+  std::vector<VSlot> slots;
+  std::map<std::string, int> index;
+  // encoder
+  float *e_in_w = nullptr, *e_in_b = nullptr, *e_gn_g = nullptr, *e_gn_b = nullptr, *e_out_b = nullptr;
+  bf16_t* e_out_w = nullptr;
+  std::vector<VStage> down;
+  VMid e_mid;
+  float *quant_w = nullptr, *quant_b = nullptr;
+  // decoder
+  float *pq_w = nullptr, *pq_b = nullptr, *d_in_w = nullptr, *d_in_b = nullptr, *d_gn_g = nullptr, *d_gn_b = nullptr,
+        *d_out_b = nullptr;
+  bf16_t* d_out_w = nullptr;
+  std::vector<VStage> up;
+  VMid d_mid;
+};
+
+namespace {
+
+template <class T>
+T* dalloc(hedit_vae* h, size_t n) {
+  void* p = nullptr;
+  if (hipMalloc(&p, n * sizeof(T) > 0 ? n * sizeof(T) : 16) != hipSuccess) {
+    h->alloc_failed = true;
+    return nullptr;
+  }
+  h->owned.push_back(p);
+  return reinterpret_cast<T*>(p);
+}
+
+void add_slot(hedit_vae* h, const std::string& name, int kind, void* dst, size_t numel, int O, int I, int ndim,
+              int d0, int d1, int d2, int d3) {
+  VSlot s{name, kind, dst, numel, O, I, false, ndim, {d0, d1, d2, d3}};
+  h->index[name] = (int)h->slots.size();
+  h->slots.push_back(s);
+}
+float* vec(hedit_vae* h, const std::string& name, int n) {
+  float* d = dalloc<float>(h, n);
+  add_slot(h, name, 0, d, n, 0, 0, 1, n, 1, 1, 1);
+  return d;
+}
+float* f32conv(hedit_vae* h, const std::string& name, int O, int I, int k) {   // kept fp32, torch layout
+  float* d = dalloc<float>(h, (size_t)O * I * k * k);
+  add_slot(h, name, 0, d, (size_t)O * I * k * k, O, I, 4, O, I, k, k);
+  return d;
+}
+bf16_t* lin(hedit_vae* h, const std::string& name, int O, int I, bool conv1x1 = false) {
+  bf16_t* d = dalloc<bf16_t>(h, (size_t)O * I);
+  add_slot(h, name, 1, d, (size_t)O * I, O, I, conv1x1 ? 4 : 2, O, I, 1, 1);
+  return d;
+}
+bf16_t* conv3(hedit_vae* h, const std::string& name, int O, int I) {
+  bf16_t* d = dalloc<bf16_t>(h, (size_t)O * I * 9);
+  add_slot(h, name, 2, d, (size_t)O * I * 9, O, I, 4, O, I, 3, 3);
+  return d;
+}
+
+VRes make_res(hedit_vae* h, const std::string& pre, int cin, int cout) {
+  VRes r{};
+  r.cin = cin; r.cout = cout;
+  r.n1g = vec(h, pre + ".norm1.weight", cin);
+  r.n1b = vec(h, pre + ".norm1.bias", cin);
+  r.conv1 = conv3(h, pre + ".conv1.weight", cout, cin);
+  r.c1b = vec(h, pre + ".conv1.bias", cout);
+  r.n2g = vec(h, pre + ".norm2.weight", cout);
+  r.n2b = vec(h, pre + ".norm2.bias", cout);
+  r.conv2 = conv3(h, pre + ".conv2.weight", cout, cout);
+  r.c2b = vec(h, pre + ".conv2.bias", cout);
+  if (cin != cout) {
+    r.sc_w = lin(h, pre + ".conv_shortcut.weight", cout, cin, true);
+    r.sc_b = vec(h, pre + ".conv_shortcut.bias", cout);
+  }
+  return r;
+}
+
+VAttn make_attn(hedit_vae* h, const std::string& pre, int C) {
+  VAttn a{};
+  a.C = C;
+  a.gn_g = vec(h, pre + ".group_norm.weight", C);
+  a.gn_b = vec(h, pre + ".group_norm.bias", C);
+  a.w_q = lin(h, pre + ".to_q.weight", C, C);
+  a.q_b = vec(h, pre + ".to_q.bias", C);
+  a.w_k = lin(h, pre + ".to_k.weight", C, C);
+  a.k_b = vec(h, pre + ".to_k.bias", C);      // loaded for completeness; softmax-invariant (see header)
+  a.w_v = lin(h, pre + ".to_v.weight", C, C);
+  a.v_b = vec(h, pre + ".to_v.bias", C);
+  a.w_o = lin(h, pre + ".to_out.0.weight", C, C);
+  a.o_b = vec(h, pre + ".to_out.0.bias", C);
+  return a;
+}
+
+VMid make_mid(hedit_vae* h, const std::string& pre, int C) {
+  VMid m;
+  m.r0 = make_res(h, pre + ".resnets.0", C, C);
+  m.at = make_attn(h, pre + ".attentions.0", C);
+  m.r1 = make_res(h, pre + ".resnets.1", C, C);
+  return m;
+}
+
+// ------------------------------------------------------------------------------ forward
+struct VF {
+  hedit_vae* h;
+  int B;
+  hipStream_t st;
+  Arena ar;
+  bool dry() const { return ar.dry; }
+};
+
+#define RUN(f, expr)            \
+  do {                          \
+    if (!(f).dry()) TRY(expr);  \
+  } while (0)
+
+template <class T>
+int aalloc(VF& f, T** out, size_t n) {
+  *out = reinterpret_cast<T*>(f.ar.alloc(n * sizeof(T)));
+  if (!*out) {
+    hedit_set_error("VAE workspace too small (need more than " + std::to_string(f.ar.cap) + " bytes)");
+    return HEDIT_ERR_ARG;
+  }
+  return HEDIT_OK;
+}
+
+int run_gemm(VF& f, GemmParams p) {
+  const int splits = p.raw_f32 ? 1 : gemm_pick_splits(p.M, p.N, p.K, 0);
+  float* part = nullptr;
+  if (splits > 1) TRY(aalloc(f, &part, (size_t)splits * p.M * p.N));
+  RUN(f, gemm_launch(p, splits, part, f.st));
+  if (part) f.ar.free(part);
+  return HEDIT_OK;
+}
+
+int linear(VF& f, const bf16_t* A, int M, int K, const bf16_t* W, int N, const float* bias, const bf16_t* residual,
+           bf16_t* C, int ldc) {
+  GemmParams p{};
+  p.A = A; p.W = W; p.M = M; p.N = N; p.K = K; p.lda = K; p.mode = 0;
+  p.bias = bias; p.residual = residual; p.ldr = N; p.C = C; p.ldc = ldc;
+  return run_gemm(f, p);
+}
+
+// mode 1: stride 1; 2: stride 2 with pad (0,1,0,1); 3: on the 2x nearest-upsampled input
+int conv3x3(VF& f, const bf16_t* X, int Hin, int Win, int Cin, const bf16_t* W, int Cout, const float* bias,
+            const bf16_t* residual, bf16_t* Y, int mode) {
+  GemmParams p{};
+  p.mode = mode;
+  p.asym = mode == 2 ? 1 : 0;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin;
+  p.Hout = mode == 2 ? Hin / 2 : (mode == 3 ? Hin * 2 : Hin);
+  p.Wout = mode == 2 ? Win / 2 : (mode == 3 ? Win * 2 : Win);
+  p.A = X; p.W = W; p.M = f.B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin; p.lda = Cin;
+  p.bias = bias; p.residual = residual; p.ldr = Cout; p.C = Y; p.ldc = Cout;
+  return run_gemm(f, p);
+}
+
+int groupnorm(VF& f, const bf16_t* x, bf16_t* y, const float* g, const float* b, int HW, int C, int silu) {
+  float* ws;
+  TRY(aalloc(f, &ws, groupnorm_ws_bytes(f.B, HW, C) / sizeof(float)));
+  RUN(f, groupnorm_launch(x, y, g, b, f.B, HW, C, f.h->cfg.norm_num_groups, 1e-6f, silu, ws, f.st));
+  f.ar.free(ws);
+  return HEDIT_OK;
+}
+
+// x [M][cin] -> *out [M][cout] (allocated here; x is NOT freed)
+int resblock(VF& f, const VRes& r, const bf16_t* x, int H, int W, bf16_t** out) {
+  const size_t M = (size_t)f.B * H * W;
+  bf16_t *a1, *h1, *a2, *sc = nullptr, *y;
+  TRY(aalloc(f, &a1, M * r.cin));
+  TRY(groupnorm(f, x, a1, r.n1g, r.n1b, H * W, r.cin, 1));
+  TRY(aalloc(f, &h1, M * r.cout));
+  TRY(conv3x3(f, a1, H, W, r.cin, r.conv1, r.cout, r.c1b, nullptr, h1, 1));
+  f.ar.free(a1);
+  TRY(aalloc(f, &a2, M * r.cout));
+  TRY(groupnorm(f, h1, a2, r.n2g, r.n2b, H * W, r.cout, 1));
+  f.ar.free(h1);
+  const bf16_t* res = x;
+  if (r.sc_w) {
+    TRY(aalloc(f, &sc, M * r.cout));
+    TRY(linear(f, x, (int)M, r.cin, r.sc_w, r.cout, r.sc_b, nullptr, sc, r.cout));
+    res = sc;
+  }
+  TRY(aalloc(f, &y, M * r.cout));
+  TRY(conv3x3(f, a2, H, W, r.cout, r.conv2, r.cout, r.c2b, res, y, 1));
+  f.ar.free(a2);
+  if (sc) f.ar.free(sc);
+  *out = y;
+  return HEDIT_OK;
+}
+
+// single-head attention over the T = H*W tokens of every image; x [B*T][C] -> *out (x is NOT freed)
+int attention(VF& f, const VAttn& a, const bf16_t* x, int H, int W, bf16_t** out) {
+  const int C = a.C, T = H * W, B = f.B;
+  const size_t M = (size_t)B * T;
+  bf16_t *xn, *q, *k, *vt, *pb, *o, *y;
+  float *s, *ob;
+  TRY(aalloc(f, &xn, M * C));
+  TRY(groupnorm(f, x, xn, a.gn_g, a.gn_b, T, C, 0));
+  TRY(aalloc(f, &q, M * C));
+  TRY(linear(f, xn, (int)M, C, a.w_q, C, a.q_b, nullptr, q, C));
+  TRY(aalloc(f, &k, M * C));
+  TRY(linear(f, xn, (int)M, C, a.w_k, C, nullptr, nullptr, k, C));
+  TRY(aalloc(f, &o, M * C));
+  TRY(aalloc(f, &vt, (size_t)C * T));
+  TRY(aalloc(f, &s, (size_t)T * T));
+  TRY(aalloc(f, &pb, (size_t)T * T));
+  for (int b = 0; b < B; ++b) {
+    const bf16_t* xb = xn + (size_t)b * T * C;
+    {   // V^T [C][T] = W_v . xn_b^T
+      GemmParams p{};
+      p.A = a.w_v; p.W = xb; p.M = C; p.N = T; p.K = C; p.lda = C; p.C = vt; p.ldc = T;
+      TRY(run_gemm(f, p));
+    }
+    {   // S [T][T] = q_b . k_b^T in fp32
+      GemmParams p{};
+      p.A = q + (size_t)b * T * C; p.W = k + (size_t)b * T * C; p.M = T; p.N = T; p.K = C; p.lda = C;
+      p.raw_f32 = s; p.ldc = T;
+      TRY(run_gemm(f, p));
+    }
+    RUN(f, softmax_rows_launch(s, pb, T, T, 1.0f / sqrtf((float)C), f.st));
+    {   // O_b [T][C] = P . V
+      GemmParams p{};
+      p.A = pb; p.W = vt; p.M = T; p.N = C; p.K = T; p.lda = T; p.C = o + (size_t)b * T * C; p.ldc = C;
+      TRY(run_gemm(f, p));
+    }
+  }
+  f.ar.free(pb); f.ar.free(s); f.ar.free(vt); f.ar.free(k); f.ar.free(q); f.ar.free(xn);
+  // output bias with the value bias folded in: o_b' = o_b + W_o . v_b
+  TRY(aalloc(f, &ob, (size_t)C));
+  RUN(f, gemv_launch(a.w_o, a.v_b, a.o_b, nullptr, ob, C, C, 0, f.st));
+  TRY(aalloc(f, &y, M * C));
+  TRY(linear(f, o, (int)M, C, a.w_o, C, ob, x, y, C));
+  f.ar.free(ob); f.ar.free(o);
+  *out = y;
+  return HEDIT_OK;
+}
+
+int mid(VF& f, const VMid& m, bf16_t** x, int H, int W) {
+  bf16_t *a, *b, *c;
+  TRY(resblock(f, m.r0, *x, H, W, &a));
+  f.ar.free(*x);
+  TRY(attention(f, m.at, a, H, W, &b));
+  f.ar.free(a);
+  TRY(resblock(f, m.r1, b, H, W, &c));
+  f.ar.free(b);
+  *x = c;
+  return HEDIT_OK;
+}
+
+int decode_impl(hedit_vae* h, const float* z, int B, int lh, int lw, float* image, void* ws, size_t ws_bytes,
+                hipStream_t st, bool dry, size_t* peak) {
+  VF f{h, B, st, Arena{}};
+  f.ar.dry = dry;
+  f.ar.base = reinterpret_cast<char*>(ws);
+  f.ar.cap = ws_bytes;
+  const hedit_vae_cfg& c = h->cfg;
+  const int L = c.n_levels, LC = c.latent_channels;
+  int H = lh, W = lw;
+  int ch = c.block_out_channels[L - 1];
+  float* z2;
+  TRY(aalloc(f, &z2, (size_t)B * LC * H * W));
+  RUN(f, mix1x1_nchw_launch(z, h->pq_w, h->pq_b, z2, B, LC, LC, (long)H * W, 1.0f, st));
+  bf16_t* x;
+  TRY(aalloc(f, &x, (size_t)B * H * W * ch));
+  RUN(f, conv_in_launch(z2, h->d_in_w, h->d_in_b, x, B, LC, H, W, ch, st));
+  f.ar.free(z2);
+  TRY(mid(f, h->d_mid, &x, H, W));
+  for (int i = 0; i < L; ++i) {
+    const VStage& s = h->up[i];
+    for (const VRes& r : s.res) {
+      bf16_t* y;
+      TRY(resblock(f, r, x, H, W, &y));
+      f.ar.free(x);
+      x = y;
+    }
+    if (s.samp_w) {
+      bf16_t* y;
+      TRY(aalloc(f, &y, (size_t)B * H * W * 4 * s.ch));
+      TRY(conv3x3(f, x, H, W, s.ch, s.samp_w, s.ch, s.samp_b, nullptr, y, 3));
+      f.ar.free(x);
+      x = y;
+      H *= 2; W *= 2;
+    }
+    ch = s.ch;
+  }
+  bf16_t* xn;
+  TRY(aalloc(f, &xn, (size_t)B * H * W * ch));
+  TRY(groupnorm(f, x, xn, h->d_gn_g, h->d_gn_b, H * W, ch, 1));
+  f.ar.free(x);
+  RUN(f, conv_out_launch(xn, h->d_out_w, h->d_out_b, image, B, H, W, ch, c.in_channels, st));
+  f.ar.free(xn);
+  if (peak) *peak = f.ar.peak;
+  return HEDIT_OK;
+}
+
+int encode_impl(hedit_vae* h, const float* image, int B, int IH, int IW, float* mean, void* ws, size_t ws_bytes,
+                hipStream_t st, bool dry, size_t* peak) {
+  VF f{h, B, st, Arena{}};
+  f.ar.dry = dry;
+  f.ar.base = reinterpret_cast<char*>(ws);
+  f.ar.cap = ws_bytes;
+  const hedit_vae_cfg& c = h->cfg;
+  const int L = c.n_levels, LC = c.latent_channels;
+  int H = IH, W = IW;
+  int ch = c.block_out_channels[0];
+  bf16_t* x;
+  TRY(aalloc(f, &x, (size_t)B * H * W * ch));
+  RUN(f, conv_in_launch(image, h->e_in_w, h->e_in_b, x, B, c.in_channels, H, W, ch, st));
+  for (int i = 0; i < L; ++i) {
+    const VStage& s = h->down[i];
+    for (const VRes& r : s.res) {
+      bf16_t* y;
+      TRY(resblock(f, r, x, H, W, &y));
+      f.ar.free(x);
+      x = y;
+    }
+    ch = s.ch;
+    if (s.samp_w) {
+      bf16_t* y;
+      TRY(aalloc(f, &y, (size_t)B * (H / 2) * (W / 2) * ch));
+      TRY(conv3x3(f, x, H, W, ch, s.samp_w, ch, s.samp_b, nullptr, y, 2));
+      f.ar.free(x);
+      x = y;
+      H /= 2; W /= 2;
+    }
+  }
+  TRY(mid(f, h->e_mid, &x, H, W));
+  bf16_t *xn, *mom;
+  TRY(aalloc(f, &xn, (size_t)B * H * W * ch));
+  TRY(groupnorm(f, x, xn, h->e_gn_g, h->e_gn_b, H * W, ch, 1));
+  f.ar.free(x);
+  TRY(aalloc(f, &mom, (size_t)B * H * W * 2 * LC));
+  TRY(conv3x3(f, xn, H, W, ch, h->e_out_w, 2 * LC, h->e_out_b, nullptr, mom, 1));
+  f.ar.free(xn);
+  // latent_dist.mode() == mean == first LC channels of quant_conv(moments)
+  RUN(f, quant_mean_launch(mom, h->quant_w, h->quant_b, mean, B, (long)H * W, 2 * LC, LC, st));
+  f.ar.free(mom);
+  if (peak) *peak = f.ar.peak;
+  return HEDIT_OK;
+}
+
+}  // namespace
+
+// ==================================================================================== C ABI
+extern "C" {
+
+int hedit_vae_create(const hedit_vae_cfg* cfg, hedit_vae** out) {
+  ARG_CHECK(cfg && out, "null");
+  ARG_CHECK(cfg->n_levels >= 1 && cfg->n_levels <= 4, "n_levels in 1..4");
+  ARG_CHECK(cfg->in_channels >= 1 && cfg->in_channels <= 4, "in_channels in 1..4");
+  ARG_CHECK(cfg->latent_channels >= 1 && cfg->latent_channels <= 8, "latent_channels in 1..8");
+  ARG_CHECK(cfg->layers_per_block >= 1 && cfg->layers_per_block <= 4, "layers_per_block in 1..4");
+  for (int i = 0; i < cfg->n_levels; ++i) {
+    const int c = cfg->block_out_channels[i];
+    ARG_CHECK(c % 64 == 0 && c % cfg->norm_num_groups == 0, "block_out_channels: multiples of 64 and of norm_num_groups");
+  }
+  TRY(gemm_prepare());
+  hedit_vae* h = new hedit_vae();
+  h->cfg = *cfg;
+  const int L = cfg->n_levels, LC = cfg->latent_channels;
+  const int* bc = cfg->block_out_channels;
+  // ---- encoder
+  h->e_in_w = f32conv(h, "encoder.conv_in.weight", bc[0], cfg->in_channels, 3);
+  h->e_in_b = vec(h, "encoder.conv_in.bias", bc[0]);
+  int ch = bc[0];
+  for (int i = 0; i < L; ++i) {
+    VStage s;
+    const std::string pre = "encoder.down_blocks." + std::to_string(i);
+    for (int j = 0; j < cfg->layers_per_block; ++j) {
+      s.res.push_back(make_res(h, pre + ".resnets." + std::to_string(j), j == 0 ? ch : bc[i], bc[i]));
+    }
+    ch = bc[i];
+    s.ch = ch;
+    if (i < L - 1) {
+      s.samp_w = conv3(h, pre + ".downsamplers.0.conv.weight", ch, ch);
+      s.samp_b = vec(h, pre + ".downsamplers.0.conv.bias", ch);
+    }
+    h->down.push_back(s);
+  }
+  h->e_mid = make_mid(h, "encoder.mid_block", ch);
+  h->e_gn_g = vec(h, "encoder.conv_norm_out.weight", ch);
+  h->e_gn_b = vec(h, "encoder.conv_norm_out.bias", ch);
+  h->e_out_w = conv3(h, "encoder.conv_out.weight", 2 * LC, ch);
+  h->e_out_b = vec(h, "encoder.conv_out.bias", 2 * LC);
+  h->quant_w = f32conv(h, "quant_conv.weight", 2 * LC, 2 * LC, 1);
+  h->quant_b = vec(h, "quant_conv.bias", 2 * LC);
+  // ---- decoder
+  h->pq_w = f32conv(h, "post_quant_conv.weight", LC, LC, 1);
+  h->pq_b = vec(h, "post_quant_conv.bias", LC);
+  ch = bc[L - 1];
+  h->d_in_w = f32conv(h, "decoder.conv_in.weight", ch, LC, 3);
+  h->d_in_b = vec(h, "decoder.conv_in.bias", ch);
+  h->d_mid = make_mid(h, "decoder.mid_block", ch);
+  for (int i = 0; i < L; ++i) {
+    VStage s;
+    const int co = bc[L - 1 - i];
+    const std::string pre = "decoder.up_blocks." + std::to_string(i);
+    for (int j = 0; j < cfg->layers_per_block + 1; ++j) {
+      s.res.push_back(make_res(h, pre + ".resnets." + std::to_string(j), j == 0 ? ch : co, co));
+    }
+    ch = co;
+    s.ch = ch;
+    if (i < L - 1) {
+      s.samp_w = conv3(h, pre + ".upsamplers.0.conv.weight", ch, ch);
+      s.samp_b = vec(h, pre + ".upsamplers.0.conv.bias", ch);
+    }
+    h->up.push_back(s);
+  }
+  h->d_gn_g = vec(h, "decoder.conv_norm_out.weight", ch);
+  h->d_gn_b = vec(h, "decoder.conv_norm_out.bias", ch);
+  h->d_out_w = conv3(h, "decoder.conv_out.weight", cfg->in_channels, ch);
+  h->d_out_b = vec(h, "decoder.conv_out.bias", cfg->in_channels);
+  if (h->alloc_failed) {
+    hedit_set_error("hipMalloc failed while creating the VAE");
+    hedit_vae_destroy(h);
+    return HEDIT_ERR_HIP;
+  }
+  *out = h;
+  return HEDIT_OK;
+}
+
+void hedit_vae_destroy(hedit_vae* h) {
+  if (!h) return;
+  for (void* p : h->owned) if (p) (void)hipFree(p);
+  delete h;
+}
+
+int hedit_vae_num_params(const hedit_vae* h) { return h ? (int)h->slots.size() : 0; }
+const char* hedit_vae_param_name(const hedit_vae* h, int i) {
+  if (!h || i < 0 || i >= (int)h->slots.size()) return nullptr;
+  return h->slots[i].name.c_str();
+}
+int hedit_vae_param_shape(const hedit_vae* h, int i, int* ndim, int* dims4) {
+  ARG_CHECK(h && ndim && dims4 && i >= 0 && i < (int)h->slots.size(), "param index");
+  *ndim = h->slots[i].ndim;
+  for (int k = 0; k < 4; ++k) dims4[k] = h->slots[i].dims[k];
+  return HEDIT_OK;
+}
+
+int hedit_vae_load(hedit_vae* h, const char* name, const float* w, size_t numel, void* stream) {
+  ARG_CHECK(h && name && w, "null");
+  auto it = h->index.find(name);
+  if (it == h->index.end()) {
+    hedit_set_error(std::string("unknown VAE parameter: ") + name);
+    return HEDIT_ERR_ARG;
+  }
+  VSlot& s = h->slots[it->second];
+  if (s.numel != numel) {
+    hedit_set_error(std::string("size mismatch for ") + name + ": expected " + std::to_string(s.numel) + ", got " + std::to_string(numel));
+    return HEDIT_ERR_ARG;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (s.kind == 0) {
+    HIP_TRY(hipMemcpyAsync(s.dst, w, numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else if (s.kind == 1) {
+    TRY(pack_linear_launch(w, reinterpret_cast<bf16_t*>(s.dst), (long)numel, 1.0f, st));
+  } else {
+    TRY(pack_conv3x3_launch(w, reinterpret_cast<bf16_t*>(s.dst), s.O, s.I, st));
+  }
+  s.loaded = true;
+  return HEDIT_OK;
+}
+
+int hedit_vae_missing(const hedit_vae* h) {
+  if (!h) return -1;
+  int m = 0;
+  for (auto& s : h->slots) m += s.loaded ? 0 : 1;
+  return m;
+}
+
+static int check_latent(const hedit_vae* h, int lh, int lw) {
+  ARG_CHECK(lh >= 1 && lw >= 1 && (lh * lw) % 64 == 0, "latent h*w must be a multiple of 64 (attention tokens)");
+  (void)h;
+  return HEDIT_OK;
+}
+
+size_t hedit_vae_workspace_bytes(hedit_vae* h, int B, int latent_h, int latent_w, int encode) {
+  if (!h || B < 1 || check_latent(h, latent_h, latent_w) != HEDIT_OK) return 0;
+  size_t peak = 0;
+  const int f = 1 << (h->cfg.n_levels - 1);
+  int rc = encode ? encode_impl(h, nullptr, B, latent_h * f, latent_w * f, nullptr, nullptr, 0, nullptr, true, &peak)
+                  : decode_impl(h, nullptr, B, latent_h, latent_w, nullptr, nullptr, 0, nullptr, true, &peak);
+  return rc == HEDIT_OK ? peak + 4096 : 0;
+}
+
+int hedit_vae_decode(hedit_vae* h, const float* z, int B, int latent_h, int latent_w, float* image, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  ARG_CHECK(h && z && image && workspace, "null");
+  ARG_CHECK(B >= 1, "B");
+  TRY(check_latent(h, latent_h, latent_w));
+  if (hedit_vae_missing(h) != 0) {
+    hedit_set_error("VAE has " + std::to_string(hedit_vae_missing(h)) + " unloaded parameters");
+    return HEDIT_ERR_STATE;
+  }
+  return decode_impl(h, z, B, latent_h, latent_w, image, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream),
+                     false, nullptr);
+}
+
+int hedit_vae_encode(hedit_vae* h, const float* image, int B, int height, int width, float* mean, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  ARG_CHECK(h && image && mean && workspace, "null");
+  ARG_CHECK(B >= 1, "B");
+  const int f = 1 << (h->cfg.n_levels - 1);
+  ARG_CHECK(height % f == 0 && width % f == 0, "image size must be divisible by 2^(levels-1)");
+  TRY(check_latent(h, height / f, width / f));
+  if (hedit_vae_missing(h) != 0) {
+    hedit_set_error("VAE has " + std::to_string(hedit_vae_missing(h)) + " unloaded parameters");
+    return HEDIT_ERR_STATE;
+  }
+  return encode_impl(h, image, B, height, width, mean, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream),
+                     false, nullptr);
+}
+
+}  // extern "C"

@@ -17,6 +17,12 @@ class UnetCfg(C.Structure):
                 ("heads", C.c_int), ("norm_num_groups", C.c_int)]
 
 
+class VaeCfg(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("latent_channels", C.c_int), ("n_levels", C.c_int),
+                ("block_out_channels", C.c_int * 4), ("layers_per_block", C.c_int),
+                ("norm_num_groups", C.c_int)]
+
+
 class P2PPlan(C.Structure):
     _fields_ = [("mode", C.c_int), ("n_pairs", C.c_int),
                 ("pair_src", C.c_void_p), ("pair_tar", C.c_void_p),
@@ -58,6 +64,18 @@ _SIGS = {
                                     C.c_void_p]),
     "hedit_local_blend": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "hedit_vae_create": (C.c_int, [C.POINTER(VaeCfg), C.POINTER(C.c_void_p)]),
+    "hedit_vae_destroy": (None, [C.c_void_p]),
+    "hedit_vae_num_params": (C.c_int, [C.c_void_p]),
+    "hedit_vae_param_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "hedit_vae_param_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "hedit_vae_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hedit_vae_missing": (C.c_int, [C.c_void_p]),
+    "hedit_vae_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "hedit_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_size_t, C.c_void_p]),
+    "hedit_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_size_t, C.c_void_p]),
     "hedit_k_gemm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "hedit_k_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 13 +
                      [C.c_void_p, C.c_void_p]),

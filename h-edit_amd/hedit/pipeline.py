@@ -18,8 +18,10 @@ class HEditPipeline:
         self.vae = vae
 
     @classmethod
-    def from_random(cls, config=None, seed=0, device="cuda:0", text_layers=12):
-        """SD-1.x-shaped pipeline with seeded synthetic weights (no checkpoints offline)."""
+    def from_random(cls, config=None, seed=0, device="cuda:0", text_layers=12, vae_config=None, with_vae=False):
+        """SD-1.x-shaped pipeline with seeded synthetic weights (no checkpoints offline).
+        ``with_vae`` adds the image autoencoder (hedit.vae.AutoencoderKL, SD-1.x shape unless
+        ``vae_config`` says otherwise)."""
         cfg = dict(SD15_CONFIG)
         cfg.update(config or {})
         unet = UNet2DConditionModel(cfg, device=device)
@@ -27,7 +29,12 @@ class HEditPipeline:
         dim = cfg["cross_attention_dim"]
         heads = 12 if dim % 12 == 0 else 4
         enc = ClipTextEncoder(dim=dim, layers=text_layers, heads=heads, seed=seed + 7).to(device)
-        return cls(unet, DDIMScheduler(), WordTokenizer(), enc, None, device)
+        vae = None
+        if with_vae or vae_config is not None:
+            from .vae import AutoencoderKL
+            vae = AutoencoderKL(vae_config, device=device)
+            vae.init_random(seed + 11)
+        return cls(unet, DDIMScheduler(), WordTokenizer(), enc, vae, device)
 
     def to(self, device):
         if torch.device(device) != self.device:

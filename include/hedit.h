@@ -133,6 +133,38 @@ int hedit_local_blend(float* const* h_maps, int n_maps, int heads, const float* 
                       const int32_t* enabled, float* xt, int n_img, int C, int H, int W, float th,
                       void* stream);
 
+/* ---- image autoencoder (SD-1.x AutoencoderKL): the steps either side of the editing loop ---------
+ * replaces `model.vae.encode(image).latent_dist.mode()` (text-guided/main_p2p.py:159; also
+ * p2p/ptp_classes.py:351-373) and `model.vae.decode(1 / 0.18215 * latents).sample`
+ * (text-guided/main_p2p.py:263).  The 0.18215 scaling stays with the caller, as in the reference.
+ * Parameters are addressed by their diffusers state_dict names (hedit_vae_param_name enumerates
+ * them); fp32 device tensors in, packed to bf16 GEMM layouts on load.  Activations bf16 NHWC. */
+typedef struct hedit_vae hedit_vae;
+typedef struct hedit_vae_cfg {
+  int in_channels;              /* 3 */
+  int latent_channels;          /* 4 */
+  int n_levels;                 /* number of entries used in block_out_channels (<= 4) */
+  int block_out_channels[4];    /* 128,256,512,512; multiples of 64 */
+  int layers_per_block;         /* 2 */
+  int norm_num_groups;          /* 32 */
+} hedit_vae_cfg;
+int hedit_vae_create(const hedit_vae_cfg* cfg, hedit_vae** out);
+void hedit_vae_destroy(hedit_vae* h);
+int hedit_vae_num_params(const hedit_vae* h);
+const char* hedit_vae_param_name(const hedit_vae* h, int i);
+int hedit_vae_param_shape(const hedit_vae* h, int i, int* ndim, int* dims4);
+int hedit_vae_load(hedit_vae* h, const char* name, const float* dev_w, size_t numel, void* stream);
+int hedit_vae_missing(const hedit_vae* h);
+/* workspace for a decode (encode = 0) or encode (encode = 1) of B images whose LATENT is h x w */
+size_t hedit_vae_workspace_bytes(hedit_vae* h, int B, int latent_h, int latent_w, int encode);
+/* z: fp32 [B][latent_channels][h][w] (already divided by the scaling factor)
+ * -> image fp32 [B][in_channels][h*f][w*f], f = 2^(n_levels-1) */
+int hedit_vae_decode(hedit_vae* h, const float* z, int B, int latent_h, int latent_w, float* image,
+                     void* workspace, size_t workspace_bytes, void* stream);
+/* image fp32 [B][in_channels][H][W] -> mean of the latent distribution, fp32 [B][latent_channels][H/f][W/f] */
+int hedit_vae_encode(hedit_vae* h, const float* image, int B, int height, int width, float* mean,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- single kernels (parity tests) ------------------------------------------------------- */
 /* C[M][N] = A . W^T (+bias)(+residual); mode 0 linear, 1 conv3x3 s1, 2 conv3x3 s2, 3 conv3x3 on
  * 2x nearest-upsampled input.  bf16 in/out.  splits: 0 = auto.  partial_ws may be NULL if the

@@ -376,6 +376,31 @@ def gen_ddim(ref, out):
         json.dump(meta, f, indent=0)
 
 
+# --------------------------------------------------------------------------- G8
+def synthetic_rgb(h, w, seed):
+    """smooth-ish deterministic uint8 image from integer arithmetic only (regenerated by the test)"""
+    y, x = np.mgrid[0:h, 0:w].astype(np.int64)
+    ch = [((x * (3 + c) + y * (5 - c) + seed * 17) % 256 + ((x * y + c * 31) // 7) % 64) % 256 for c in range(3)]
+    return np.stack(ch, -1).astype(np.uint8)
+
+
+def gen_load512(ref, out):
+    """reference load_512 (p2p/ptp_classes.py:351-373) on synthetic arrays; stores every 4th pixel
+    of the result as the integer k with x = k / 127.5 - 1, plus the sum of all k."""
+    cases = [(300, 500, 0, 0, 0, 0), (640, 480, 0, 0, 0, 0), (512, 512, 0, 0, 0, 0), (400, 600, 10, 20, 5, 7),
+             (200, 200, 300, 0, 0, 0)]
+    rec = {}
+    for i, (h, w, l, r, t, b) in enumerate(cases):
+        img = synthetic_rgb(h, w, i)
+        x = ref.pc.load_512(img, l, r, t, b, torch.device("cpu"))
+        k = torch.round((x + 1) * 127.5).to(torch.int64)
+        assert torch.allclose(k.float() / 127.5 - 1, x, atol=1e-6)
+        rec[f"case{i}"] = np.array([h, w, l, r, t, b], dtype=np.int64)
+        rec[f"sub{i}"] = npy(k[0, :, ::4, ::4]).astype(np.uint8)
+        rec[f"sum{i}"] = np.array([int(k.sum())], dtype=np.int64)
+    np.savez_compressed(os.path.join(out, "g8_load512.npz"), **rec)
+
+
 def main():
     torch.set_num_threads(4)
     torch.set_grad_enabled(True)
@@ -387,6 +412,7 @@ def main():
     gen_processor(ref, out)
     gen_loops(ref, out)
     gen_ddim(ref, out)
+    gen_load512(ref, out)
     for f in sorted(os.listdir(out)):
         if f.endswith((".npz", ".json")):
             print(f"{f:32s} {os.path.getsize(os.path.join(out, f)) / 1024:9.1f} KiB")

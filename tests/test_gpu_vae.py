@@ -1,0 +1,108 @@
+"""GPU parity of the native AutoencoderKL executor (csrc/vae.hip) against the CPU restatement
+(oracle/sd_vae.py) on identical synthetic weights: the steps either side of the editing loop
+(reference text-guided/main_p2p.py:159 encode, :263 decode)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import gpu as G  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(config, seed=0):
+    from hedit.vae import AutoencoderKL
+    from oracle import sd_vae
+    hip = AutoencoderKL(config, device=G.dev())
+    sd = hip.init_random(seed)
+    om = sd_vae.AutoencoderKL(config)
+    om.load_state_dict(sd)
+    return hip, om.eval()
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from hedit.vae import TINY_VAE_CONFIG
+    return make_pair(TINY_VAE_CONFIG)
+
+
+def test_param_inventory_matches_oracle_sd15():
+    """names and shapes of every parameter == the diffusers-keyed state_dict of the restatement
+    (248 tensors, 83,653,863 parameters for the SD-1.x autoencoder)."""
+    from hedit.vae import AutoencoderKL
+    from oracle import sd_vae
+    hip = AutoencoderKL(device=G.dev())
+    want = {k: tuple(v.shape) for k, v in sd_vae.AutoencoderKL().state_dict().items()}
+    assert hip.param_shapes == want
+    assert sum(torch.Size(s).numel() for s in hip.param_shapes.values()) == 83653863
+
+
+@pytest.mark.parametrize("B,h,w", [(1, 16, 16), (3, 16, 8), (2, 8, 8)])
+def test_decode_matches_oracle(tiny, B, h, w):
+    hip, om = tiny
+    g = torch.Generator().manual_seed(B * 100 + h)
+    z = torch.randn(B, 4, h, w, generator=g)
+    with torch.no_grad():
+        want = om.decode(z).sample
+    got = hip.decode(z.to(G.dev())).sample
+    G.sync()
+    assert got.shape == want.shape == (B, 3, 2 * h, 2 * w)
+    assert G.rel_err(got, want) < 2.5e-2        # bf16 activations, fp32 accumulation
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 32, 32), (2, 16, 64)])
+def test_encode_mode_matches_oracle(tiny, B, H, W):
+    hip, om = tiny
+    g = torch.Generator().manual_seed(B * 7 + H)
+    x = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    with torch.no_grad():
+        want = om.encode(x).latent_dist.mode()
+    got = hip.encode(x.to(G.dev())).latent_dist.mode()
+    G.sync()
+    assert got.shape == want.shape == (B, 4, H // 2, W // 2)
+    assert G.rel_err(got, want) < 2.5e-2
+
+
+def test_batch_rows_are_independent_and_deterministic(tiny):
+    hip, _ = tiny
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(1, 4, 16, 16, generator=g).repeat(3, 1, 1, 1).to(G.dev())
+    a = hip.decode(z).sample.clone()
+    b = hip.decode(z).sample
+    G.sync()
+    assert torch.equal(a, b)
+    assert torch.equal(a[0], a[1]) and torch.equal(a[0], a[2])
+
+
+def test_sd15_decode_512():
+    """full-size autoencoder (random weights): (1,4,64,64) latent -> finite (1,3,512,512) image,
+    and encode returns to a (1,4,64,64) latent."""
+    from hedit.vae import AutoencoderKL
+    vae = AutoencoderKL(device=G.dev())
+    vae.init_random(1)
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(1, 4, 64, 64, generator=g).to(G.dev())
+    img = vae.decode(z / vae.config.scaling_factor).sample
+    G.sync()
+    assert img.shape == (1, 3, 512, 512) and torch.isfinite(img).all()
+    lat = vae.encode(img.clamp(-1, 1)).latent_dist.mode()
+    G.sync()
+    assert lat.shape == (1, 4, 64, 64) and torch.isfinite(lat).all()
+
+
+def test_error_paths(tiny):
+    hip, _ = tiny
+    with pytest.raises(Exception, match="multiple of 64"):
+        hip.decode(torch.randn(1, 4, 6, 6).to(G.dev()))
+    with pytest.raises(ValueError):
+        hip.encode(torch.randn(1, 3, 33, 32).to(G.dev()))
+    from hedit.vae import AutoencoderKL, TINY_VAE_CONFIG
+    fresh = AutoencoderKL(TINY_VAE_CONFIG, device=G.dev())
+    with pytest.raises(Exception, match="unloaded"):
+        fresh.decode(torch.randn(1, 4, 8, 8).to(G.dev()))
