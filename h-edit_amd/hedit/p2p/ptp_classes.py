@@ -371,27 +371,4 @@ def get_equalizer(text, word_select, values, tokenizer):
     return equalizer
 
 
-def load_512(image_path, left=0, right=0, top=0, bottom=0, device=None):
-    """Centre-crop to a square and resize to 512x512, range [-1,1], (1,3,512,512).
-    Reference: ptp_classes.py:351-373 (including its `top = min(top, h - left - 1)` quirk)."""
-    from PIL import Image
-    if isinstance(image_path, str):
-        image = np.array(Image.open(image_path).convert("RGB"))[:, :, :3]
-    else:
-        image = image_path
-    h, w, _ = image.shape
-    left = min(left, w - 1)
-    right = min(right, w - left - 1)
-    top = min(top, h - left - 1)
-    bottom = min(bottom, h - top - 1)
-    image = image[top:h - bottom, left:w - right]
-    h, w, _ = image.shape
-    if h < w:
-        off = (w - h) // 2
-        image = image[:, off:off + h]
-    elif w < h:
-        off = (h - w) // 2
-        image = image[off:off + w]
-    image = np.array(Image.fromarray(image).resize((512, 512)))
-    image = torch.from_numpy(image).float() / 127.5 - 1
-    return image.permute(2, 0, 1).unsqueeze(0).to(device)
+from ..utils.utils import load_512  # noqa: E402,F401  (reference: p2p/ptp_classes.py:351-373)

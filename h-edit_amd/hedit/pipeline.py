@@ -36,6 +36,46 @@ class HEditPipeline:
             vae.init_random(seed + 11)
         return cls(unet, DDIMScheduler(), WordTokenizer(), enc, vae, device)
 
+    @classmethod
+    def from_pretrained(cls, path, device="cuda:0", tokenizer=None, text_encoder=None):
+        """Load a LOCAL Stable-Diffusion-1.x checkpoint directory in the diffusers layout (what the
+        reference's ``StableDiffusionPipeline.from_pretrained(model_id)`` resolves to,
+        text-guided/main_p2p.py:104-106).  The UNet and VAE run on the HIP executors; the CLIP
+        text encoder / tokenizer are transformers' (PyTorch-ROCm), unless objects are passed in."""
+        import os
+        from . import checkpoint as CK
+        from .vae import AutoencoderKL
+        if not os.path.isdir(path):
+            raise FileNotFoundError(f"{path}: not a local checkpoint directory (this build never downloads)")
+        ucfg, usd = CK.read_component(os.path.join(path, "unet"))
+        unet = UNet2DConditionModel(CK.unet_config(ucfg), device=device)
+        unet.load_state_dict(usd)
+        vae = None
+        if os.path.isdir(os.path.join(path, "vae")):
+            vcfg, vsd = CK.read_component(os.path.join(path, "vae"))
+            vae = AutoencoderKL(CK.vae_config(vcfg), device=device)
+            vae.load_state_dict(vsd)
+        if tokenizer is None:
+            from transformers import CLIPTokenizer
+            tokenizer = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"), local_files_only=True)
+        if text_encoder is None:
+            from transformers import CLIPTextModel
+            text_encoder = CLIPTextModel.from_pretrained(os.path.join(path, "text_encoder"), local_files_only=True)
+            text_encoder = text_encoder.to(device).eval()
+        sch = DDIMScheduler(**CK.scheduler_kwargs(os.path.join(path, "scheduler")))
+        return cls(unet, sch, tokenizer, text_encoder, vae, device)
+
+    def save_pretrained(self, path, unet_state_dict, vae_state_dict=None):
+        """Write the UNet / VAE weights given as state dicts (the executors keep packed bf16 copies
+        only) in the layout from_pretrained reads."""
+        import os
+        from . import checkpoint as CK
+        CK.write_component(os.path.join(path, "unet"), {k: (list(v) if isinstance(v, tuple) else v)
+                                                        for k, v in self.unet.config.items()}, unet_state_dict)
+        if self.vae is not None and vae_state_dict is not None:
+            CK.write_component(os.path.join(path, "vae"), {k: (list(v) if isinstance(v, tuple) else v)
+                                                           for k, v in self.vae.config.items()}, vae_state_dict)
+
     def to(self, device):
         if torch.device(device) != self.device:
             raise RuntimeError("the HIP UNet is bound to its creation device; build one pipeline per GPU")

@@ -1,0 +1,98 @@
+"""End-to-end on the GPU: checkpoint directory -> pipeline, and the main_p2p.py driver from a
+PIE-Bench-style mapping file to edited PNGs (reference text-guided/main_p2p.py:110-275)."""
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import gpu as G  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _driver():
+    spec = importlib.util.spec_from_file_location("hedit_main_p2p", os.path.join(ROOT, "h-edit_amd", "main_p2p.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _dataset(tmp_path):
+    from PIL import Image
+    d = tmp_path / "data"
+    (d / "annotation_images" / "0_random").mkdir(parents=True)
+    y, x = np.mgrid[0:96, 0:128]
+    mapping = {}
+    for i, (src, tar, blend, cat) in enumerate([("a cat sitting on a bench", "a dog sitting on a bench", "cat dog", "0"),
+                                                 ("a [red] car", "a [blue] car on a road", "", "1"),
+                                                 ("a tree", "a tall tree", "tree tree", "7")]):
+        img = np.stack([(x * (i + 2)) % 256, (y * 3 + i * 40) % 256, (x + y) % 256], -1).astype(np.uint8)
+        rel = f"0_random/{i:012d}.png"
+        Image.fromarray(img).save(d / "annotation_images" / rel)
+        mapping[f"{i:012d}"] = dict(image_path=rel, original_prompt=src, editing_prompt=tar, editing_instruction="",
+                                    editing_type_id=cat, blended_word=blend)
+    with open(d / "mapping_file.json", "w") as f:
+        json.dump(mapping, f)
+    return d
+
+
+@pytest.mark.parametrize("extra", [["--implicit", "--optimization_steps", "2"], [],
+                                   ["--mode", "h_edit_D_p2p", "--eta", "0.0", "--implicit", "--sa", "0.6"],
+                                   ["--mode", "h_edit_R", "--implicit"]])
+def test_driver_writes_edited_images(tmp_path, extra):
+    from PIL import Image
+    d = _dataset(tmp_path)
+    out = tmp_path / "results"
+    written = _driver().main(["--data_path", str(d), "--output_path", str(out), "--random_init", "--tiny",
+                              "--num_diffusion_steps", "4", "--edit_category_list", "0", "1"] + extra)
+    assert len(written) == 2                       # category 7 filtered out
+    for p in written:
+        assert p.startswith(str(out)) and "_total_steps_4_skip_0_" in p and os.path.exists(p)
+        im = np.array(Image.open(p))
+        assert im.shape == (256, 256, 3) and im.std() > 0
+
+
+def test_driver_refuses_baselines(tmp_path):
+    with pytest.raises(NotImplementedError):
+        _driver().main(["--data_path", str(_dataset(tmp_path)), "--random_init", "--tiny", "--mode", "ef_p2p"])
+
+
+def test_from_pretrained_round_trip(tmp_path):
+    """weights written in the diffusers directory layout load back into executors that compute
+    exactly what the original ones do"""
+    from hedit.pipeline import HEditPipeline
+    from hedit.unet import TINY_CONFIG, UNet2DConditionModel
+    from hedit.vae import TINY_VAE_CONFIG, AutoencoderKL
+    from hedit.text import ClipTextEncoder, WordTokenizer
+    dev = G.dev()
+    unet = UNet2DConditionModel(TINY_CONFIG, device=dev)
+    usd = unet.init_random(5)
+    vae = AutoencoderKL(TINY_VAE_CONFIG, device=dev)
+    vsd = vae.init_random(6)
+    enc = ClipTextEncoder(dim=64, layers=1, heads=4, seed=1).to(dev)
+    pipe = HEditPipeline(unet, None, WordTokenizer(), enc, vae, dev)
+    pipe.save_pretrained(str(tmp_path / "ckpt"), usd, vsd)
+    os.makedirs(tmp_path / "ckpt" / "scheduler")
+    with open(tmp_path / "ckpt" / "scheduler" / "scheduler_config.json", "w") as f:
+        json.dump(dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                       clip_sample=False, set_alpha_to_one=False, steps_offset=1, _class_name="PNDMScheduler"), f)
+    back = HEditPipeline.from_pretrained(str(tmp_path / "ckpt"), device=dev, tokenizer=WordTokenizer(), text_encoder=enc)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 32, 32, generator=g).to(dev)
+    ctx = torch.randn(2, 77, 64, generator=g).to(dev)
+    a = unet(x, 500, encoder_hidden_states=ctx).sample
+    b = back.unet(x, 500, encoder_hidden_states=ctx).sample
+    G.sync()
+    assert torch.equal(a, b)
+    z = torch.randn(1, 4, 16, 16, generator=g).to(dev)
+    assert torch.equal(vae.decode(z).sample, back.vae.decode(z).sample)
+    assert back.scheduler.config.steps_offset == 1
+    with pytest.raises(FileNotFoundError):
+        HEditPipeline.from_pretrained(str(tmp_path / "nope"), device=dev)

@@ -1,0 +1,47 @@
+"""Checkpoint-directory plumbing (hedit/checkpoint.py) on the CPU."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+from hedit import checkpoint as CK  # noqa: E402
+
+
+def test_component_round_trip(tmp_path):
+    sd = {"a.weight": torch.randn(4, 3), "b.bias": torch.arange(5, dtype=torch.float32)}
+    CK.write_component(str(tmp_path / "unet"), {"in_channels": 4, "block_out_channels": [64, 128]}, sd)
+    cfg, back = CK.read_component(str(tmp_path / "unet"))
+    assert cfg["block_out_channels"] == [64, 128]
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    os.remove(tmp_path / "unet" / "diffusion_pytorch_model.safetensors")
+    torch.save(sd, tmp_path / "unet" / "diffusion_pytorch_model.bin")
+    assert torch.equal(CK.read_component(str(tmp_path / "unet"))[1]["a.weight"], sd["a.weight"])
+    os.remove(tmp_path / "unet" / "diffusion_pytorch_model.bin")
+    with pytest.raises(FileNotFoundError):
+        CK.read_component(str(tmp_path / "unet"))
+
+
+def test_unet_config_filter():
+    sd14 = dict(in_channels=4, out_channels=4, sample_size=64, block_out_channels=[320, 640, 1280, 1280],
+                down_block_types=["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"],
+                up_block_types=["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3, layers_per_block=2,
+                cross_attention_dim=768, attention_head_dim=8, norm_num_groups=32, act_fn="silu",
+                use_linear_projection=False, only_cross_attention=False, _class_name="UNet2DConditionModel")
+    c = CK.unet_config(sd14)
+    assert c["block_out_channels"] == (320, 640, 1280, 1280) and "act_fn" not in c
+    with pytest.raises(NotImplementedError):
+        CK.unet_config(dict(sd14, use_linear_projection=True))                  # SD-2.x
+    with pytest.raises(NotImplementedError):
+        CK.unet_config(dict(sd14, attention_head_dim=[5, 10, 20, 20]))
+    assert CK.unet_config(dict(sd14, attention_head_dim=[8, 8, 8, 8]))["attention_head_dim"] == 8
+
+
+def test_scheduler_kwargs(tmp_path):
+    assert CK.scheduler_kwargs(str(tmp_path)) == {}
+    with open(tmp_path / "scheduler_config.json", "w") as f:
+        json.dump(dict(beta_start=0.001, steps_offset=1, skip_prk_steps=True), f)
+    assert CK.scheduler_kwargs(str(tmp_path)) == dict(beta_start=0.001, steps_offset=1)
