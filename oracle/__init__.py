@@ -19,4 +19,9 @@ Pinning status
     it => PARITY UNPINNED for the network body.  What is pinned: the attention op order (through
     the reference's P2PCrossAttnProcessor, g6), and the parameter inventory (859.5 M params,
     diffusers state_dict key names) -- see DESIGN.md §Oracle.
+  * SD-1.x image autoencoder (oracle/sd_vae.py): same situation -- diffusers' AutoencoderKL, no
+    reference test or vector => PARITY UNPINNED for the body; pinned: the parameter inventory
+    (248 tensors, 83,653,863 parameters, diffusers key names).  The host image I/O around it
+    (load_512) is not oracle code at all: the product function is checked bit-exactly against
+    vectors produced by the reference's own load_512 (tests/golden/g8_load512.npz).
 """
