@@ -57,7 +57,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): LDS-DMA targets, tile roles
   const int wm = wave >> 1, wn = wave & 1;      // (BM/64) x 2 waves
 
   // XCD-aware tile order.  Workgroup b is observed to run on XCD b % 8 (speed only, never
@@ -208,6 +208,56 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     }
   };
 
+  // the same DMA in two halves, so each can be woven into a different MFMA group of the K loop:
+  // prep_glds computes the A_CH + W_CH per-lane source pointers of K-tile kt (tap arithmetic,
+  // 64-bit adds, zero-page selects: VALU/SALU only), fire_glds issues the LDS-DMA instructions
+  // (M0 + global_load_lds each) into stage `buf`.
+  constexpr int NPTR = A_CH + W_CH;
+  auto prep_glds = [&](int kt, const bf16_t* (&src)[NPTR]) __attribute__((always_inline)) {
+    int k0 = kt * BK;
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) src[i] = a_mask[i] ? a_ptr[i] + k0 : zero_page;
+    } else {
+      const int tap = kt % 9;
+      const int ci0 = (kt / 9) * BK;
+      k0 = tap * p.Cin + ci0;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      if (MODE == 3) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+          const int fy = (a_oy[i] + dy) >> 1, fx = (a_ox[i] + dx) >> 1;      // in {-1, 0, +1}
+          const bool ok = (a_mask[i] >> tap) & 1u;
+          src[i] = ok ? a_ptr[i] + (fy * p.Win + fx) * p.Cin + ci0 : zero_page;
+        }
+      } else {
+        const long delta = ((long)dy * p.Win + dx) * p.Cin + ci0;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) src[i] = ((a_mask[i] >> tap) & 1u) ? a_ptr[i] + delta : zero_page;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i) src[A_CH + i] = w_ok[i] ? w_ptr[i] + k0 : zero_page;
+  };
+  auto fire_glds = [&](int buf, const bf16_t* (&src)[NPTR]) __attribute__((always_inline)) {
+    char* sa = smem + buf * S::STAGE;
+    char* sw = sa + S::A_BYTES;
+#ifndef GEMM_AUX_A
+#define GEMM_AUX_A 0
+#endif
+#ifndef GEMM_AUX_W
+#define GEMM_AUX_W 0
+#endif
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                       (__attribute__((address_space(3))) void*)(sa + a_lds[i]), 16, 0, GEMM_AUX_A);
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[A_CH + i],
+                                       (__attribute__((address_space(3))) void*)(sw + w_lds[i]), 16, 0, GEMM_AUX_W);
+  };
+
   auto load_tile = [&](int kt, u32x4* a_reg, u32x4* w_reg) __attribute__((always_inline)) {
     // K-tile order.  linear: k0 = kt*64.  conv: the 9 taps of one 64-channel slab are visited
     // back to back (tap = kt % 9, slab = kt / 9) so the shifted re-reads of the same input
@@ -317,7 +367,113 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       nxt = nxt == 2 ? 0 : nxt + 1;
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the epilogue
-  } else if constexpr (GLDS) {
+  }
+#ifndef GEMM_FULLSTEP
+  else if constexpr (GLDS) {
+    // two LDS stages, pipelined at the granularity of a 32-deep k-step: the fragments of the NEXT
+    // k-step are read from LDS while the 20 MFMAs of the current one run, across the K-tile
+    // boundary too -- a wave never sits in a read-only phase.  Tile k+1 must therefore be visible
+    // in the middle of tile k: the barrier sits between the two MFMA groups, after it stage `cur`
+    // has been read into registers completely (lgkmcnt(0) first) and takes the DMA of tile k+2.
+    const int nk = kt_end - kt_begin;
+    bf16x8 xa[MI], wa[NI], xb[MI], wb[NI];
+    auto read_frags = [&](int buf, int ks, bf16x8 (&xf)[MI], bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
+      const char* pa = smem + buf * S::STAGE + (a_rd ^ (ks << 6));
+      const char* pw = smem + buf * S::STAGE + S::A_BYTES + (w_rd ^ (ks << 6));
+#pragma unroll
+      for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(pa + i * 2048);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + j * 2048);
+    };
+    auto mfma_group = [&](const bf16x8 (&xf)[MI], const bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    // Steady state of one K-tile i (two MFMA groups of MI*NI, one barrier between them):
+    //   group 1 = MFMAs of k-step 0, with the fragment reads of k-step 1 in front and the source
+    //             pointers of tile i+2 (prep_glds: ~10 VALU/SALU per DMA) woven between the MFMAs;
+    //   barrier  = tile i+1 has landed everywhere, stage `cur` is in registers everywhere;
+    //   group 2 = MFMAs of k-step 1, with the 9 LDS-DMA issues of tile i+2 (into stage cur) and the
+    //             fragment reads of tile i+1's k-step 0 woven in.
+    // The ~130 non-MFMA instructions a tile's DMA needs thereby sit in issue slots the 16-cycle
+    // MFMAs leave free instead of forming a serial phase (they were ~45 % of a wave's K-tile time).
+    // sched_group_barrier spells the interleave out for the scheduler.
+    const bf16_t* nsrc[NPTR];
+    auto weave_prep = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < MI * NI / 2; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);      // 8 VALU | SALU (pointer arithmetic)
+      }
+    };
+    // (the fragment reads come first: the compiler cannot prove that the LDS-DMA writes into stage
+    // `cur` do not alias the reads of stage `cur ^ 1`, so reads and DMA issues cannot alternate)
+    auto weave_fire = [&]() __attribute__((always_inline)) {
+      constexpr int G = MI * NI / 2, GR = (MI + NI + 1) / 2;     // MFMA pairs; pairs that carry 2 reads each
+#pragma unroll
+      for (int r = 0; r < G; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+        if (r < GR) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // 2 ds_read
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);    // M0
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // 2 LDS-DMA
+        }
+      }
+    };
+    auto mfmas = [&](const bf16x8 (&xf)[MI], const bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    };
+    if (nk > 0) {
+      issue_glds(kt_begin, 0);
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (nk > 1) issue_glds(kt_begin + 1, 1);
+      read_frags(0, 0, xa, wa);
+    }
+    int i = 0;
+    for (; i + 2 < nk; ++i) {          // steady state: tile i+2 exists, no conditionals inside
+      const int cur = i & 1;
+      read_frags(cur, 1, xb, wb);
+      __builtin_amdgcn_s_setprio(1);
+      prep_glds(kt_begin + i + 2, nsrc);
+      mfmas(xa, wa);
+      weave_prep();
+      __builtin_amdgcn_s_setprio(0);
+#ifndef GEMM_NOBAR
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+      __builtin_amdgcn_s_setprio(1);
+      read_frags(cur ^ 1, 0, xa, wa);
+#ifndef GEMM_NODMA
+      fire_glds(cur, nsrc);
+#endif
+      mfmas(xb, wb);
+      weave_fire();
+      __builtin_amdgcn_s_setprio(0);
+    }
+    for (; i < nk; ++i) {              // last two tiles: nothing left to fetch
+      const int cur = i & 1;
+      read_frags(cur, 1, xb, wb);
+      mfma_group(xa, wa);
+      if (i + 1 < nk) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        read_frags(cur ^ 1, 0, xa, wa);
+      }
+      mfma_group(xb, wb);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the epilogue
+  }
+#endif
+  else if constexpr (GLDS) {
     // two LDS stages: the DMA of tile k+1 runs under the MFMAs of tile k; a wave waits for its
     // own DMA (vmcnt) and the barrier then makes every wave's part of the stage visible and
     // guarantees nobody still reads the stage that is about to be overwritten.
