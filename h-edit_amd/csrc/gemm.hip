@@ -40,9 +40,7 @@ struct Smem {
   static constexpr int TOTAL = STAGES * STAGE;
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
-
-template <int BM, int BN, int MODE, bool GLDS>
+template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = BM * 2;       // threads: 4 or 8 waves, each owning a 64 x BN/2 sub-tile
@@ -52,7 +50,6 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   constexpr int A_CH = BM * 8 / NT;                    // 16-byte chunks (or 8-row DMA groups) per thread / wave
   constexpr int W_GROUPS = BN / 8;
   constexpr int W_CH = (W_GROUPS + NW - 1) / NW;       // 8 waves x 3 > 20 groups: the surplus re-loads the last group
-  static_assert(GLDS || BM == 128, "the 256-row tile exists for LDS-DMA staging only");
   using S = Smem<BM, BN>;
 
   const int tid = threadIdx.x;
@@ -98,12 +95,11 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     // LDS-DMA staging: one wave instruction fills 8 rows x 128 B linearly (lane L -> row L>>3,
     // slot L&7), so the swizzle is applied on the SOURCE side: slot p of row r must receive
     // chunk p ^ (r & 7)  (same involution the fragment reads use).
-    const int id = tid + i * NT;
-    const int row = GLDS ? (wave * A_CH + i) * 8 + (lane >> 3) : id >> 3;
-    const int c = GLDS ? ((lane & 7) ^ (lane >> 3)) : id & 7;
+    const int row = (wave * A_CH + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (lane >> 3);
     const int m = m0 + row;
     const bool ok = m < p.M;
-    a_lds[i] = GLDS ? (wave * A_CH + i) * 1024 : swz(row, c);
+    a_lds[i] = (wave * A_CH + i) * 1024;
     a_oy[i] = a_ox[i] = 0;
     if (MODE == 0) {
       a_ptr[i] = ok ? p.A + (long)m * p.lda + c * 8 : zero_page;
@@ -149,20 +145,15 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   int w_lds[W_CH];
 #pragma unroll
   for (int i = 0; i < W_CH; ++i) {
-    const int id = tid + i * NT;
     int wg = wave * W_CH + i;
     if (wg > W_GROUPS - 1) wg = W_GROUPS - 1;
-    const int row = GLDS ? wg * 8 + (lane >> 3) : id >> 3;
-    const int c = GLDS ? ((lane & 7) ^ (lane >> 3)) : id & 7;
+    const int row = wg * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (lane >> 3);
     const int n = n0 + row;
     w_ok[i] = n < p.N;
-    w_lds[i] = GLDS ? wg * 1024 : swz(row, c);
+    w_lds[i] = wg * 1024;
     w_ptr[i] = p.W + (long)n * p.K + c * 8;
   }
-
-  // two register stages: tile k+2 is requested while tile k is being multiplied, so every global
-  // load has two K-iterations to land (2 x 36 KB per block in flight)
-  u32x4 a_reg0[A_CH], w_reg0[W_CH], a_reg1[A_CH], w_reg1[W_CH];
 
   // direct-to-LDS DMA of one K-tile into stage `buf` (no VGPR round trip, no ds_write)
   auto issue_glds = [&](int kt, int buf) __attribute__((always_inline)) {
@@ -258,54 +249,6 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
                                        (__attribute__((address_space(3))) void*)(sw + w_lds[i]), 16, 0, GEMM_AUX_W);
   };
 
-  auto load_tile = [&](int kt, u32x4* a_reg, u32x4* w_reg) __attribute__((always_inline)) {
-    // K-tile order.  linear: k0 = kt*64.  conv: the 9 taps of one 64-channel slab are visited
-    // back to back (tap = kt % 9, slab = kt / 9) so the shifted re-reads of the same input
-    // pixels are nine consecutive K-tiles apart at most -> they stay in L1/L2.
-    int k0 = kt * BK;
-    if (MODE == 0) {
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) {
-        const bf16_t* src = a_mask[i] ? a_ptr[i] + k0 : zero_page;
-        a_reg[i] = *reinterpret_cast<const u32x4*>(src);
-      }
-    } else {
-      const int tap = kt % 9;
-      const int ci0 = (kt / 9) * BK;
-      k0 = tap * p.Cin + ci0;
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      if (MODE == 3) {
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-          const int fy = (a_oy[i] + dy) >> 1, fx = (a_ox[i] + dx) >> 1;      // in {-1, 0, +1}
-          const bool ok = (a_mask[i] >> tap) & 1u;
-          const bf16_t* src = ok ? a_ptr[i] + (fy * p.Win + fx) * p.Cin + ci0 : zero_page;
-          a_reg[i] = *reinterpret_cast<const u32x4*>(src);
-        }
-      } else {
-        const long delta = ((long)dy * p.Win + dx) * p.Cin + ci0;     // wave-uniform
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-          const bf16_t* src = ((a_mask[i] >> tap) & 1u) ? a_ptr[i] + delta : zero_page;
-          a_reg[i] = *reinterpret_cast<const u32x4*>(src);
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < W_CH; ++i) {
-      const bf16_t* src = w_ok[i] ? w_ptr[i] + k0 : zero_page;
-      w_reg[i] = *reinterpret_cast<const u32x4*>(src);
-    }
-  };
-  auto store_tile = [&](int buf, const u32x4* a_reg, const u32x4* w_reg) __attribute__((always_inline)) {
-    char* sa = smem + buf * S::STAGE;
-    char* sw = sa + S::A_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(sa + a_lds[i]) = a_reg[i];
-#pragma unroll
-    for (int i = 0; i < W_CH; ++i) *reinterpret_cast<u32x4*>(sw + w_lds[i]) = w_reg[i];
-  };
-
   f32x4 acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -348,7 +291,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     __builtin_amdgcn_s_setprio(0);
   };
 
-  if constexpr (GLDS && S::STAGES == 3) {
+  if constexpr (S::STAGES == 3) {
     // three LDS stages, two K-tiles of DMA in flight.  A wave waits (counted vmcnt: everything
     // except its A_CH + W_CH newest DMA instructions) for ITS part of tile k, the raw barrier then
     // publishes every wave's part and proves that nobody still reads the stage tile k+2 is about
@@ -367,9 +310,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       nxt = nxt == 2 ? 0 : nxt + 1;
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the epilogue
-  }
-#ifndef GEMM_FULLSTEP
-  else if constexpr (GLDS) {
+  } else {
     // two LDS stages, pipelined at the granularity of a 32-deep k-step: the fragments of the NEXT
     // k-step are read from LDS while the 20 MFMAs of the current one run, across the K-tile
     // boundary too -- a wave never sits in a read-only phase.  Tile k+1 must therefore be visible
@@ -472,43 +413,6 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the epilogue
   }
-#endif
-  else if constexpr (GLDS) {
-    // two LDS stages: the DMA of tile k+1 runs under the MFMAs of tile k; a wave waits for its
-    // own DMA (vmcnt) and the barrier then makes every wave's part of the stage visible and
-    // guarantees nobody still reads the stage that is about to be overwritten.
-    if (kt_begin < kt_end) issue_glds(kt_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int cur = (kt - kt_begin) & 1;
-      if (kt + 1 < kt_end) issue_glds(kt + 1, cur ^ 1);
-      compute(cur);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  } else {
-  if (kt_begin < kt_end) {
-    load_tile(kt_begin, a_reg0, w_reg0);
-    store_tile(0, a_reg0, w_reg0);
-  }
-  if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1, a_reg1, w_reg1);
-  __syncthreads();
-
-  for (int kt = kt_begin; kt < kt_end; kt += 2) {
-    // even step: tile kt is in LDS buffer 0, tile kt+1 is in flight in register set 1
-    if (kt + 2 < kt_end) load_tile(kt + 2, a_reg0, w_reg0);
-    compute(0);
-    if (kt + 1 < kt_end) store_tile(1, a_reg1, w_reg1);
-    __syncthreads();
-    if (kt + 1 >= kt_end) break;
-    // odd step: tile kt+1 is in LDS buffer 1, tile kt+2 is in flight in register set 0
-    if (kt + 3 < kt_end) load_tile(kt + 3, a_reg1, w_reg1);
-    compute(1);
-    if (kt + 2 < kt_end) store_tile(0, a_reg0, w_reg0);
-    __syncthreads();
-  }
-  }   // !GLDS
 
   // ---- epilogue.  A lane holds 4 consecutive n of column m = mb + fr.
   if (p.partial) {
@@ -678,17 +582,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   *reinterpret_cast<uint2*>(p.C + (long)m * p.ldc + n) = o;
 }
 
-template <int BM, int BN, int MODE, bool GLDS>
+template <int BM, int BN, int MODE>
 int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
   using S = Smem<BM, BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, GLDS>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, S::TOTAL));
     attr_set = true;
   }
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), splits);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, GLDS>), grid, dim3(BM * 2), S::TOTAL, st, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE>), grid, dim3(BM * 2), S::TOTAL, st, p);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }
@@ -704,25 +608,9 @@ static int big_tile_mode() {
   return v;
 }
 
-// operand staging: direct-to-LDS DMA by default; HEDIT_GEMM_STAGING=regs selects the
-// register-staged pipeline (kept for A/B measurements)
-static bool use_glds() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("HEDIT_GEMM_STAGING");
-    v = (e && std::string(e) == "regs") ? 0 : 1;
-  }
-  return v == 1;
-}
-
 template <int BN, int MODE>
 int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
-  if (!use_glds()) return launch_igemm_impl<128, BN, MODE, false>(p, splits, st);
-  const long big_tiles = (long)cdiv(p.M, 256) * cdiv(p.N, BN);
-  const int mode = big_tile_mode();
-  (void)big_tiles;
-  const bool big = mode == 256;
-  return big ? launch_igemm_impl<256, BN, MODE, true>(p, splits, st) : launch_igemm_impl<128, BN, MODE, true>(p, splits, st);
+  return big_tile_mode() == 256 ? launch_igemm_impl<256, BN, MODE>(p, splits, st) : launch_igemm_impl<128, BN, MODE>(p, splits, st);
 }
 
 }  // namespace
