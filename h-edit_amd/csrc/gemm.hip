@@ -239,6 +239,16 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
 #ifndef GEMM_AUX_W
 #define GEMM_AUX_W 0
 #endif
+#ifdef GEMM_LOAD_NOLDS
+    // timing experiment only: the same global traffic, landing in dead registers instead of LDS
+#pragma unroll
+    for (int i = 0; i < NPTR; ++i) {
+      u32x4 t;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t) : "v"(src[i]) : "memory");
+      (void)t;
+    }
+    (void)sa; (void)sw;
+#else
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
@@ -247,6 +257,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     for (int i = 0; i < W_CH; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[A_CH + i],
                                        (__attribute__((address_space(3))) void*)(sw + w_lds[i]), 16, 0, GEMM_AUX_W);
+#endif
   };
 
   f32x4 acc[MI][NI];
