@@ -5,6 +5,25 @@ import torch
 from ..engine import HEditEngine
 
 
+def sample_xts_from_x0(model, x0, num_inference_steps=50):
+    """Independent draws x_t ~ q(x_t | x_0) for every scheduler timestep (reference
+    ddpm_inversion.py:5-52): returns (xts, noise_added), both (T+1, C, H, W) with row 0 = x0 / zeros
+    and row idx = T - position of t in ``scheduler.timesteps``."""
+    ab = model.scheduler.alphas_cumprod
+    ts = [int(t) for t in model.scheduler.timesteps]
+    x = x0 if x0.dim() == 3 else x0[0]
+    xts = torch.zeros((num_inference_steps + 1,) + tuple(x.shape), device=x0.device)
+    noise_added = torch.zeros_like(xts)
+    xts[0] = x
+    for pos in reversed(range(len(ts))):
+        t = ts[pos]
+        idx = num_inference_steps - pos
+        nz = torch.randn_like(x)
+        xts[idx] = x * float(ab[t]) ** 0.5 + nz * float(1 - ab[t]) ** 0.5
+        noise_added[idx] = nz
+    return xts, noise_added
+
+
 def inversion_forward_process_ddpm(model, x0, etas=None, prog_bar=True, prompt="", cfg_scale_src=1.0,
                                    cfg_scale_src_edit=3.5, num_inference_steps=50, noise=None, generator=None):
     """Returns (xt, zs, xts, noise_added) like the reference: zs (T,C,H,W), xts (T+1,C,H,W).

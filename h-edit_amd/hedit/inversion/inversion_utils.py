@@ -56,3 +56,18 @@ def reverse_step(model, model_output, timestep, sample, eta=0, variance_noise=No
 
 def compute_full_coeff(model, timestep, prev_timestep, eta, is_ddim_inversion=False):
     return Schedule(model.scheduler).full_coeff(int(timestep), int(prev_timestep), eta, is_ddim_inversion)
+
+
+def slerp(val, low, high):
+    """Spherical interpolation between the rows of two (B, D) tensors (reference
+    inversion_utils.py:142-152)."""
+    ln = low / torch.norm(low, dim=1, keepdim=True)
+    hn = high / torch.norm(high, dim=1, keepdim=True)
+    omega = torch.acos((ln * hn).sum(1))
+    so = torch.sin(omega)
+    return (torch.sin((1.0 - val) * omega) / so).unsqueeze(1) * low + (torch.sin(val * omega) / so).unsqueeze(1) * high
+
+
+def slerp_tensor(val, low, high):
+    """slerp on flattened per-item tensors, reshaped back (reference inversion_utils.py:154-160)."""
+    return slerp(val, low.flatten(1), high.flatten(1)).reshape(low.shape)

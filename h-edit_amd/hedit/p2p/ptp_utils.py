@@ -66,3 +66,12 @@ def get_time_words_attention_alpha(prompts, num_steps, cross_replace_steps, toke
             if len(ind) > 0:
                 table = update_alpha_time_word(table, bounds, i, torch.as_tensor(ind))
     return table.reshape(num_steps + 1, n_edit, 1, 1, max_num_words)
+
+
+@torch.no_grad()
+def latent2image(vae, latents):
+    """latents -> uint8 HWC numpy images (reference ptp_utils.py:76-83): decode(latents / 0.18215),
+    (x / 2 + 0.5).clamp(0, 1) * 255."""
+    image = vae.decode(1 / 0.18215 * latents)["sample"]
+    image = (image / 2 + 0.5).clamp(0, 1)
+    return (image.cpu().permute(0, 2, 3, 1).numpy() * 255).astype("uint8")

@@ -135,3 +135,28 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports oracle"
+
+
+def test_sample_xts_and_slerp_helpers():
+    """small host helpers with the reference's names (ddpm_inversion.py:5-52, inversion_utils.py:142-160)"""
+    import types
+    from hedit.inversion.ddpm_inversion import sample_xts_from_x0
+    from hedit.inversion.inversion_utils import slerp, slerp_tensor
+    from hedit.scheduler import DDIMScheduler
+    sch = DDIMScheduler()
+    sch.set_timesteps(10)
+    model = types.SimpleNamespace(scheduler=sch, device=torch.device("cpu"))
+    x0 = torch.randn(4, 8, 8)
+    torch.manual_seed(3)
+    xts, nz = sample_xts_from_x0(model, x0, num_inference_steps=10)
+    assert xts.shape == nz.shape == (11, 4, 8, 8) and torch.equal(xts[0], x0) and not nz[0].any()
+    ts = [int(t) for t in sch.timesteps]
+    for pos, t in enumerate(ts):
+        idx = 10 - pos
+        ab = float(sch.alphas_cumprod[t])
+        assert torch.allclose(xts[idx], x0 * ab ** 0.5 + nz[idx] * (1 - ab) ** 0.5, atol=1e-6)
+    assert ts[-1] < ts[0] and xts[10].std() > xts[1].std() * 0.5      # idx grows with the noise level
+    a, b = torch.randn(2, 3, 4, 4), torch.randn(2, 3, 4, 4)
+    assert torch.allclose(slerp_tensor(0.0, a, b), a, atol=1e-5) and torch.allclose(slerp_tensor(1.0, a, b), b, atol=1e-5)
+    mid = slerp(0.5, a.flatten(1), b.flatten(1))
+    assert mid.shape == (2, 48)
