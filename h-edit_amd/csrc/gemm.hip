@@ -276,49 +276,92 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   const int a_rd = (wm * 64 + fr) * 128 + rd_x;
   const int w_rd = (wn * (BN / 2) + fr) * 128 + rd_x;
 
-  auto compute = [&](int buf) __attribute__((always_inline)) {
-    const char* sa = smem + buf * S::STAGE;
-    const char* sw = sa + S::A_BYTES;
-    // all 18 fragment reads of the K-tile are issued up front (fragments of both 32-deep k-steps
-    // live in registers), so the second k-step's LDS latency hides under the first one's MFMAs
-    bf16x8 xf[2][MI], wf[2][NI];
+  if constexpr (S::STAGES == 3) {
+    // Three LDS stages as a ring with the DMA TWO tiles ahead and a counted vmcnt: the queue never
+    // drains (one to two tiles = 52-104 KB in flight), which is what the measured ~0.85 us
+    // issue-to-landed time of an LDS-DMA under load needs -- the 2-stage loop below can only give a
+    // DMA one tile of MFMAs to land and is bound by exactly that latency (operand traffic without
+    // MFMAs runs at 1.6-1.9 PF/s-equivalent, MFMAs without traffic at 1.3-1.6, the two together
+    // at 0.9-1.15: they do not overlap).  Same k-step-level weave as the 2-stage loop:
+    //   group 1 of tile j = MFMAs of k-step 0 | fragment reads of k-step 1 | pointers of tile j+3
+    //   mid-tile          = wait [my DMA of tile j+1 landed: vmcnt(NDMA) lets tile j+2 stay in
+    //                       flight] + lgkmcnt(0); barrier -> tile j+1 visible everywhere, stage
+    //                       j%3 in registers everywhere
+    //   group 2 of tile j = MFMAs of k-step 1 | DMA of tile j+3 into stage j%3 | reads of tile
+    //                       j+1's k-step 0
+    constexpr int NDMA = A_CH + W_CH;
+    const int nk = kt_end - kt_begin;
+    bf16x8 xa[MI], wa[NI], xb[MI], wb[NI];
+    const bf16_t* nsrc[NPTR];
+    auto read_frags = [&](int buf, int ks, bf16x8 (&xf)[MI], bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
+      const char* pa = smem + buf * S::STAGE + (a_rd ^ (ks << 6));
+      const char* pw = smem + buf * S::STAGE + S::A_BYTES + (w_rd ^ (ks << 6));
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const char* pa = sa + (a_rd ^ (ks << 6));
-      const char* pw = sw + (w_rd ^ (ks << 6));
+      for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(pa + i * 2048);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) xf[ks][i] = *reinterpret_cast<const bf16x8*>(pa + i * 2048);
-#pragma unroll
-      for (int j = 0; j < NI; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(pw + j * 2048);
-    }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + j * 2048);
+    };
+    auto mfmas = [&](const bf16x8 (&xf)[MI], const bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], xf[ks][i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-
-  if constexpr (S::STAGES == 3) {
-    // three LDS stages, two K-tiles of DMA in flight.  A wave waits (counted vmcnt: everything
-    // except its A_CH + W_CH newest DMA instructions) for ITS part of tile k, the raw barrier then
-    // publishes every wave's part and proves that nobody still reads the stage tile k+2 is about
-    // to overwrite (it was consumed in iteration k-1).  __syncthreads() would drain vmcnt to 0.
-    constexpr int NDMA = A_CH + W_CH;
-    const int nk = kt_end - kt_begin;
-    if (nk > 0) issue_glds(kt_begin, 0);
-    if (nk > 1) issue_glds(kt_begin + 1, 1);
-    int cur = 0, nxt = 2;
-    for (int i = 0; i < nk; ++i) {
-      if (i + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NDMA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      if (i + 2 < nk) issue_glds(kt_begin + i + 2, nxt);
-      compute(cur);
-      cur = cur == 2 ? 0 : cur + 1;
-      nxt = nxt == 2 ? 0 : nxt + 1;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    };
+    for (int t = 0; t < 3 && t < nk; ++t) issue_glds(kt_begin + t, t);
+    if (nk > 0) {
+      if (nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+      else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      read_frags(0, 0, xa, wa);
+    }
+    int j = 0, cur = 0;
+    for (; j + 3 < nk; ++j) {          // steady state: tiles j+1 .. j+3 exist
+      const int nx = cur == 2 ? 0 : cur + 1;
+      read_frags(cur, 1, xb, wb);
+      __builtin_amdgcn_s_setprio(1);
+      prep_glds(kt_begin + j + 3, nsrc);
+      mfmas(xa, wa);
+#pragma unroll
+      for (int r = 0; r < MI * NI / 2; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);      // pointer arithmetic
+      }
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA) : "memory");
+      __builtin_amdgcn_s_setprio(1);
+      read_frags(nx, 0, xa, wa);
+      fire_glds(cur, nsrc);
+      mfmas(xb, wb);
+#pragma unroll
+      for (int r = 0; r < MI * NI / 2; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+        if (r < (MI + NI + 1) / 2) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // 2 ds_read
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);    // M0
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // 2 LDS-DMA
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      cur = nx;
+    }
+    for (; j < nk; ++j) {              // last three tiles: nothing left to fetch
+      const int nx = cur == 2 ? 0 : cur + 1;
+      read_frags(cur, 1, xb, wb);
+      __builtin_amdgcn_s_setprio(1);
+      mfmas(xa, wa);
+      __builtin_amdgcn_s_setprio(0);
+      if (j + 1 < nk) {
+        if (j + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        read_frags(nx, 0, xa, wa);
+      }
+      __builtin_amdgcn_s_setprio(1);
+      mfmas(xb, wb);
+      __builtin_amdgcn_s_setprio(0);
+      cur = nx;
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the epilogue
   } else {
@@ -338,6 +381,9 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + j * 2048);
     };
     auto mfma_group = [&](const bf16x8 (&xf)[MI], const bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
+#ifdef GEMM_NOMFMA
+      acc[0][0][1] += (float)xf[0][0] + (float)wf[0][0] + (float)xf[MI - 1][7] + (float)wf[NI - 1][7];
+#else
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -345,6 +391,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
+#endif
     };
     // Steady state of one K-tile i (two MFMA groups of MI*NI, one barrier between them):
     //   group 1 = MFMAs of k-step 0, with the fragment reads of k-step 1 in front and the source
@@ -379,11 +426,16 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       }
     };
     auto mfmas = [&](const bf16x8 (&xf)[MI], const bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
+#ifdef GEMM_NOMFMA
+      // timing experiment only: operand traffic without the multiply
+      acc[0][0][0] += (float)xf[0][0] + (float)wf[0][0] + (float)xf[MI - 1][7] + (float)wf[NI - 1][7];
+#else
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+#endif
     };
     if (nk > 0) {
       issue_glds(kt_begin, 0);
@@ -608,8 +660,10 @@ int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
   return HEDIT_OK;
 }
 
-// HEDIT_GEMM_BM=256 selects the 8-wave 256-row / 3-stage variant for every launch; measured on MI355X it ties the default 128-row kernel within +-3 % (both sit at
-// the ceiling of the two-barrier-per-K-tile structure), so it is off by default.
+// Tile choice.  The 8-wave 256-row kernel (three-stage ring, DMA two tiles ahead) is 5-8 % faster
+// than the 4-wave 128-row kernel when the K loop is long and there is at least one tile per CU
+// (3x3 convs, FF2: 1.17-1.26 vs 1.10-1.16 PF/s); with few K-tiles its longer prologue / epilogue
+// per tile loses (K = 320: -3...-9 %).  HEDIT_GEMM_BM=128|256 forces one of them (A/B runs).
 static int big_tile_mode() {
   static int v = -1;
   if (v < 0) {
@@ -621,7 +675,10 @@ static int big_tile_mode() {
 
 template <int BN, int MODE>
 int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
-  return big_tile_mode() == 256 ? launch_igemm_impl<256, BN, MODE>(p, splits, st) : launch_igemm_impl<128, BN, MODE>(p, splits, st);
+  const int mode = big_tile_mode();
+  const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.N, BN);
+  const bool big = mode == 256 || (mode != 128 && splits == 1 && !p.geglu && p.K / BK >= 16 && tiles256 >= 200);
+  return big ? launch_igemm_impl<256, BN, MODE>(p, splits, st) : launch_igemm_impl<128, BN, MODE>(p, splits, st);
 }
 
 }  // namespace

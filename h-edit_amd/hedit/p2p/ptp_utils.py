@@ -70,7 +70,7 @@ def get_time_words_attention_alpha(prompts, num_steps, cross_replace_steps, toke
 
 @torch.no_grad()
 def latent2image(vae, latents):
-    """latents -> uint8 HWC numpy images (reference ptp_utils.py:76-83): decode(latents / 0.18215),
+    """latents -> uint8 HWC numpy images (reference ptp_utils.py:181-187): decode(latents / 0.18215),
     (x / 2 + 0.5).clamp(0, 1) * 255."""
     image = vae.decode(1 / 0.18215 * latents)["sample"]
     image = (image / 2 + 0.5).clamp(0, 1)
