@@ -14,8 +14,8 @@ import sys
 
 def klass(name):
     if "igemm_kernel" in name:
-        mode = name.split("igemm_kernel<")[1].split(",")[1].strip()
-        return "linear_gemm" if mode == "0" else "conv3x3_gemm"
+        args = [a.strip() for a in name.split("igemm_kernel<")[1].split(">")[0].split(",")]   # BM, BN, MODE
+        return "linear_gemm" if args[2] == "0" else "conv3x3_gemm"
     if "splitk_reduce" in name:
         return "splitk_reduce"
     if "self_attn" in name:
