@@ -662,8 +662,9 @@ int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
 
 // Tile choice.  The 8-wave 256-row kernel (three-stage ring, DMA two tiles ahead) is 5-8 % faster
 // than the 4-wave 128-row kernel when the K loop is long and there is at least one tile per CU
-// (3x3 convs, FF2: 1.17-1.26 vs 1.10-1.16 PF/s); with few K-tiles its longer prologue / epilogue
-// per tile loses (K = 320: -3...-9 %).  HEDIT_GEMM_BM=128|256 forces one of them (A/B runs).
+// (3x3 convs, FF2: 1.17-1.26 vs 1.10-1.16 PF/s) and for the fused FF1+GEGLU at every K (+2 / +9 /
+// +14 % at K = 320 / 640 / 1280: half as many tiles pay the GELU epilogue's LDS pass); plain
+// launches with few K-tiles lose to its longer per-tile prologue / epilogue (K = 320: -3...-9 %).  HEDIT_GEMM_BM=128|256 forces one of them (A/B runs).
 static int big_tile_mode() {
   static int v = -1;
   if (v < 0) {
@@ -677,7 +678,7 @@ template <int BN, int MODE>
 int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
   const int mode = big_tile_mode();
   const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.N, BN);
-  const bool big = mode == 256 || (mode != 128 && splits == 1 && !p.geglu && p.K / BK >= 16 && tiles256 >= 200);
+  const bool big = mode == 256 || (mode != 128 && splits == 1 && (p.geglu || p.K / BK >= 16) && tiles256 >= 200);
   return big ? launch_igemm_impl<256, BN, MODE>(p, splits, st) : launch_igemm_impl<128, BN, MODE>(p, splits, st);
 }
 
