@@ -6,20 +6,33 @@
 //   * v_mfma_f32_16x16x32_bf16; the WEIGHT fragment is fed as the MFMA "A" operand and the
 //     activation fragment as "B", so a lane ends up holding 4 consecutive output channels n of
 //     one row m -> 8-byte bf16x4 / 16-byte f32x4 epilogue stores along the contiguous NHWC axis.
-//   * 256 threads = 4 waves (2 along m x 2 along n); block tile 128 x BN x 64 with BN = 128 or
-//     160 (every SD-1.x channel count is a multiple of 160, so no n-tile is wasted).
-//   * operands staged global -> VGPR -> LDS (the conv gather needs per-lane addresses and zero
-//     fill at the image border), double-buffered: the next K-tile's global loads are issued
-//     before the MFMAs of the current one and written to the other LDS buffer afterwards, one
-//     barrier per K-tile.
-//   * LDS rows are 64 bf16 = 8 chunks of 16 B, chunk index XOR (row & 7): ds_read_b128 fragment
-//     reads and ds_write_b128 staging writes are both bank-conflict free.
+//   * two block shapes: 256 threads = 4 waves (2 x 2), tile 128 x BN x 64, two LDS stages, two
+//     blocks per CU; and 512 threads = 8 waves (4 x 2), tile 256 x BN x 64, three LDS stages, one
+//     block per CU (long K loops and the FF1+GEGLU launches, see launch_igemm).  BN = 128 or 160
+//     (every SD-1.x channel count is a multiple of 160, so no n-tile is wasted).
+//   * operands go global -> LDS by DMA (global_load_lds, 16 B per lane, no VGPR round trip and no
+//     ds_write).  A DMA instruction fills 8 rows x 128 B lane-linearly, so the bank swizzle is
+//     applied on the SOURCE side: slot p of row r receives chunk p ^ (r & 7), the same involution
+//     the ds_read_b128 fragment reads use (conflict-free).  Per-lane source pointers carry the conv
+//     gather: centre pixel + wave-uniform tap delta, a 9-bit tap mask and a zero page for the
+//     border / ragged rows -- no exec-mask branches.
+//   * the K loop is pipelined per 32-deep k-step: fragment reads of the next step, the pointer
+//     arithmetic of a later tile's DMA and its issue are all woven between the MFMAs of the
+//     current step (sched_group_barrier), one barrier per K-tile in mid-tile.  4-wave kernel: DMA
+//     one tile ahead, drained at the barrier.  8-wave kernel: ring of three stages, DMA two tiles
+//     ahead, counted vmcnt -- the queue never drains.
 //   * split-K (grid.y) for the low-resolution, weight-heavy layers: fp32 partial slabs + a
 //     reduce/epilogue kernel.
 #include <stdlib.h>
 
 #include "common.h"
 #include "kernels.h"
+
+// Build-time switches, MEASUREMENT ONLY (tools/build_variant.sh builds a side library with them; the
+// product library never defines any): GEMM_NODMA (K loop without operand traffic), GEMM_NOBAR (and
+// without the mid-tile barrier), GEMM_NOMFMA (operand traffic without the multiply),
+// GEMM_LOAD_NOLDS (same global loads into dead registers instead of LDS), GEMM_AUX_A / GEMM_AUX_W
+// (cache-policy bits of the LDS-DMA).  Their results are in DESIGN.md section 5, item 8.
 
 namespace {
 
@@ -514,15 +527,10 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
           }
           const int ol = wn * (ON / 2) + (j / 2) * 16 + fq * 4;      // output column inside the tile
           uint2 o;
-#ifdef GEGLU_SCALAR
-          o.x = pack_bf16x2(v[0] * gelu_erf_fast(g[0]), v[1] * gelu_erf_fast(g[1]));
-          o.y = pack_bf16x2(v[2] * gelu_erf_fast(g[2]), v[3] * gelu_erf_fast(g[3]));
-#else
           const f32x2 r0 = mul_gelu2((f32x2){v[0], v[1]}, (f32x2){g[0], g[1]});
           const f32x2 r1 = mul_gelu2((f32x2){v[2], v[3]}, (f32x2){g[2], g[3]});
           o.x = pack_bf16x2(r0[0], r0[1]);
           o.y = pack_bf16x2(r1[0], r1[1]);
-#endif
           *reinterpret_cast<uint2*>(sg + ml * CSG + ol) = o;
         }
       }
