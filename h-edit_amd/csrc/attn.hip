@@ -1,24 +1,26 @@
 // Attention for the SD UNet on MFMA (v_mfma_f32_32x32x16_bf16), with the Prompt-to-Prompt edits
 // applied inside the kernels so probabilities are never materialised in HBM.
 //
-// Common structure (per wave: 32 query rows, workgroup = 4 waves = 128 query rows):
+// Common structure (a wave works on groups of 32 query rows; workgroup = 4 waves):
 //   * "swapped" QK^T: S^T[kv][q] = mfma(A = K tile, B = Q^T) -> a lane owns ONE query column
 //     (q = lane & 31) and 16 of the 32 kv rows of the tile; the other 16 live in lane ^ 32.  Row
-//     max / row sum are in-register reductions + one cross-half shuffle.
+//     max / row sum are in-register reductions + one cross-half exchange.
 //   * P feeds the PV MFMA straight from registers: O^T[d][q] = mfma(A = V^T tile, B = P^T).  The
-//     B-operand wants 8 consecutive k per lane, a lane holds kv = (r&3) + 8(r>>2) + 4*half; since
-//     the contraction order over kv is free, the V^T fragment is simply read with the SAME
-//     permutation (two 8-byte LDS reads), so no cross-lane traffic is needed.
+//     B-operand wants 8 consecutive k per lane while a lane holds kv = (r&3) + 8(r>>2) + 4*half;
+//     the contraction order over kv is free, so either the V^T fragment is read with the SAME
+//     permutation (cross_attn: two 8-byte LDS reads) or the S^T rows are visited in a permuted
+//     order that makes the lane's 8 values consecutive (self_attn: one 16-byte read).
 //   * V arrives transposed (V^T[h*d + dd][b*N + token]) from a GEMM with swapped operands.
 //   * Q is pre-scaled by softmax_scale * log2(e) (folded into W_q), so exp2 is used directly.
 //
-// self_attn: flash / online softmax over 64-row KV tiles staged in LDS (registers prefetch the
-//   next tile).  P2P self-attention replacement (ptp_classes.py:194-200: P_tar <- P_src) needs no
-//   probabilities at all: the target row just uses the SOURCE row's Q and K (qk_src[b]).
+// self_attn: flash / online softmax over 64-row KV tiles, DMA-staged and software-pipelined (see
+//   the section comment below).  P2P self-attention replacement (ptp_classes.py:194-200:
+//   P_tar <- P_src) needs no probabilities at all: the target row just uses the SOURCE row's Q
+//   and K (qk_src[b]).
 // cross_attn: 77 (padded 96) keys, whole K/V^T in LDS, exact softmax.  For a (src,tar) pair the
 //   wave computes P_src, then P_new = P_src . A + bvec * P_tar with the per-step 96x96 mixing
 //   matrix on MFMA (Replace / Refine / Reweight and the cross_replace_alpha blend all fold into
-//   (A, bvec), see hedit/p2p/plan.py), accumulates the post-edit maps into the fp32 store when
+//   (A, bvec), see hedit/p2p/ptp_classes.py::_mix_tables), accumulates the post-edit maps into the fp32 store when
 //   asked, and finishes with P.V for both rows.
 #include "common.h"
 #include "kernels.h"
@@ -62,8 +64,10 @@ __device__ __forceinline__ bf16x8 read_perm_frag(const bf16_t* base, int row, in
 // block a lane has ~55 VALU instructions of softmax work (sub, exp2, max, bf16 pack) against
 // 3 + 4 MFMAs (d = 40), and a wave issues in order -- an MFMA queued behind a busy matrix pipe
 // blocks the VALU work after it.  So:
-//   * KV tiles go global -> LDS by DMA (global_load_lds, no staging VGPRs, no ds_write) into three
-//     stages, issued two tiles ahead; one barrier per tile.  Tiles are dense (no row padding): the
+//   * KV tiles go global -> LDS by DMA (global_load_lds, no staging VGPRs, no ds_write) into a ring
+//     of four stages (three for d >= 80, where four would cost the second workgroup per CU): the
+//     DMA of tile t+2 is issued when tile t is handed over and retired with a counted vmcnt, so a
+//     tile has two tiles of work to land (an LDS-DMA needs ~0.85 us under load); one barrier per tile.  Tiles are dense (no row padding): the
 //     source chunk each lane fetches is XOR-swizzled so that the b128 fragment reads are
 //     conflict-free for every head dim.
 //   * the work is cut into "units" (32 kv rows x 32 queries) and software-pipelined across them:
@@ -96,9 +100,17 @@ struct SelfCfg {
   static constexpr int V_ROWS = H::DT * 32;
   static constexpr int V_BYTES = V_ROWS * 128;
   static constexpr int STAGE = K_BYTES + V_BYTES;
-  static constexpr int TOTAL = 3 * STAGE;
   static constexpr int KI = DCH, VI = D / 8;           // 1 KiB DMA instructions per tile (K, V^T)
   static constexpr int TI = KI + VI, NI = (TI + 3) / 4;
+  // LDS ring: 4 stages (DMA two tiles ahead) when two workgroups of that still fit a CU, else 3
+#ifdef SA_NSTG3
+  static constexpr int NSTG = 3;
+#else
+  static constexpr int NSTG = 2 * 4 * STAGE <= 160 * 1024 ? 4 : 3;
+#endif
+  static constexpr int PD = NSTG - 2;                  // prefetch distance in KV tiles
+  static constexpr int DUMP = TI % 4 ? 4096 : 0;       // parking area for DMA slots without a chunk
+  static constexpr int TOTAL = NSTG * STAGE + DUMP;
   static constexpr int UT = 2 * QG;                    // units per KV tile
 };
 
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
   for (int i = tid; i < C::TOTAL / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   if (ONES) {
-    for (int i = tid; i < 3 * 64; i += 256)
+    for (int i = tid; i < C::NSTG * 64; i += 256)
       reinterpret_cast<bf16_t*>(smem + (i >> 6) * C::STAGE + C::K_BYTES + D * 128)[i & 63] = (bf16_t)0x3F80;
   }
 
@@ -143,36 +155,57 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
     }
   }
 
-  // ---- DMA plan: instruction i = wave + 4n moves 1 KiB (64 lanes x 16 B) of the tile
-  unsigned dma_off[C::NI];
+  // ---- DMA plan: instruction i = wave + 4n moves 1 KiB (64 lanes x 16 B) of the tile.  Everything
+  // that does not depend on the tile is fixed here -- per-lane source pointer of tile 0, the
+  // (wave-uniform) byte stride per tile and LDS target -- so that issuing a tile is three
+  // instructions per DMA and free of branches: a wave whose last slot has no chunk to fetch
+  // (TI % 4 != 0) re-fetches its previous chunk into a dump area behind the ring instead.
+  // Buffer addressing (base descriptor in SGPRs + 32-bit lane offset + scalar tile offset): the
+  // DMA needs no per-lane 64-bit pointer arithmetic at all and moves one address dword per lane
+  // instead of two.
+  unsigned dma_voff[C::NI];
+  int dma_step[C::NI], dma_dst[C::NI];
+  bool dma_is_k[C::NI];
+#if defined(__HIP_DEVICE_COMPILE__)     // (the resource type only exists in the device pass)
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.k + (long)bqk * p.N * p.ldk + h * D), (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.vt + (long)h * D * p.ldvt + (long)b * p.N), (short)0, 0x7fffffff, 0x00020000);
+#endif
 #pragma unroll
   for (int n = 0; n < C::NI; ++n) {
     const int i = wave + 4 * n;
-    if (i < C::KI) {
-      const int s = i * 64 + lane;
+    const bool real = i < C::TI;
+    const int ii = real ? i : i - 4;                  // the chunk a dump slot re-fetches
+    dma_is_k[n] = ii < C::KI;
+    if (ii < C::KI) {
+      const int s = ii * 64 + lane;
       const int row = s / C::DCH, cs = s - row * C::DCH;
-      dma_off[n] = (unsigned)(row * p.ldk + (cs ^ k_swz<D>(row)) * 8) * 2u;
+      dma_voff[n] = (unsigned)(row * p.ldk + (cs ^ k_swz<D>(row)) * 8) * 2u;
+      dma_step[n] = 128 * p.ldk;                      // bytes per 64 rows of K
+      dma_dst[n] = ii * 1024;
     } else {
-      const int s = (i - C::KI) * 64 + lane;
+      const int s = (ii - C::KI) * 64 + lane;
       const int row = s >> 3, cs = s & 7;
-      dma_off[n] = (unsigned)((long)row * p.ldvt + (cs ^ v_swz(row)) * 8) * 2u;
+      dma_voff[n] = (unsigned)(((long)row * p.ldvt + (cs ^ v_swz(row)) * 8) * 2);
+      dma_step[n] = 128;                              // bytes per 64 columns of V^T
+      dma_dst[n] = C::K_BYTES + (ii - C::KI) * 1024;
     }
+    if (!real) dma_dst[n] = -1;
   }
-  const char* const kbase = reinterpret_cast<const char*>(p.k + (long)bqk * p.N * p.ldk + h * D);
-  const char* const vbase = reinterpret_cast<const char*>(p.vt + (long)h * D * p.ldvt + (long)b * p.N);
-  const long kstep = 128L * p.ldk;   // bytes per 64-row KV tile
   auto dma_tile = [&](int t, int stage) __attribute__((always_inline)) {
     char* sb = smem + stage * C::STAGE;
 #pragma unroll
     for (int n = 0; n < C::NI; ++n) {
-      const int i = wave + 4 * n;
-      if (i < C::TI) {
-        const bool is_k = i < C::KI;
-        const char* src = (is_k ? kbase + t * kstep : vbase + t * 128) + dma_off[n];
-        char* dst = sb + (is_k ? i * 1024 : C::K_BYTES + (i - C::KI) * 1024);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      }
+      char* dst = dma_dst[n] >= 0 ? sb + dma_dst[n] : smem + C::NSTG * C::STAGE + wave * 1024;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (dma_is_k[n])
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (__attribute__((address_space(3))) void*)dst, 16, dma_voff[n], t * dma_step[n], 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (__attribute__((address_space(3))) void*)dst, 16, dma_voff[n], t * dma_step[n], 0, 0);
+#else
+      (void)dst;
+#endif
     }
   };
 
@@ -218,8 +251,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
   const int ntiles = p.N / 64;
   const int TU = ntiles * C::UT;
   __syncthreads();          // zero / ones fill done
-  dma_tile(0, 0);
-  if (ntiles > 1) dma_tile(1, 1);
+  for (int t = 0; t <= C::PD && t < ntiles; ++t) dma_tile(t, t);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
   // Lazy rescale: the running maximum (log2 domain) of a stream is only raised -- and O, l
@@ -249,7 +281,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
 
   // unit U -> (tile, sub, stream a, query group g)
   auto unit_tile = [&](int U) __attribute__((always_inline)) { return QG == 2 ? (U >> 2) : (U >> 1); };
-  auto stage_of = [&](int U) __attribute__((always_inline)) { return smem + (unit_tile(U) % 3) * C::STAGE; };
+  auto stage_of = [&](int U) __attribute__((always_inline)) { return smem + (unit_tile(U) % C::NSTG) * C::STAGE; };
 
   auto read_kf = [&](const char* st, int sub) __attribute__((always_inline)) {
 #pragma unroll
@@ -433,10 +465,26 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
 
   // tile hand-over before the block that first touches tile tn: everyone's DMA for it has landed,
   // and nobody reads tile tn-2 any more -> its stage takes tile tn+1
+  // DMA instructions this wave issues per tile (instruction i = wave + 4n < TI): the vmcnt that lets
+  // exactly one younger tile stay in flight
+  constexpr int my_dma = C::NI;
   auto hand_over = [&](int tn) __attribute__((always_inline)) {
     if (tn < ntiles) {
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      if (tn + 1 < ntiles) dma_tile(tn + 1, (tn + 1) % 3);
+#ifndef SA_NOBAR     // (SA_NOBAR / SA_NODMA: measurement-only builds, see tools/build_variant.sh)
+      if (C::PD == 2 && tn + 1 < ntiles) {
+        // tile tn has landed when at most the DMAs of tile tn+1 are outstanding
+        if (my_dma == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (my_dma == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (my_dma == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_barrier" ::: "memory");
+#endif
+#ifndef SA_NODMA
+      if (tn + C::PD < ntiles) dma_tile(tn + C::PD, (tn + C::PD) % C::NSTG);
+#endif
     }
   };
 
