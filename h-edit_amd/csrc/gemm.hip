@@ -94,11 +94,14 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
 
   // ---- per-thread staging state, fixed for the whole K loop.  Everything that can be decided
   // once is decided here so that the K loop issues (almost) nothing but loads, LDS traffic and
-  // MFMAs: out-of-range rows / padded taps read a 16-byte zero page through a pointer select
-  // (no exec-mask branches), the conv gather is "centre pixel pointer + wave-uniform tap delta"
-  // gated by a 9-bit tap mask.
-  const bf16_t* const zero_page = p.zeros;
-  const bf16_t* a_ptr[A_CH];
+  // MFMAs.  Operands are addressed through buffer descriptors (base in SGPRs + a 32-bit byte offset
+  // per lane + a wave-uniform scalar offset): the conv gather is "centre pixel offset + uniform
+  // tap delta" gated by a 9-bit tap mask, and an out-of-range row / padded tap simply gets an offset
+  // beyond the descriptor's size, which the hardware answers with zeros (no exec-mask branches, no
+  // 64-bit pointer arithmetic, one address dword per lane).
+  constexpr unsigned OOB = 0x80000000u;    // > any operand size accepted by gemm_launch
+  const bf16_t* const zero_page = p.zeros; // (the epilogue's residual prefetch still selects a pointer)
+  unsigned a_off[A_CH];
   unsigned a_mask[A_CH];     // conv: bit t = tap t is inside the image; linear: ~0 / 0
   int a_oy[A_CH], a_ox[A_CH];
   int a_lds[A_CH];
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     a_lds[i] = (wave * A_CH + i) * 1024;
     a_oy[i] = a_ox[i] = 0;
     if (MODE == 0) {
-      a_ptr[i] = ok ? p.A + (long)m * p.lda + c * 8 : zero_page;
+      a_off[i] = (unsigned)(((long)m * p.lda + c * 8) * 2);
       a_mask[i] = ok ? ~0u : 0u;
     } else {
       const int hw = p.Hout * p.Wout;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
           mk |= in << t;
         }
         a_mask[i] = mk;
-        a_ptr[i] = p.A + (((long)b * p.Hin + (oy >> 1)) * p.Win + (ox >> 1)) * p.Cin + c * 8;
+        a_off[i] = (unsigned)(((((long)b * p.Hin + (oy >> 1)) * p.Win + (ox >> 1)) * p.Cin + c * 8) * 2);
         a_oy[i] = oy & 1;
         a_ox[i] = ox & 1;
       } else {
@@ -149,12 +152,11 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
           mk |= in << t;
         }
         a_mask[i] = mk;
-        a_ptr[i] = p.A + (((long)b * p.Hin + cy) * p.Win + cx) * p.Cin + c * 8;
+        a_off[i] = (unsigned)(((((long)b * p.Hin + cy) * p.Win + cx) * p.Cin + c * 8) * 2);
       }
     }
   }
-  const bf16_t* w_ptr[W_CH];
-  bool w_ok[W_CH];
+  unsigned w_off[W_CH];      // out-of-range weight rows: OOB once and for all
   int w_lds[W_CH];
 #pragma unroll
   for (int i = 0; i < W_CH; ++i) {
@@ -163,23 +165,31 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     const int row = wg * 8 + (lane >> 3);
     const int c = (lane & 7) ^ (lane >> 3);
     const int n = n0 + row;
-    w_ok[i] = n < p.N;
     w_lds[i] = wg * 1024;
-    w_ptr[i] = p.W + (long)n * p.K + c * 8;
+    w_off[i] = n < p.N ? (unsigned)(((long)n * p.K + c * 8) * 2) : OOB;
   }
+#if defined(__HIP_DEVICE_COMPILE__)     // (the resource type only exists in the device pass)
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), (short)0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), (short)0, (int)p.w_bytes, 0x00020000);
+#endif
 
-  // direct-to-LDS DMA of one K-tile into stage `buf` (no VGPR round trip, no ds_write)
-  auto issue_glds = [&](int kt, int buf) __attribute__((always_inline)) {
-    char* sa = smem + buf * S::STAGE;
-    char* sw = sa + S::A_BYTES;
+  // The DMA of one K-tile in two halves, so each can be woven into a different MFMA group of the K
+  // loop: prep_dma computes the lane offsets of the A_CH activation chunks (tap mask -> offset or OOB;
+  // the weight offsets never change) and the two scalar offsets, fire_dma issues the A_CH + W_CH
+  // LDS-DMA instructions (M0 + buffer_load ... lds each) into stage `buf`.
+  // K-tile order.  linear: k0 = kt*64.  conv: the 9 taps of one 64-channel slab are visited back
+  // to back (tap = kt % 9, slab = kt / 9) so the shifted re-reads of the same input pixels are
+  // nine consecutive K-tiles apart at most -> they stay in L2.
+  struct DmaArgs {
+    unsigned a_voff[A_CH];
+    int a_soff, w_soff;       // wave-uniform, non-negative byte offsets
+  };
+  auto prep_dma = [&](int kt, DmaArgs& d) __attribute__((always_inline)) {
     int k0 = kt * BK;
     if (MODE == 0) {
 #pragma unroll
-      for (int i = 0; i < A_CH; ++i) {
-        const bf16_t* src = a_mask[i] ? a_ptr[i] + k0 : zero_page;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(sa + a_lds[i]), 16, 0, 0);
-      }
+      for (int i = 0; i < A_CH; ++i) d.a_voff[i] = a_mask[i] ? a_off[i] : OOB;
+      d.a_soff = k0 * 2;
     } else {
       const int tap = kt % 9;
       const int ci0 = (kt / 9) * BK;
@@ -190,87 +200,59 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
         for (int i = 0; i < A_CH; ++i) {
           const int fy = (a_oy[i] + dy) >> 1, fx = (a_ox[i] + dx) >> 1;      // in {-1, 0, +1}
           const bool ok = (a_mask[i] >> tap) & 1u;
-          const bf16_t* src = ok ? a_ptr[i] + (fy * p.Win + fx) * p.Cin + ci0 : zero_page;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(sa + a_lds[i]), 16, 0, 0);
+          d.a_voff[i] = ok ? a_off[i] + (unsigned)((fy * p.Win + fx) * p.Cin * 2) : OOB;
         }
+        d.a_soff = ci0 * 2;
       } else {
-        const long delta = ((long)dy * p.Win + dx) * p.Cin + ci0;
+        // the tap delta can be negative and the scalar offset of a buffer access is an unsigned
+        // addend outside the range check, so the delta goes into the lane offset (wrapping add)
+        const unsigned tapd = (unsigned)((dy * p.Win + dx) * p.Cin * 2);
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-          const bf16_t* src = ((a_mask[i] >> tap) & 1u) ? a_ptr[i] + delta : zero_page;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(sa + a_lds[i]), 16, 0, 0);
-        }
+        for (int i = 0; i < A_CH; ++i) d.a_voff[i] = ((a_mask[i] >> tap) & 1u) ? a_off[i] + tapd : OOB;
+        d.a_soff = ci0 * 2;
       }
     }
-#pragma unroll
-    for (int i = 0; i < W_CH; ++i) {
-      const bf16_t* src = w_ok[i] ? w_ptr[i] + k0 : zero_page;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sw + w_lds[i]), 16, 0, 0);
-    }
+    d.w_soff = k0 * 2;
   };
-
-  // the same DMA in two halves, so each can be woven into a different MFMA group of the K loop:
-  // prep_glds computes the A_CH + W_CH per-lane source pointers of K-tile kt (tap arithmetic,
-  // 64-bit adds, zero-page selects: VALU/SALU only), fire_glds issues the LDS-DMA instructions
-  // (M0 + global_load_lds each) into stage `buf`.
-  constexpr int NPTR = A_CH + W_CH;
-  auto prep_glds = [&](int kt, const bf16_t* (&src)[NPTR]) __attribute__((always_inline)) {
-    int k0 = kt * BK;
-    if (MODE == 0) {
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) src[i] = a_mask[i] ? a_ptr[i] + k0 : zero_page;
-    } else {
-      const int tap = kt % 9;
-      const int ci0 = (kt / 9) * BK;
-      k0 = tap * p.Cin + ci0;
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      if (MODE == 3) {
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-          const int fy = (a_oy[i] + dy) >> 1, fx = (a_ox[i] + dx) >> 1;      // in {-1, 0, +1}
-          const bool ok = (a_mask[i] >> tap) & 1u;
-          src[i] = ok ? a_ptr[i] + (fy * p.Win + fx) * p.Cin + ci0 : zero_page;
-        }
-      } else {
-        const long delta = ((long)dy * p.Win + dx) * p.Cin + ci0;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) src[i] = ((a_mask[i] >> tap) & 1u) ? a_ptr[i] + delta : zero_page;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < W_CH; ++i) src[A_CH + i] = w_ok[i] ? w_ptr[i] + k0 : zero_page;
-  };
-  auto fire_glds = [&](int buf, const bf16_t* (&src)[NPTR]) __attribute__((always_inline)) {
-    char* sa = smem + buf * S::STAGE;
-    char* sw = sa + S::A_BYTES;
 #ifndef GEMM_AUX_A
 #define GEMM_AUX_A 0
 #endif
 #ifndef GEMM_AUX_W
 #define GEMM_AUX_W 0
 #endif
+  auto fire_dma = [&](int buf, const DmaArgs& d) __attribute__((always_inline)) {
+    char* sa = smem + buf * S::STAGE;
+    char* sw = sa + S::A_BYTES;
+#if defined(__HIP_DEVICE_COMPILE__)
 #ifdef GEMM_LOAD_NOLDS
     // timing experiment only: the same global traffic, landing in dead registers instead of LDS
 #pragma unroll
-    for (int i = 0; i < NPTR; ++i) {
-      u32x4 t;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t) : "v"(src[i]) : "memory");
-      (void)t;
+    for (int i = 0; i < A_CH; ++i) {
+      u32x4 t = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, d.a_voff[i], d.a_soff, 0));
+      asm volatile("" ::"v"(t));
+    }
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i) {
+      u32x4 t = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[i], d.w_soff, 0));
+      asm volatile("" ::"v"(t));
     }
     (void)sa; (void)sw;
 #else
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                       (__attribute__((address_space(3))) void*)(sa + a_lds[i]), 16, 0, GEMM_AUX_A);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(sa + a_lds[i]), 16, d.a_voff[i], d.a_soff, 0, GEMM_AUX_A);
 #pragma unroll
     for (int i = 0; i < W_CH; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[A_CH + i],
-                                       (__attribute__((address_space(3))) void*)(sw + w_lds[i]), 16, 0, GEMM_AUX_W);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(sw + w_lds[i]), 16, w_off[i], d.w_soff, 0, GEMM_AUX_W);
 #endif
+#else
+    (void)sa; (void)sw; (void)d;
+#endif
+  };
+  auto issue_glds = [&](int kt, int buf) __attribute__((always_inline)) {
+    DmaArgs d;
+    prep_dma(kt, d);
+    fire_dma(buf, d);
   };
 
   f32x4 acc[MI][NI];
@@ -305,7 +287,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     constexpr int NDMA = A_CH + W_CH;
     const int nk = kt_end - kt_begin;
     bf16x8 xa[MI], wa[NI], xb[MI], wb[NI];
-    const bf16_t* nsrc[NPTR];
+    DmaArgs nsrc;
     auto read_frags = [&](int buf, int ks, bf16x8 (&xf)[MI], bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
       const char* pa = smem + buf * S::STAGE + (a_rd ^ (ks << 6));
       const char* pw = smem + buf * S::STAGE + S::A_BYTES + (w_rd ^ (ks << 6));
@@ -334,7 +316,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       const int nx = cur == 2 ? 0 : cur + 1;
       read_frags(cur, 1, xb, wb);
       __builtin_amdgcn_s_setprio(1);
-      prep_glds(kt_begin + j + 3, nsrc);
+      prep_dma(kt_begin + j + 3, nsrc);
       mfmas(xa, wa);
 #pragma unroll
       for (int r = 0; r < MI * NI / 2; ++r) {
@@ -345,7 +327,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA) : "memory");
       __builtin_amdgcn_s_setprio(1);
       read_frags(nx, 0, xa, wa);
-      fire_glds(cur, nsrc);
+      fire_dma(cur, nsrc);
       mfmas(xb, wb);
 #pragma unroll
       for (int r = 0; r < MI * NI / 2; ++r) {
@@ -408,14 +390,14 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     };
     // Steady state of one K-tile i (two MFMA groups of MI*NI, one barrier between them):
     //   group 1 = MFMAs of k-step 0, with the fragment reads of k-step 1 in front and the source
-    //             pointers of tile i+2 (prep_glds: ~10 VALU/SALU per DMA) woven between the MFMAs;
+    //             pointers of tile i+2 (prep_dma: one select per activation chunk) woven between the MFMAs;
     //   barrier  = tile i+1 has landed everywhere, stage `cur` is in registers everywhere;
     //   group 2 = MFMAs of k-step 1, with the 9 LDS-DMA issues of tile i+2 (into stage cur) and the
     //             fragment reads of tile i+1's k-step 0 woven in.
     // The ~130 non-MFMA instructions a tile's DMA needs thereby sit in issue slots the 16-cycle
     // MFMAs leave free instead of forming a serial phase (they were ~45 % of a wave's K-tile time).
     // sched_group_barrier spells the interleave out for the scheduler.
-    const bf16_t* nsrc[NPTR];
+    DmaArgs nsrc;
     auto weave_prep = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int r = 0; r < MI * NI / 2; ++r) {
@@ -461,7 +443,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       const int cur = i & 1;
       read_frags(cur, 1, xb, wb);
       __builtin_amdgcn_s_setprio(1);
-      prep_glds(kt_begin + i + 2, nsrc);
+      prep_dma(kt_begin + i + 2, nsrc);
       mfmas(xa, wa);
       weave_prep();
       __builtin_amdgcn_s_setprio(0);
@@ -471,7 +453,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       __builtin_amdgcn_s_setprio(1);
       read_frags(cur ^ 1, 0, xa, wa);
 #ifndef GEMM_NODMA
-      fire_glds(cur, nsrc);
+      fire_dma(cur, nsrc);
 #endif
       mfmas(xb, wb);
       weave_fire();
@@ -742,6 +724,17 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
   ARG_CHECK(p.mode >= 0 && p.mode <= 3, "gemm: mode");
   if (p.mode != 0) ARG_CHECK(p.Cin % BK == 0 && p.K == 9 * p.Cin, "gemm: conv needs Cin % 64 == 0 and K = 9 Cin");
   ARG_CHECK(p.ldc % 4 == 0 && (p.residual == nullptr || p.ldr % 4 == 0), "gemm: ldc/ldr alignment");
+  {
+    // operand extents for the buffer descriptors; lane offsets are 32-bit and offsets >= 2^31 mean
+    // "zero fill", so an operand must stay below 2 GiB (the largest here: 80 rows x 4096 x 1280 x 2 B
+    // = 0.84 GB).  Split a launch over M if that is ever exceeded.
+    const double a_b = p.mode == 0 ? (double)p.M * p.lda * 2.0
+                                   : (double)(p.M / ((long)p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * 2.0;
+    const double w_b = (double)p.N * p.K * 2.0;
+    ARG_CHECK(a_b < 2040.0 * 1048576.0 && w_b < 2040.0 * 1048576.0, "gemm: operand larger than 2 GiB");
+    p.a_bytes = (unsigned)a_b;
+    p.w_bytes = (unsigned)w_b;
+  }
   const int kt = p.K / BK;
   if (splits < 1) splits = 1;
   if (splits > kt) splits = kt;

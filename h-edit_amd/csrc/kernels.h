@@ -18,7 +18,8 @@ struct GemmParams {
   float* partial;    // set by gemm_launch
   int splits, kt_per_split;
   int n_fastest;     // tile order, set by gemm_launch
-  const bf16_t* zeros;   // 16-byte-aligned zero page (>= 16 B), set by gemm_launch
+  const bf16_t* zeros;   // 16-byte-aligned zero page (>= 16 B), set by gemm_launch (residual prefetch of ragged tiles)
+  unsigned a_bytes, w_bytes;   // sizes of the A and W operands for the buffer descriptors, set by gemm_launch
   int geglu;             // FF1: rows interleaved (value16|gate16), output [M][N/2] = v * gelu(g)
   int asym;              // mode 2 only: 1 = pad (0,1,0,1) instead of 1 all round (the VAE encoder's
                          // Downsample2D(padding=0): taps at rows 2oy .. 2oy+2)
