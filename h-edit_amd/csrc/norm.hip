@@ -194,6 +194,58 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   }
 }
 
+// Narrow rows (C <= 320): a whole wave per row would leave 24+ of its 64 lanes idle.  Here 8 lanes
+// share a row (5 x 16-byte chunks each at C = 320, consecutive lanes on consecutive chunks = one
+// 128-byte line per load), a wave normalises 8 rows, and the two reductions stay inside the 8-lane
+// groups.  Same arithmetic order per row as layernorm_kernel up to the reduction tree.
+constexpr int LNN_MAXV = 5;
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               long rows, int C, float eps) {
+  const int l8 = threadIdx.x & 7;
+  const long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool live = row < rows;
+  const int CV = C / 8, NV = CV / 8;       // chunks per row, chunks per lane
+  float f[LNN_MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < LNN_MAXV; ++v) {
+    if (v < NV && live) {
+      uint4 u = *reinterpret_cast<const uint4*>(x + row * C + (l8 + v * 8) * 8);
+      unpack8(u, f[v]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += f[v][j];
+    }
+  }
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int v = 0; v < LNN_MAXV; ++v) {
+    if (v < NV && live) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float d = f[v][j] - mean; q += d * d; }
+    }
+  }
+  q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+  const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int v = 0; v < LNN_MAXV; ++v) {
+    if (v < NV && live) {
+      const int cv = l8 + v * 8;
+      const float4* g4 = reinterpret_cast<const float4*>(gamma + cv * 8);
+      const float4* b4 = reinterpret_cast<const float4*>(beta + cv * 8);
+      float4 g0 = g4[0], g1 = g4[1], b0 = b4[0], b1 = b4[1];
+      float o[8];
+      o[0] = (f[v][0] - mean) * rstd * g0.x + b0.x; o[1] = (f[v][1] - mean) * rstd * g0.y + b0.y;
+      o[2] = (f[v][2] - mean) * rstd * g0.z + b0.z; o[3] = (f[v][3] - mean) * rstd * g0.w + b0.w;
+      o[4] = (f[v][4] - mean) * rstd * g1.x + b1.x; o[5] = (f[v][5] - mean) * rstd * g1.y + b1.y;
+      o[6] = (f[v][6] - mean) * rstd * g1.z + b1.z; o[7] = (f[v][7] - mean) * rstd * g1.w + b1.w;
+      *reinterpret_cast<uint4*>(y + row * C + cv * 8) = pack8(o);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ GEGLU: y = h * gelu(g), x = [h | g]
 __global__ __launch_bounds__(256) void geglu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long rows, int inner) {
   const int IV = inner / 8;
@@ -434,6 +486,11 @@ int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float
 int layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, long rows, int C,
                      float eps, hipStream_t st) {
   ARG_CHECK(C % 8 == 0 && C / 8 <= 64 * LN_MAXV, "layernorm: C");
+  if (C % 64 == 0 && C / 64 <= LNN_MAXV) {     // 8 lanes per row
+    hipLaunchKernelGGL(layernorm_narrow_kernel, dim3(cdiv(rows, 32)), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps);
+    LAUNCH_CHECK();
+    return HEDIT_OK;
+  }
   hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps);
   LAUNCH_CHECK();
   return HEDIT_OK;
