@@ -45,3 +45,22 @@ def test_scheduler_kwargs(tmp_path):
     with open(tmp_path / "scheduler_config.json", "w") as f:
         json.dump(dict(beta_start=0.001, steps_offset=1, skip_prk_steps=True), f)
     assert CK.scheduler_kwargs(str(tmp_path)) == dict(beta_start=0.001, steps_offset=1)
+
+
+def test_driver_flags_match_the_reference_cli():
+    """h-edit_amd/main_p2p.py keeps the flag names and defaults of the reference driver
+    (text-guided/main_p2p.py:38-70); the additions are separate flags."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hedit_main_p2p_cli", os.path.join(ROOT, "h-edit_amd", "main_p2p.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    a = vars(m.build_parser().parse_args([]))
+    reference_defaults = dict(device_num=0, data_path="./PIE_Bench_Data", output_path="./results/p2p",
+                              edit_category_list=[str(i) for i in range(10)], mode="h_edit_R_p2p",
+                              num_diffusion_steps=50, skip=0, eta=1.0, cfg_src=1.0, cfg_src_edit=5.0, cfg_tar=7.5,
+                              implicit=False, optimization_steps=1, weight_reconstruction=0.1, xa=0.4, sa=0.35)
+    for k, v in reference_defaults.items():
+        assert a[k] == v, k
+    assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed"}
+    b = vars(m.build_parser().parse_args(["--implicit", "--mode", "h_edit_D_p2p", "--eta", "0.0", "--edit_category_list", "0", "3"]))
+    assert b["implicit"] is True and b["eta"] == 0.0 and b["edit_category_list"] == ["0", "3"]
