@@ -304,7 +304,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   const int ctx_dim = f.h->cfg.cross_attention_dim;
   const size_t M = (size_t)B * N;
   const hedit_p2p_plan* pl = (f.plan && f.plan->mode > 0) ? f.plan : nullptr;
-  bf16_t *xn, *t0, *tn, *qk, *vt, *ao, *t1, *q2, *k2, *vt2, *t2, *hf, *gf, *t3, *y;
+  bf16_t *xn, *t0, *tn, *qk, *vt, *ao, *t1, *q2, *k2, *vt2, *t2, *gf, *t3, *y;
 
   TRY(aalloc(f, &xn, M * C));
   TRY(groupnorm(f, x, xn, a.gn_g, a.gn_b, N, C, 1e-6f, 0));
@@ -376,7 +376,6 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   // ---- GEGLU feed-forward
   TRY(aalloc(f, &tn, M * C));
   { ProfScope ps(f, PK_NORM, 0.0); RUN(f, layernorm_launch(t2, tn, a.ln3g, a.ln3b, (long)M, C, 1e-5f, f.st)); }
-  (void)hf;
   TRY(aalloc(f, &gf, M * 4 * C));
   {
     GemmParams gp{};
