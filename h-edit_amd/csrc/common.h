@@ -120,4 +120,24 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = bf16_to_f32((bf16_t)(v.x & 0xffff)); f[1] = bf16_to_f32((bf16_t)(v.x >> 16));
+  f[2] = bf16_to_f32((bf16_t)(v.y & 0xffff)); f[3] = bf16_to_f32((bf16_t)(v.y >> 16));
+  f[4] = bf16_to_f32((bf16_t)(v.z & 0xffff)); f[5] = bf16_to_f32((bf16_t)(v.z >> 16));
+  f[6] = bf16_to_f32((bf16_t)(v.w & 0xffff)); f[7] = bf16_to_f32((bf16_t)(v.w >> 16));
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+  v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+  return v;
+}
+
+static inline int ew_grid(long work_items) {
+  long g = (work_items + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

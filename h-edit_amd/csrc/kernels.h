@@ -39,7 +39,8 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st);
 // GroupNorm over NHWC bf16 [B][HW][C] with G groups; deterministic two-stage statistics.
 size_t groupnorm_ws_bytes(int B, int HW, int C);
 int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B,
-                     int HW, int C, int G, float eps, int silu, float* ws, hipStream_t st);
+                     int HW, int C, int G, float eps, int silu, float* ws, hipStream_t st,
+                     float* stats = nullptr);   // stats: optional [B][G][2] (mean, rstd) for the backward pass
 int layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, long rows,
                      int C, float eps, hipStream_t st);
 int geglu_launch(const bf16_t* x, bf16_t* y, long rows, int inner, hipStream_t st);
@@ -67,6 +68,24 @@ int pack_linear_launch(const float* w, bf16_t* out, long n, float scale, hipStre
 int pack_conv3x3_launch(const float* w_oihw, bf16_t* out, int O, int I, hipStream_t st);
 // GEGLU row interleave: out row t*32+u <- in row (u<16 ? t*16+u : half + t*16+u-16); K = 1 for the bias
 int pack_geglu_rows_launch(const float* w, bf16_t* out_bf16, float* out_f32, int rows, int K, hipStream_t st);
+
+// ---------------------------------------------------------------- grad.hip (decoder input-gradient pieces)
+// GroupNorm(+SiLU) backward: x = the forward input, stats = (mean, rstd) [B][G][2] saved by
+// groupnorm_launch, dy = gradient w.r.t. the output; dx = input gradient (+ add, if given)
+size_t groupnorm_bwd_ws_bytes(int B, int HW, int C);
+int groupnorm_bwd_launch(const bf16_t* x, const bf16_t* dy, const bf16_t* add, bf16_t* dx, const float* gamma,
+                         const float* beta, const float* stats, int B, int HW, int C, int G, int silu, float* ws,
+                         hipStream_t st);
+// ds = scale * p * (dp - rowsum(dp * p))
+int softmax_bwd_launch(const bf16_t* p, const float* dp, bf16_t* ds, long rows, int N, float scale, hipStream_t st);
+int transpose_bf16_launch(const bf16_t* src, bf16_t* dst, int R, int C, hipStream_t st);   // [R][C] -> [C][R]
+// du [B][2H][2W][C] -> dx [B][H][W][C]: backward of the 2x nearest upsample
+int sum2x2_launch(const bf16_t* du, bf16_t* dx, int B, int H, int W, int C, hipStream_t st);
+// weights of the input-gradient GEMMs: conv3x3 OIHW -> bf16 [I][9][O] taps flipped; linear [O][I] -> bf16 [I][O];
+// k x k OIHW fp32 -> IOHW fp32 taps flipped
+int pack_conv3x3_dgrad_launch(const float* w_oihw, bf16_t* out, int O, int I, hipStream_t st);
+int pack_linear_t_launch(const float* w, bf16_t* out, int O, int I, hipStream_t st);
+int flip_oihw_launch(const float* w, float* out, int O, int I, int k, hipStream_t st);
 
 // ---------------------------------------------------------------- attn.hip
 struct SelfAttnParams {

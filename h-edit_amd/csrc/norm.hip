@@ -6,18 +6,6 @@
 
 namespace {
 
-__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
-  f[0] = bf16_to_f32((bf16_t)(v.x & 0xffff)); f[1] = bf16_to_f32((bf16_t)(v.x >> 16));
-  f[2] = bf16_to_f32((bf16_t)(v.y & 0xffff)); f[3] = bf16_to_f32((bf16_t)(v.y >> 16));
-  f[4] = bf16_to_f32((bf16_t)(v.z & 0xffff)); f[5] = bf16_to_f32((bf16_t)(v.z >> 16));
-  f[6] = bf16_to_f32((bf16_t)(v.w & 0xffff)); f[7] = bf16_to_f32((bf16_t)(v.w >> 16));
-}
-__device__ __forceinline__ uint4 pack8(const float* f) {
-  uint4 v;
-  v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
-  v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
-  return v;
-}
 
 // ------------------------------------------------------------------ GroupNorm
 // stage 1: per (batch, pixel-slab) partial sums per group.  Threads are laid out as
@@ -89,7 +77,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
 // summation order), then per-channel scale & shift for this batch item
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ ss,
-                                                          int HW, int C, int G, int nslab, float eps) {
+                                                          int HW, int C, int G, int nslab, float eps,
+                                                          float* __restrict__ stats) {
   __shared__ float mean[64], rstd[64];
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -109,6 +98,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
       var = var < 0.f ? 0.f : var;
       mean[g] = m;
       rstd[g] = rsqrtf(var + eps);
+      if (stats) *reinterpret_cast<float2*>(stats + ((long)b * G + g) * 2) = make_float2(m, rstd[g]);
     }
   }
   __syncthreads();
@@ -435,13 +425,6 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* __restrict_
   }
 }
 
-inline int ew_grid(long work_items) {
-  long g = (work_items + 255) / 256;
-  if (g > 8192) g = 8192;
-  if (g < 1) g = 1;
-  return (int)g;
-}
-
 int gn_nslab(int B, int HW, int C) {
   const int CV = C / 8;
   const int R = CV <= 256 ? 256 / CV : 1;
@@ -462,7 +445,7 @@ size_t groupnorm_ws_bytes(int B, int HW, int C) {
 }
 
 int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B, int HW,
-                     int C, int G, float eps, int silu, float* ws, hipStream_t st) {
+                     int C, int G, float eps, int silu, float* ws, hipStream_t st, float* stats) {
   ARG_CHECK(C % 8 == 0 && C % G == 0 && G <= 64, "groupnorm: C % 8, C % G, G <= 64");
   ARG_CHECK(C / 8 <= 256 * GN_MAXV, "groupnorm: C too large");
   const int nslab = gn_nslab(B, HW, C);
@@ -475,7 +458,7 @@ int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, B), dim3(256), lds, st, x, part, HW, C, G, nslab);
   LAUNCH_CHECK();
   // partial buffer is indexed with stride G (<=64 reserved)
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, gamma, beta, ss, HW, C, G, nslab, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, gamma, beta, ss, HW, C, G, nslab, eps, stats);
   LAUNCH_CHECK();
   const long total_v = (long)B * HW * CV;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(total_v)), dim3(256), 0, st, x, y, ss, total_v, HW, C, silu);

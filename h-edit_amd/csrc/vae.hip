@@ -40,18 +40,24 @@ struct VSlot {
   bool loaded;
   int ndim;
   int dims[4];
+  // input-gradient twin (decoder only), filled by the same hedit_vae_load call:
+  // 0 none, 1 bf16 [I][O], 2 bf16 [I][9][O] taps flipped, 3 fp32 IOHW taps flipped
+  int tkind = 0;
+  void* tdst = nullptr;
 };
 
 struct VRes {
   int cin, cout;
   float *n1g, *n1b, *n2g, *n2b, *c1b, *c2b, *sc_b;
   bf16_t *conv1, *conv2, *sc_w;
+  bf16_t *conv1_t = nullptr, *conv2_t = nullptr, *sc_t = nullptr;   // input-gradient weights (decoder)
 };
 
 struct VAttn {
   int C;
   float *gn_g, *gn_b, *q_b, *k_b, *v_b, *o_b;
   bf16_t *w_q, *w_k, *w_v, *w_o;
+  bf16_t *w_q_t = nullptr, *w_k_t = nullptr, *w_v_t = nullptr, *w_o_t = nullptr;
 };
 
 struct VMid {
@@ -62,6 +68,7 @@ struct VMid {
 struct VStage {
   std::vector<VRes> res;
   bf16_t* samp_w = nullptr;   // down: stride-2 conv; up: conv after the 2x nearest upsample
+  bf16_t* samp_t = nullptr;   // up: its input-gradient weight
   float* samp_b = nullptr;
   int ch = 0;
 };
@@ -86,6 +93,9 @@ struct hedit_vae {
   bf16_t* d_out_w = nullptr;
   std::vector<VStage> up;
   VMid d_mid;
+  // input-gradient twins of the decoder's head / tail weights, and a zero bias vector
+  float *pq_t = nullptr, *d_out_t = nullptr, *zero_bias = nullptr;
+  bf16_t* d_in_t = nullptr;
 };
 
 namespace {
@@ -128,45 +138,61 @@ bf16_t* conv3(hedit_vae* h, const std::string& name, int O, int I) {
   return d;
 }
 
-VRes make_res(hedit_vae* h, const std::string& pre, int cin, int cout) {
+// attach an input-gradient twin to the slot just added
+template <class T>
+T* twin(hedit_vae* h, int tkind, size_t n) {
+  T* d = dalloc<T>(h, n);
+  h->slots.back().tkind = tkind;
+  h->slots.back().tdst = d;
+  return d;
+}
+
+VRes make_res(hedit_vae* h, const std::string& pre, int cin, int cout, bool grad = false) {
   VRes r{};
   r.cin = cin; r.cout = cout;
   r.n1g = vec(h, pre + ".norm1.weight", cin);
   r.n1b = vec(h, pre + ".norm1.bias", cin);
   r.conv1 = conv3(h, pre + ".conv1.weight", cout, cin);
+  if (grad) r.conv1_t = twin<bf16_t>(h, 2, (size_t)cout * cin * 9);
   r.c1b = vec(h, pre + ".conv1.bias", cout);
   r.n2g = vec(h, pre + ".norm2.weight", cout);
   r.n2b = vec(h, pre + ".norm2.bias", cout);
   r.conv2 = conv3(h, pre + ".conv2.weight", cout, cout);
+  if (grad) r.conv2_t = twin<bf16_t>(h, 2, (size_t)cout * cout * 9);
   r.c2b = vec(h, pre + ".conv2.bias", cout);
   if (cin != cout) {
     r.sc_w = lin(h, pre + ".conv_shortcut.weight", cout, cin, true);
+    if (grad) r.sc_t = twin<bf16_t>(h, 1, (size_t)cout * cin);
     r.sc_b = vec(h, pre + ".conv_shortcut.bias", cout);
   }
   return r;
 }
 
-VAttn make_attn(hedit_vae* h, const std::string& pre, int C) {
+VAttn make_attn(hedit_vae* h, const std::string& pre, int C, bool grad = false) {
   VAttn a{};
   a.C = C;
   a.gn_g = vec(h, pre + ".group_norm.weight", C);
   a.gn_b = vec(h, pre + ".group_norm.bias", C);
   a.w_q = lin(h, pre + ".to_q.weight", C, C);
+  if (grad) a.w_q_t = twin<bf16_t>(h, 1, (size_t)C * C);
   a.q_b = vec(h, pre + ".to_q.bias", C);
   a.w_k = lin(h, pre + ".to_k.weight", C, C);
+  if (grad) a.w_k_t = twin<bf16_t>(h, 1, (size_t)C * C);
   a.k_b = vec(h, pre + ".to_k.bias", C);      // loaded for completeness; softmax-invariant (see header)
   a.w_v = lin(h, pre + ".to_v.weight", C, C);
+  if (grad) a.w_v_t = twin<bf16_t>(h, 1, (size_t)C * C);
   a.v_b = vec(h, pre + ".to_v.bias", C);
   a.w_o = lin(h, pre + ".to_out.0.weight", C, C);
+  if (grad) a.w_o_t = twin<bf16_t>(h, 1, (size_t)C * C);
   a.o_b = vec(h, pre + ".to_out.0.bias", C);
   return a;
 }
 
-VMid make_mid(hedit_vae* h, const std::string& pre, int C) {
+VMid make_mid(hedit_vae* h, const std::string& pre, int C, bool grad = false) {
   VMid m;
-  m.r0 = make_res(h, pre + ".resnets.0", C, C);
-  m.at = make_attn(h, pre + ".attentions.0", C);
-  m.r1 = make_res(h, pre + ".resnets.1", C, C);
+  m.r0 = make_res(h, pre + ".resnets.0", C, C, grad);
+  m.at = make_attn(h, pre + ".attentions.0", C, grad);
+  m.r1 = make_res(h, pre + ".resnets.1", C, C, grad);
   return m;
 }
 
@@ -225,26 +251,53 @@ int conv3x3(VF& f, const bf16_t* X, int Hin, int Win, int Cin, const bf16_t* W, 
   return run_gemm(f, p);
 }
 
-int groupnorm(VF& f, const bf16_t* x, bf16_t* y, const float* g, const float* b, int HW, int C, int silu) {
-  float* ws;
+// stats: if non-null, *stats receives a kept [B][G][2] (mean, rstd) buffer for the backward pass
+int groupnorm(VF& f, const bf16_t* x, bf16_t* y, const float* g, const float* b, int HW, int C, int silu,
+              float** stats = nullptr) {
+  float *ws, *sb = nullptr;
+  if (stats) {
+    TRY(aalloc(f, &sb, (size_t)f.B * 64 * 2));
+    *stats = sb;
+  }
   TRY(aalloc(f, &ws, groupnorm_ws_bytes(f.B, HW, C) / sizeof(float)));
-  RUN(f, groupnorm_launch(x, y, g, b, f.B, HW, C, f.h->cfg.norm_num_groups, 1e-6f, silu, ws, f.st));
+  RUN(f, groupnorm_launch(x, y, g, b, f.B, HW, C, f.h->cfg.norm_num_groups, 1e-6f, silu, ws, f.st, sb));
   f.ar.free(ws);
   return HEDIT_OK;
 }
 
+// what the backward pass needs from a forward block (all buffers stay allocated in the arena)
+struct ResRec {
+  const VRes* r;
+  const bf16_t* x;
+  bf16_t* h1;
+  float *st1, *st2;
+  int H, W;
+};
+struct AttnRec {
+  const VAttn* a;
+  const bf16_t* x;
+  bf16_t *xn, *q, *k;
+  float* st;
+  int H, W;
+};
+
 // x [M][cin] -> *out [M][cout] (allocated here; x is NOT freed)
-int resblock(VF& f, const VRes& r, const bf16_t* x, int H, int W, bf16_t** out) {
+int resblock(VF& f, const VRes& r, const bf16_t* x, int H, int W, bf16_t** out, ResRec* rec = nullptr) {
   const size_t M = (size_t)f.B * H * W;
   bf16_t *a1, *h1, *a2, *sc = nullptr, *y;
+  if (rec) {
+    // kept buffers first, so the temporaries freed below do not fragment around them
+    TRY(aalloc(f, &h1, M * r.cout));
+    *rec = ResRec{&r, x, h1, nullptr, nullptr, H, W};
+  }
   TRY(aalloc(f, &a1, M * r.cin));
-  TRY(groupnorm(f, x, a1, r.n1g, r.n1b, H * W, r.cin, 1));
-  TRY(aalloc(f, &h1, M * r.cout));
+  TRY(groupnorm(f, x, a1, r.n1g, r.n1b, H * W, r.cin, 1, rec ? &rec->st1 : nullptr));
+  if (!rec) TRY(aalloc(f, &h1, M * r.cout));
   TRY(conv3x3(f, a1, H, W, r.cin, r.conv1, r.cout, r.c1b, nullptr, h1, 1));
   f.ar.free(a1);
   TRY(aalloc(f, &a2, M * r.cout));
-  TRY(groupnorm(f, h1, a2, r.n2g, r.n2b, H * W, r.cout, 1));
-  f.ar.free(h1);
+  TRY(groupnorm(f, h1, a2, r.n2g, r.n2b, H * W, r.cout, 1, rec ? &rec->st2 : nullptr));
+  if (!rec) f.ar.free(h1);
   const bf16_t* res = x;
   if (r.sc_w) {
     TRY(aalloc(f, &sc, M * r.cout));
@@ -260,13 +313,13 @@ int resblock(VF& f, const VRes& r, const bf16_t* x, int H, int W, bf16_t** out) 
 }
 
 // single-head attention over the T = H*W tokens of every image; x [B*T][C] -> *out (x is NOT freed)
-int attention(VF& f, const VAttn& a, const bf16_t* x, int H, int W, bf16_t** out) {
+int attention(VF& f, const VAttn& a, const bf16_t* x, int H, int W, bf16_t** out, AttnRec* rec = nullptr) {
   const int C = a.C, T = H * W, B = f.B;
   const size_t M = (size_t)B * T;
   bf16_t *xn, *q, *k, *vt, *pb, *o, *y;
-  float *s, *ob;
+  float *s, *ob, *st = nullptr;
   TRY(aalloc(f, &xn, M * C));
-  TRY(groupnorm(f, x, xn, a.gn_g, a.gn_b, T, C, 0));
+  TRY(groupnorm(f, x, xn, a.gn_g, a.gn_b, T, C, 0, rec ? &st : nullptr));
   TRY(aalloc(f, &q, M * C));
   TRY(linear(f, xn, (int)M, C, a.w_q, C, a.q_b, nullptr, q, C));
   TRY(aalloc(f, &k, M * C));
@@ -295,7 +348,12 @@ int attention(VF& f, const VAttn& a, const bf16_t* x, int H, int W, bf16_t** out
       TRY(run_gemm(f, p));
     }
   }
-  f.ar.free(pb); f.ar.free(s); f.ar.free(vt); f.ar.free(k); f.ar.free(q); f.ar.free(xn);
+  f.ar.free(pb); f.ar.free(s); f.ar.free(vt);
+  if (rec) {
+    *rec = AttnRec{&a, x, xn, q, k, st, H, W};
+  } else {
+    f.ar.free(k); f.ar.free(q); f.ar.free(xn);
+  }
   // output bias with the value bias folded in: o_b' = o_b + W_o . v_b
   TRY(aalloc(f, &ob, (size_t)C));
   RUN(f, gemv_launch(a.w_o, a.v_b, a.o_b, nullptr, ob, C, C, 0, f.st));
@@ -306,24 +364,149 @@ int attention(VF& f, const VAttn& a, const bf16_t* x, int H, int W, bf16_t** out
   return HEDIT_OK;
 }
 
-int mid(VF& f, const VMid& m, bf16_t** x, int H, int W) {
+struct MidRec {
+  ResRec r0, r1;
+  AttnRec at;
+};
+
+int mid(VF& f, const VMid& m, bf16_t** x, int H, int W, MidRec* rec = nullptr) {
   bf16_t *a, *b, *c;
-  TRY(resblock(f, m.r0, *x, H, W, &a));
-  f.ar.free(*x);
-  TRY(attention(f, m.at, a, H, W, &b));
-  f.ar.free(a);
-  TRY(resblock(f, m.r1, b, H, W, &c));
-  f.ar.free(b);
+  TRY(resblock(f, m.r0, *x, H, W, &a, rec ? &rec->r0 : nullptr));
+  if (!rec) f.ar.free(*x);
+  TRY(attention(f, m.at, a, H, W, &b, rec ? &rec->at : nullptr));
+  if (!rec) f.ar.free(a);
+  TRY(resblock(f, m.r1, b, H, W, &c, rec ? &rec->r1 : nullptr));
+  if (!rec) f.ar.free(b);
   *x = c;
   return HEDIT_OK;
 }
 
+// ------------------------------------------------------------------------------ backward (input gradients)
+int groupnorm_bwd(VF& f, const bf16_t* x, const bf16_t* dy, const bf16_t* add, bf16_t* dx, const float* g, const float* b,
+                  const float* stats, int HW, int C, int silu) {
+  float* ws;
+  TRY(aalloc(f, &ws, groupnorm_bwd_ws_bytes(f.B, HW, C) / sizeof(float)));
+  RUN(f, groupnorm_bwd_launch(x, dy, add, dx, g, b, stats, f.B, HW, C, f.h->cfg.norm_num_groups, silu, ws, f.st));
+  f.ar.free(ws);
+  return HEDIT_OK;
+}
+
+// dy [M][cout] -> *dx [M][cin] (allocated here; dy is NOT freed)
+int resblock_bwd(VF& f, const ResRec& rec, const bf16_t* dy, bf16_t** dx_out) {
+  const VRes& r = *rec.r;
+  const int H = rec.H, W = rec.W;
+  const size_t M = (size_t)f.B * H * W;
+  bf16_t *da2, *dh1, *da1, *dsc = nullptr, *dx;
+  TRY(aalloc(f, &da2, M * r.cout));
+  TRY(conv3x3(f, dy, H, W, r.cout, r.conv2_t, r.cout, nullptr, nullptr, da2, 1));
+  TRY(aalloc(f, &dh1, M * r.cout));
+  TRY(groupnorm_bwd(f, rec.h1, da2, nullptr, dh1, r.n2g, r.n2b, rec.st2, H * W, r.cout, 1));
+  f.ar.free(da2);
+  TRY(aalloc(f, &da1, M * r.cin));
+  TRY(conv3x3(f, dh1, H, W, r.cout, r.conv1_t, r.cin, nullptr, nullptr, da1, 1));
+  f.ar.free(dh1);
+  const bf16_t* add = dy;
+  if (r.sc_w) {
+    TRY(aalloc(f, &dsc, M * r.cin));
+    TRY(linear(f, dy, (int)M, r.cout, r.sc_t, r.cin, nullptr, nullptr, dsc, r.cin));
+    add = dsc;
+  }
+  TRY(aalloc(f, &dx, M * r.cin));
+  TRY(groupnorm_bwd(f, rec.x, da1, add, dx, r.n1g, r.n1b, rec.st1, H * W, r.cin, 1));
+  f.ar.free(da1);
+  if (dsc) f.ar.free(dsc);
+  *dx_out = dx;
+  return HEDIT_OK;
+}
+
+// Backward of the single-head attention.  With P = softmax(scale Q K^T), O = P V, Y = O Wo^T + X:
+//   dO = dY Wo ; dV = P^T dO ; dP = dO V^T ; dS = scale P (dP - rowsum(dP P)) ; dQ = dS K ; dK = dS^T Q
+// P is recomputed per image from the kept q, k.  The dropped key / value biases stay dropped: a
+// row-constant in dP cancels inside dS, and rows of dS sum to zero so K's bias cannot reach dQ.
+int attention_bwd(VF& f, const AttnRec& rec, const bf16_t* dy, bf16_t** dx_out) {
+  const VAttn& a = *rec.a;
+  const int C = a.C, T = rec.H * rec.W, B = f.B;
+  const size_t M = (size_t)B * T;
+  const float scale = 1.0f / sqrtf((float)C);
+  bf16_t *dO, *v, *dq, *dk, *dv, *pb, *ds, *tt, *ct, *dxn, *dx;
+  float *s, *dp;
+  TRY(aalloc(f, &dO, M * C));
+  TRY(linear(f, dy, (int)M, C, a.w_o_t, C, nullptr, nullptr, dO, C));
+  TRY(aalloc(f, &v, M * C));
+  TRY(linear(f, rec.xn, (int)M, C, a.w_v, C, nullptr, nullptr, v, C));
+  TRY(aalloc(f, &dq, M * C));
+  TRY(aalloc(f, &dk, M * C));
+  TRY(aalloc(f, &dv, M * C));
+  TRY(aalloc(f, &s, (size_t)T * T));
+  TRY(aalloc(f, &dp, (size_t)T * T));
+  TRY(aalloc(f, &pb, (size_t)T * T));
+  TRY(aalloc(f, &ds, (size_t)T * T));
+  TRY(aalloc(f, &tt, (size_t)T * T));   // P^T, then dS^T
+  TRY(aalloc(f, &ct, (size_t)C * T));   // dO^T, K^T, Q^T in turn
+  for (int b = 0; b < B; ++b) {
+    const size_t o = (size_t)b * T * C;
+    GemmParams p{};
+    p.A = rec.q + o; p.W = rec.k + o; p.M = T; p.N = T; p.K = C; p.lda = C; p.raw_f32 = s; p.ldc = T;
+    TRY(run_gemm(f, p));
+    RUN(f, softmax_rows_launch(s, pb, T, T, scale, f.st));
+    p = GemmParams{};   // dP = dO V^T
+    p.A = dO + o; p.W = v + o; p.M = T; p.N = T; p.K = C; p.lda = C; p.raw_f32 = dp; p.ldc = T;
+    TRY(run_gemm(f, p));
+    RUN(f, softmax_bwd_launch(pb, dp, ds, T, T, scale, f.st));
+    // dV = P^T dO
+    RUN(f, transpose_bf16_launch(pb, tt, T, T, f.st));
+    RUN(f, transpose_bf16_launch(dO + o, ct, T, C, f.st));
+    p = GemmParams{};
+    p.A = tt; p.W = ct; p.M = T; p.N = C; p.K = T; p.lda = T; p.C = dv + o; p.ldc = C;
+    TRY(run_gemm(f, p));
+    // dQ = dS K
+    RUN(f, transpose_bf16_launch(rec.k + o, ct, T, C, f.st));
+    p = GemmParams{};
+    p.A = ds; p.W = ct; p.M = T; p.N = C; p.K = T; p.lda = T; p.C = dq + o; p.ldc = C;
+    TRY(run_gemm(f, p));
+    // dK = dS^T Q
+    RUN(f, transpose_bf16_launch(ds, tt, T, T, f.st));
+    RUN(f, transpose_bf16_launch(rec.q + o, ct, T, C, f.st));
+    p = GemmParams{};
+    p.A = tt; p.W = ct; p.M = T; p.N = C; p.K = T; p.lda = T; p.C = dk + o; p.ldc = C;
+    TRY(run_gemm(f, p));
+  }
+  f.ar.free(ct); f.ar.free(tt); f.ar.free(ds); f.ar.free(pb); f.ar.free(dp); f.ar.free(s);
+  f.ar.free(v); f.ar.free(dO);
+  // d(xn) = dQ Wq + dK Wk + dV Wv, accumulated through the GEMM's residual input
+  TRY(aalloc(f, &dxn, M * C));
+  TRY(linear(f, dq, (int)M, C, a.w_q_t, C, nullptr, nullptr, dxn, C));
+  TRY(linear(f, dk, (int)M, C, a.w_k_t, C, nullptr, dxn, dq, C));    // dq's buffer is free again
+  TRY(linear(f, dv, (int)M, C, a.w_v_t, C, nullptr, dq, dxn, C));
+  f.ar.free(dv); f.ar.free(dk); f.ar.free(dq);
+  TRY(aalloc(f, &dx, M * C));
+  TRY(groupnorm_bwd(f, rec.x, dxn, dy, dx, a.gn_g, a.gn_b, rec.st, T, C, 0));
+  f.ar.free(dxn);
+  *dx_out = dx;
+  return HEDIT_OK;
+}
+
+int mid_bwd(VF& f, const MidRec& rec, bf16_t** d) {
+  bf16_t *a, *b, *c;
+  TRY(resblock_bwd(f, rec.r1, *d, &a));
+  f.ar.free(*d);
+  TRY(attention_bwd(f, rec.at, a, &b));
+  f.ar.free(a);
+  TRY(resblock_bwd(f, rec.r0, b, &c));
+  f.ar.free(b);
+  *d = c;
+  return HEDIT_OK;
+}
+
+// forward; with d_image != null also the vector-Jacobian product d_z = (d image / d z)^T d_image: the
+// forward then keeps what the backward needs (block inputs, conv1 outputs, GroupNorm statistics)
 int decode_impl(hedit_vae* h, const float* z, int B, int lh, int lw, float* image, void* ws, size_t ws_bytes,
-                hipStream_t st, bool dry, size_t* peak) {
+                hipStream_t st, bool dry, size_t* peak, const float* d_image = nullptr, float* d_z = nullptr) {
   VF f{h, B, st, Arena{}};
   f.ar.dry = dry;
   f.ar.base = reinterpret_cast<char*>(ws);
   f.ar.cap = ws_bytes;
+  const bool grad = d_z != nullptr;
   const hedit_vae_cfg& c = h->cfg;
   const int L = c.n_levels, LC = c.latent_channels;
   int H = lh, W = lw;
@@ -335,31 +518,84 @@ int decode_impl(hedit_vae* h, const float* z, int B, int lh, int lw, float* imag
   TRY(aalloc(f, &x, (size_t)B * H * W * ch));
   RUN(f, conv_in_launch(z2, h->d_in_w, h->d_in_b, x, B, LC, H, W, ch, st));
   f.ar.free(z2);
-  TRY(mid(f, h->d_mid, &x, H, W));
+  MidRec mrec{};
+  std::vector<ResRec> rrec;
+  TRY(mid(f, h->d_mid, &x, H, W, grad ? &mrec : nullptr));
   for (int i = 0; i < L; ++i) {
     const VStage& s = h->up[i];
     for (const VRes& r : s.res) {
       bf16_t* y;
-      TRY(resblock(f, r, x, H, W, &y));
-      f.ar.free(x);
+      if (grad) {
+        rrec.emplace_back();
+        TRY(resblock(f, r, x, H, W, &y, &rrec.back()));
+      } else {
+        TRY(resblock(f, r, x, H, W, &y));
+        f.ar.free(x);
+      }
       x = y;
     }
     if (s.samp_w) {
       bf16_t* y;
       TRY(aalloc(f, &y, (size_t)B * H * W * 4 * s.ch));
       TRY(conv3x3(f, x, H, W, s.ch, s.samp_w, s.ch, s.samp_b, nullptr, y, 3));
-      f.ar.free(x);
+      f.ar.free(x);   // the upsampling conv is linear in x: nothing to keep
       x = y;
       H *= 2; W *= 2;
     }
     ch = s.ch;
   }
   bf16_t* xn;
+  float* st_out = nullptr;
   TRY(aalloc(f, &xn, (size_t)B * H * W * ch));
-  TRY(groupnorm(f, x, xn, h->d_gn_g, h->d_gn_b, H * W, ch, 1));
-  f.ar.free(x);
-  RUN(f, conv_out_launch(xn, h->d_out_w, h->d_out_b, image, B, H, W, ch, c.in_channels, st));
+  TRY(groupnorm(f, x, xn, h->d_gn_g, h->d_gn_b, H * W, ch, 1, grad ? &st_out : nullptr));
+  if (!grad) f.ar.free(x);
+  if (image) RUN(f, conv_out_launch(xn, h->d_out_w, h->d_out_b, image, B, H, W, ch, c.in_channels, st));
   f.ar.free(xn);
+  if (!grad) {
+    if (peak) *peak = f.ar.peak;
+    return HEDIT_OK;
+  }
+  // ---------------- backward
+  bf16_t *d, *t;
+  TRY(aalloc(f, &t, (size_t)B * H * W * ch));
+  RUN(f, conv_in_launch(d_image, h->d_out_t, h->zero_bias, t, B, c.in_channels, H, W, ch, st));
+  TRY(aalloc(f, &d, (size_t)B * H * W * ch));
+  TRY(groupnorm_bwd(f, x, t, nullptr, d, h->d_gn_g, h->d_gn_b, st_out, H * W, ch, 1));
+  f.ar.free(t);
+  f.ar.free(x);
+  size_t ri = rrec.size();
+  for (int i = L - 1; i >= 0; --i) {
+    const VStage& s = h->up[i];
+    if (s.samp_w) {
+      // d(2x upsample) = dgrad conv at the high resolution, then 2x2 block sums
+      bf16_t *du, *dx;
+      TRY(aalloc(f, &du, (size_t)B * H * W * s.ch));
+      TRY(conv3x3(f, d, H, W, s.ch, s.samp_t, s.ch, nullptr, nullptr, du, 1));
+      f.ar.free(d);
+      H /= 2; W /= 2;
+      TRY(aalloc(f, &dx, (size_t)B * H * W * s.ch));
+      RUN(f, sum2x2_launch(du, dx, B, H, W, s.ch, st));
+      f.ar.free(du);
+      d = dx;
+    }
+    for (size_t j = 0; j < s.res.size(); ++j) {
+      const ResRec& rec = rrec[--ri];
+      bf16_t* dx;
+      TRY(resblock_bwd(f, rec, d, &dx));
+      f.ar.free(d);
+      f.ar.free(rec.h1); f.ar.free(rec.st1); f.ar.free(rec.st2);
+      f.ar.free(const_cast<bf16_t*>(rec.x));   // this block's input: last use
+      d = dx;
+    }
+  }
+  TRY(mid_bwd(f, mrec, &d));
+  ch = c.block_out_channels[L - 1];
+  float* dz2;
+  TRY(aalloc(f, &dz2, (size_t)B * LC * H * W));
+  RUN(f, conv_out_launch(d, h->d_in_t, h->zero_bias, dz2, B, H, W, ch, LC, st));
+  f.ar.free(d);
+  RUN(f, mix1x1_nchw_launch(dz2, h->pq_t, nullptr, d_z, B, LC, LC, (long)H * W, 1.0f, st));
+  f.ar.free(dz2);
   if (peak) *peak = f.ar.peak;
   return HEDIT_OK;
 }
@@ -457,22 +693,25 @@ int hedit_vae_create(const hedit_vae_cfg* cfg, hedit_vae** out) {
   h->quant_b = vec(h, "quant_conv.bias", 2 * LC);
   // ---- decoder
   h->pq_w = f32conv(h, "post_quant_conv.weight", LC, LC, 1);
+  h->pq_t = twin<float>(h, 3, (size_t)LC * LC);
   h->pq_b = vec(h, "post_quant_conv.bias", LC);
   ch = bc[L - 1];
   h->d_in_w = f32conv(h, "decoder.conv_in.weight", ch, LC, 3);
+  h->d_in_t = twin<bf16_t>(h, 2, (size_t)ch * LC * 9);
   h->d_in_b = vec(h, "decoder.conv_in.bias", ch);
-  h->d_mid = make_mid(h, "decoder.mid_block", ch);
+  h->d_mid = make_mid(h, "decoder.mid_block", ch, true);
   for (int i = 0; i < L; ++i) {
     VStage s;
     const int co = bc[L - 1 - i];
     const std::string pre = "decoder.up_blocks." + std::to_string(i);
     for (int j = 0; j < cfg->layers_per_block + 1; ++j) {
-      s.res.push_back(make_res(h, pre + ".resnets." + std::to_string(j), j == 0 ? ch : co, co));
+      s.res.push_back(make_res(h, pre + ".resnets." + std::to_string(j), j == 0 ? ch : co, co, true));
     }
     ch = co;
     s.ch = ch;
     if (i < L - 1) {
       s.samp_w = conv3(h, pre + ".upsamplers.0.conv.weight", ch, ch);
+      s.samp_t = twin<bf16_t>(h, 2, (size_t)ch * ch * 9);
       s.samp_b = vec(h, pre + ".upsamplers.0.conv.bias", ch);
     }
     h->up.push_back(s);
@@ -480,7 +719,14 @@ int hedit_vae_create(const hedit_vae_cfg* cfg, hedit_vae** out) {
   h->d_gn_g = vec(h, "decoder.conv_norm_out.weight", ch);
   h->d_gn_b = vec(h, "decoder.conv_norm_out.bias", ch);
   h->d_out_w = conv3(h, "decoder.conv_out.weight", cfg->in_channels, ch);
+  h->d_out_t = twin<float>(h, 3, (size_t)cfg->in_channels * ch * 9);
   h->d_out_b = vec(h, "decoder.conv_out.bias", cfg->in_channels);
+  {
+    int zc = 8;
+    for (int i = 0; i < L; ++i) zc = bc[i] > zc ? bc[i] : zc;
+    h->zero_bias = dalloc<float>(h, zc);
+    if (h->zero_bias && hipMemset(h->zero_bias, 0, zc * sizeof(float)) != hipSuccess) h->alloc_failed = true;
+  }
   if (h->alloc_failed) {
     hedit_set_error("hipMalloc failed while creating the VAE");
     hedit_vae_destroy(h);
@@ -528,6 +774,13 @@ int hedit_vae_load(hedit_vae* h, const char* name, const float* w, size_t numel,
   } else {
     TRY(pack_conv3x3_launch(w, reinterpret_cast<bf16_t*>(s.dst), s.O, s.I, st));
   }
+  if (s.tkind == 1) {
+    TRY(pack_linear_t_launch(w, reinterpret_cast<bf16_t*>(s.tdst), s.O, s.I, st));
+  } else if (s.tkind == 2) {
+    TRY(pack_conv3x3_dgrad_launch(w, reinterpret_cast<bf16_t*>(s.tdst), s.O, s.I, st));
+  } else if (s.tkind == 3) {
+    TRY(flip_oihw_launch(w, reinterpret_cast<float*>(s.tdst), s.O, s.I, s.dims[2], st));
+  }
   s.loaded = true;
   return HEDIT_OK;
 }
@@ -549,8 +802,10 @@ size_t hedit_vae_workspace_bytes(hedit_vae* h, int B, int latent_h, int latent_w
   if (!h || B < 1 || check_latent(h, latent_h, latent_w) != HEDIT_OK) return 0;
   size_t peak = 0;
   const int f = 1 << (h->cfg.n_levels - 1);
-  int rc = encode ? encode_impl(h, nullptr, B, latent_h * f, latent_w * f, nullptr, nullptr, 0, nullptr, true, &peak)
-                  : decode_impl(h, nullptr, B, latent_h, latent_w, nullptr, nullptr, 0, nullptr, true, &peak);
+  float dummy = 0.f;   // only its address matters in the dry run (selects the gradient pass)
+  int rc = encode == 1 ? encode_impl(h, nullptr, B, latent_h * f, latent_w * f, nullptr, nullptr, 0, nullptr, true, &peak)
+         : encode == 2 ? decode_impl(h, nullptr, B, latent_h, latent_w, nullptr, nullptr, 0, nullptr, true, &peak, &dummy, &dummy)
+                       : decode_impl(h, nullptr, B, latent_h, latent_w, nullptr, nullptr, 0, nullptr, true, &peak);
   return rc == HEDIT_OK ? peak + 4096 : 0;
 }
 
@@ -565,6 +820,19 @@ int hedit_vae_decode(hedit_vae* h, const float* z, int B, int latent_h, int late
   }
   return decode_impl(h, z, B, latent_h, latent_w, image, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream),
                      false, nullptr);
+}
+
+int hedit_vae_decode_vjp(hedit_vae* h, const float* z, const float* d_image, int B, int latent_h, int latent_w, float* d_z,
+                         float* image, void* workspace, size_t workspace_bytes, void* stream) {
+  ARG_CHECK(h && z && d_image && d_z && workspace, "null");
+  ARG_CHECK(B >= 1, "B");
+  TRY(check_latent(h, latent_h, latent_w));
+  if (hedit_vae_missing(h) != 0) {
+    hedit_set_error("VAE has " + std::to_string(hedit_vae_missing(h)) + " unloaded parameters");
+    return HEDIT_ERR_STATE;
+  }
+  return decode_impl(h, z, B, latent_h, latent_w, image, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream),
+                     false, nullptr, d_image, d_z);
 }
 
 int hedit_vae_encode(hedit_vae* h, const float* image, int B, int height, int width, float* mean, void* workspace,

@@ -74,6 +74,8 @@ _SIGS = {
     "hedit_vae_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "hedit_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p]),
+    "hedit_vae_decode_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hedit_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p]),
     "hedit_k_gemm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -50,6 +50,25 @@ class _Config(dict):
     __getattr__ = dict.__getitem__
 
 
+class _DecodeFn(torch.autograd.Function):
+    """``vae.decode`` as a differentiable node: the reference's style-guidance closure calls
+    ``torch.autograd.grad(loss, latents)`` through ``model.vae.decode``
+    (text-guided-n-style/inversion/h_edit.py:146-185).  The backward is one C call
+    (hedit_vae_decode_vjp: forward with kept activations + input-gradient pass, all HIP); only the
+    gradient w.r.t. the latents exists -- the weights are constants here as in the reference."""
+
+    @staticmethod
+    def forward(ctx, z, vae):
+        ctx.vae = vae
+        ctx.save_for_backward(z)
+        return vae._decode_raw(z)
+
+    @staticmethod
+    def backward(ctx, d_image):
+        (z,) = ctx.saved_tensors
+        return ctx.vae.decode_vjp(z, d_image), None
+
+
 class AutoencoderKL:
     def __init__(self, config=None, device="cuda:0"):
         cfg = dict(SD15_VAE_CONFIG)
@@ -134,7 +153,29 @@ class AutoencoderKL:
         return self._ws
 
     def decode(self, z, return_dict=True):
-        """z (B, latent_channels, h, w) -> .sample (B, in_channels, h*f, w*f), fp32."""
+        """z (B, latent_channels, h, w) -> .sample (B, in_channels, h*f, w*f), fp32.  Differentiable
+        w.r.t. z when z requires grad (see _DecodeFn)."""
+        if torch.is_grad_enabled() and z.requires_grad:
+            img = _DecodeFn.apply(z.to(device=self.device, dtype=torch.float32), self)
+        else:
+            img = self._decode_raw(z)
+        return DecoderOutput(sample=img) if return_dict else (img,)
+
+    def decode_vjp(self, z, d_image):
+        """d_z = (d decode(z) / d z)^T d_image, fp32 like z."""
+        z = z.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        d_image = d_image.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        B, _, lh, lw = z.shape
+        if tuple(d_image.shape) != (B, self.config["in_channels"], lh * self.factor, lw * self.factor):
+            raise ValueError(f"d_image shape {tuple(d_image.shape)} does not match decode({tuple(z.shape)})")
+        ws = self._workspace(B, lh, lw, 2)
+        dz = torch.empty_like(z)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.hedit_vae_decode_vjp(self._h, _lib.ptr(z), _lib.ptr(d_image), B, lh, lw, _lib.ptr(dz),
+                                                      None, _lib.ptr(ws), ws.numel(), _lib.cur_stream()))
+        return dz
+
+    def _decode_raw(self, z):
         z = z.detach().to(device=self.device, dtype=torch.float32).contiguous()
         B, _, lh, lw = z.shape
         ws = self._workspace(B, lh, lw, False)
@@ -143,7 +184,7 @@ class AutoencoderKL:
         with torch.cuda.device(self.device):
             _lib.check(self._lib.hedit_vae_decode(self._h, _lib.ptr(z), B, lh, lw, _lib.ptr(img), _lib.ptr(ws),
                                                   ws.numel(), _lib.cur_stream()))
-        return DecoderOutput(sample=img) if return_dict else (img,)
+        return img
 
     def encode(self, x):
         """x (B, in_channels, H, W) in [-1, 1] -> EncoderOutput with latent_dist.mode() (B, latent_channels, H/f, W/f)."""

@@ -155,12 +155,22 @@ const char* hedit_vae_param_name(const hedit_vae* h, int i);
 int hedit_vae_param_shape(const hedit_vae* h, int i, int* ndim, int* dims4);
 int hedit_vae_load(hedit_vae* h, const char* name, const float* dev_w, size_t numel, void* stream);
 int hedit_vae_missing(const hedit_vae* h);
-/* workspace for a decode (encode = 0) or encode (encode = 1) of B images whose LATENT is h x w */
+/* workspace for a decode (encode = 0), an encode (encode = 1) or a decode_vjp (encode = 2) of B images
+ * whose LATENT is h x w */
 size_t hedit_vae_workspace_bytes(hedit_vae* h, int B, int latent_h, int latent_w, int encode);
 /* z: fp32 [B][latent_channels][h][w] (already divided by the scaling factor)
  * -> image fp32 [B][in_channels][h*f][w*f], f = 2^(n_levels-1) */
 int hedit_vae_decode(hedit_vae* h, const float* z, int B, int latent_h, int latent_w, float* image,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* Vector-Jacobian product of the decoder: d_z = (d image / d z)^T d_image, what
+ * `torch.autograd.grad(loss, latents)` pulls through `vae.decode` inside the reference's style-guidance
+ * closure (text-guided-n-style/inversion/h_edit.py:146-185: x0 -> model.vae.decode -> image encoder ->
+ * loss -> autograd.grad).  One call runs the forward (keeping block inputs and GroupNorm statistics
+ * in the workspace) and the backward; no state survives the call.
+ * z [B][latent_channels][h][w], d_image [B][in_channels][h*f][w*f] -> d_z like z; image (optional, may be
+ * NULL) receives the decoded image as hedit_vae_decode would. */
+int hedit_vae_decode_vjp(hedit_vae* h, const float* z, const float* d_image, int B, int latent_h, int latent_w,
+                         float* d_z, float* image, void* workspace, size_t workspace_bytes, void* stream);
 /* image fp32 [B][in_channels][H][W] -> mean of the latent distribution, fp32 [B][latent_channels][H/f][W/f] */
 int hedit_vae_encode(hedit_vae* h, const float* image, int B, int height, int width, float* mean,
                      void* workspace, size_t workspace_bytes, void* stream);
