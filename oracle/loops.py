@@ -8,6 +8,7 @@ Restates, against the same duck-typed ``model`` object the reference uses:
   h_edit_r_implicit             text-guided/inversion/p2p_h_edit.py:162-362
   h_edit_p2p_explicit           text-guided/inversion/p2p_h_edit.py:380-523
   h_edit_p2p_implicit           text-guided/inversion/p2p_h_edit.py:529-701
+  h_edit_p2p_implicit_style     text-guided-n-style/inversion/h_edit.py:14-192 (text + style editing)
 The four loops share one skeleton here (``_loop``); the per-variant differences are the UNet
 batches and which eps feeds the three CFG mixes.
 """
@@ -146,8 +147,25 @@ def _l1_pull(x, anchor, corr, w):
     return x - rho * g
 
 
+def _style_step(model, image_encoder, x, e_tar, corr, tt, weight):
+    """Style-guidance update of x_{t-1}^k (n-style h_edit.py:162-185): Tweedie x0 from the target
+    eps at t-1 -> vae.decode(x0 / 0.18215) -> ||Gram residual||_F of the image encoder -> gradient
+    w.r.t. x through decoder and encoder -> x - rho g, rho = rms(correction) / rms(g) * weight."""
+    xs = x.clone().detach().requires_grad_(True)
+    with torch.enable_grad():
+        x0 = S.tweedie_x0(model.scheduler, e_tar, tt, xs)
+        img = model.vae.decode(1 / 0.18215 * x0).sample
+        loss = torch.linalg.norm(image_encoder.get_gram_matrix_residual(img))
+        g = torch.autograd.grad(outputs=loss, inputs=xs)[0]
+    rho = _rms(corr) / _rms(g) * weight
+    return (xs - rho * g.detach()).detach()
+
+
 def _loop(model, xT, eta, prompts, cfg_scales, zs, controller, after_skip_steps, ddim_inv,
-          p2p, implicit, K=1, w_rec=0.1):
+          p2p, implicit, K=1, w_rec=0.1, style=None):
+    """style = (image_encoder | None, weight_edit_clip) selects the n-style variant of the implicit
+    P2P loop: no reconstruction pull between inner steps (rec_term = x^k, h_edit.py:149) and one
+    style-guidance update after every text update (h_edit.py:160-188)."""
     sch, (w_src, w_hat, w_tar), txt, unc, xt, op = _prep(model, xT, prompts, cfg_scales,
                                                           after_skip_steps)
     T = sch.num_inference_steps
@@ -211,8 +229,11 @@ def _loop(model, xT, eta, prompts, cfg_scales, zs, controller, after_skip_steps,
                 else:
                     e = unet(torch.cat([x_k] * 4), tt, torch.cat([unc, txt]), off)
                     corr = mixes(e[0:1], e[2:3], e[1:2], e[3:4])
-                rec = _l1_pull(x_k, x_base, corr, w_rec) if k > 0 else x_k
+                rec = _l1_pull(x_k, x_base, corr, w_rec) if (k > 0 and style is None) else x_k
                 x_k = rec + coeff * corr
+                if style is not None and style[0]:
+                    e_tar = e[1:2] + w_tar * (e[3:4] - e[1:2])
+                    x_k = _style_step(model, style[0], x_k, e_tar, corr, tt, style[1])
 
         xt = torch.cat([x_orig, x_k.detach()])
         if controller is not None:
@@ -246,3 +267,12 @@ def h_edit_p2p_implicit(model, xT, eta=1.0, prompts="", cfg_scales=None, zs=None
     return _loop(model, xT, eta, prompts, cfg_scales, zs, controller, after_skip_steps,
                  is_ddim_inversion, p2p=True, implicit=True, K=optimization_steps,
                  w_rec=weight_reconstruction)
+
+
+def h_edit_p2p_implicit_style(model, image_encoder, xT, eta=1.0, prompts="", cfg_scales=None, zs=None,
+                              controller=None, weight_edit_clip=0.55, optimization_steps=1,
+                              after_skip_steps=100, is_ddim_inversion=False):
+    """text-guided-n-style/inversion/h_edit.py:14-192 (its h_Edit_p2p_implicit)."""
+    return _loop(model, xT, eta, prompts, cfg_scales, zs, controller, after_skip_steps,
+                 is_ddim_inversion, p2p=True, implicit=True, K=optimization_steps,
+                 style=(image_encoder, weight_edit_clip))

@@ -401,9 +401,92 @@ def gen_load512(ref, out):
     np.savez_compressed(os.path.join(out, "g8_load512.npz"), **rec)
 
 
+# --------------------------------------------------------------------------- G9: text + style loop
+REF_STYLE = "/root/reference/text-guided-n-style"
+
+
+def gen_style_child(out):
+    """Runs in its own interpreter (the n-style sub-project reuses the package names ``inversion`` /
+    ``p2p`` of text-guided): imports text-guided-n-style/inversion/h_edit.py UNMODIFIED and drives
+    h_Edit_p2p_implicit (text + style editing) with the toy UNet / VAE / style encoder."""
+    global REF
+    REF = REF_STYLE
+    _stub("diffusers")
+    _stub("diffusers.utils")
+    _stub("diffusers.utils.torch_utils", randn_tensor=None)
+    _stub("diffusers.models")
+    _stub("diffusers.models.attention_processor", Attention=object)
+    _stub("cv2")
+    nltk = _stub("nltk", download=lambda *a, **k: None)
+    nltk.tokenize = _stub("nltk.tokenize", word_tokenize=lambda s: s.split())
+    sys.path.insert(0, REF_STYLE)
+    import warnings
+    warnings.filterwarnings("ignore")      # autocast("cuda") without a GPU: disabled with a warning
+    import inversion.h_edit as hs
+    import inversion.ddpm_inversion as di
+    import p2p.ptp_utils as pu
+    import p2p.ptp_classes as pc
+    import p2p.ptp_controller_utils as pcu
+    hs.tqdm = lambda x, *a, **k: x
+    di.tqdm = lambda x, *a, **k: x
+    ref = types.SimpleNamespace(pcu=pcu, pc=pc, pu=pu)
+    from helpers.tiny import make_tiny_model, PROMPT_PAIRS, TinyVae, TinyStyleEncoder
+    T = 10
+    d = {}
+    meta = {"T": T, "cases": []}
+    cfg = [1.0, 5.0, 7.5]
+    torch.manual_seed(1234)                 # the g3 start sample: a well-conditioned trajectory
+    w0 = torch.randn(1, 4, 16, 16) * 0.8
+    d["w0"] = npy(w0)
+
+    def run(name, pi, skip, K, weight, with_encoder=True, blend=True):
+        model = make_tiny_model(T)
+        model.vae = TinyVae()
+        torch.manual_seed(4321 + pi)
+        _, zs, wts, _ = di.inversion_forward_process_ddpm(model, w0, etas=1.0, prog_bar=False,
+                                                          prompt=PROMPT_PAIRS[pi][0], cfg_scale_src=1.0,
+                                                          num_inference_steps=T)
+        d[f"{name}_zs"] = npy(zs)
+        d[f"{name}_wts"] = npy(wts)
+        model = make_tiny_model(T)          # fresh objects for the edit, as in gen_loops
+        model.vae = TinyVae()
+        after = T - skip
+        pair = PROMPT_PAIRS[pi] if blend else PROMPT_PAIRS[pi][:2] + (None, PROMPT_PAIRS[pi][3])
+        ctrl = build_ref_controller(ref, model, pair, after)
+        pu.register_attention_control(model, ctrl)
+        enc = TinyStyleEncoder() if with_encoder else None
+        edit, recon = hs.h_Edit_p2p_implicit(model, enc, xT=wts[after], eta=1.0,
+                                             prompts=[pair[0], pair[1]], cfg_scales=cfg, prog_bar=False,
+                                             zs=zs[:after], controller=ctrl, weight_edit_clip=weight,
+                                             optimization_steps=K, after_skip_steps=after, is_ddim_inversion=False)
+        d[f"{name}_edit"] = npy(edit)
+        d[f"{name}_recon"] = npy(recon)
+        meta["cases"].append({"name": name, "pair": pi, "skip": skip, "K": K, "weight": weight,
+                              "with_encoder": with_encoder, "blend": blend, "cur_step": ctrl.cur_step})
+
+    run("style_k1", 0, 0, 1, 0.5, blend=False)           # main_edit.py passes blend_word=None
+    run("style_k2_skip2", 2, 2, 2, 0.55)
+    run("style_blend", 2, 0, 1, 0.8)
+    run("style_noenc", 0, 0, 1, 0.5, with_encoder=False)  # `if image_encoder:` false -> text editing only
+    np.savez_compressed(os.path.join(out, "g9_style.npz"), **d)
+    with open(os.path.join(out, "g9_style.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+
+
+def gen_style(out):
+    import subprocess
+    subprocess.run([sys.executable, os.path.abspath(__file__), "--style-child"], check=True)
+
+
 def main():
     torch.set_num_threads(4)
     torch.set_grad_enabled(True)
+    if "--style-child" in sys.argv:
+        if not os.path.isdir(REF_STYLE):
+            raise SystemExit("reference tree not present")
+        return gen_style_child(HERE)
+    if "--only-style" in sys.argv:
+        return gen_style(HERE)
     ref = import_reference()
     out = HERE
     gen_scheduler(ref, out)
@@ -413,6 +496,7 @@ def main():
     gen_loops(ref, out)
     gen_ddim(ref, out)
     gen_load512(ref, out)
+    gen_style(out)
     for f in sorted(os.listdir(out)):
         if f.endswith((".npz", ".json")):
             print(f"{f:32s} {os.path.getsize(os.path.join(out, f)) / 1024:9.1f} KiB")

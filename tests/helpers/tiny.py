@@ -325,3 +325,57 @@ PROMPT_PAIRS = [
     ("a photo of a house on a hill", "a watercolor painting of a house on a hill", None, False),
     ("the dog runs", "the dog runs on a sunny beach", ("dog", "dog"), False),
 ]
+
+
+# --------------------------------------------------------------------------- style-guidance toys
+class _Sample(dict):
+    @property
+    def sample(self):
+        return self["sample"]
+
+
+class TinyVae(nn.Module):
+    """Differentiable stand-in for ``model.vae`` inside the style closure (reference
+    text-guided-n-style/inversion/h_edit.py:172-173 only calls ``.decode(z).sample``):
+    conv 4->8, SiLU, 2x nearest upsample, conv 8->3; seeded weights."""
+
+    def __init__(self, seed=23):
+        super().__init__()
+        self.c1 = nn.Conv2d(4, 8, 3, padding=1)
+        self.c2 = nn.Conv2d(8, 3, 3, padding=1)
+        with torch.no_grad():
+            for i, p in enumerate(self.parameters()):
+                p.copy_(hash_normal(tuple(p.shape), seed + i) * (0.25 if p.dim() > 1 else 0.05))
+                p.requires_grad_(False)
+
+    def decode(self, z):
+        h = F.silu(self.c1(z.float()))
+        h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+        return _Sample(sample=self.c2(h))
+
+
+class TinyStyleEncoder(nn.Module):
+    """Stand-in for the reference's CLIPEncoder (clip_guidance/base_clip.py:30-65): the only member
+    the loop calls is ``get_gram_matrix_residual(image)`` -> Gram matrix of token features of batch
+    item 0 minus the Gram matrix of a fixed style reference.  Here: bicubic resize to ``size``,
+    one strided conv + tanh as the feature extractor; works for any input resolution."""
+
+    def __init__(self, size=16, feat=6, seed=41):
+        super().__init__()
+        self.size = size
+        self.conv = nn.Conv2d(3, feat, 4, stride=2, padding=1)
+        with torch.no_grad():
+            self.conv.weight.copy_(hash_normal(tuple(self.conv.weight.shape), seed) * 0.3)
+            self.conv.bias.copy_(hash_normal(tuple(self.conv.bias.shape), seed + 1) * 0.1)
+        ref = hash_normal((1, 3, size, size), seed + 2) * 0.7
+        self.register_buffer("ref", ref)
+
+    def _tokens(self, im):
+        f = torch.tanh(self.conv(im.float()))           # (B, feat, s/2, s/2)
+        return f[0].flatten(1).t()                      # tokens of batch item 0: (s*s/4, feat)
+
+    def get_gram_matrix_residual(self, im1):
+        im1 = F.interpolate(im1.float(), size=(self.size, self.size), mode="bicubic")
+        a = self._tokens(im1)
+        b = self._tokens(self.ref)
+        return a.t() @ a - b.t() @ b
