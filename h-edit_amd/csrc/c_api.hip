@@ -35,6 +35,21 @@ int hedit_step_update(const float* e_u_src, const float* e_c_src, const float* e
                             elems, k_gt0, to_coef(c), S(stream));
 }
 
+int hedit_step_tweedie(const float* e_u_tar, const float* e_c_tar, int64_t stride_img, const float* x, float* z0,
+                       int n_img, int elems, float w_tar, float sqrt_ab, float sqrt_1m_ab, float inv_scale, void* stream) {
+  ARG_CHECK(e_u_tar && e_c_tar && x && z0 && sqrt_ab > 0.f, "step_tweedie args");
+  return step_tweedie_launch(e_u_tar, e_c_tar, (long)stride_img, x, z0, n_img, elems, w_tar, sqrt_ab, sqrt_1m_ab, inv_scale,
+                             S(stream));
+}
+
+int hedit_step_style(const float* e_u_src, const float* e_c_src, const float* e_u_tar, const float* e_c_tar,
+                     int64_t stride_img, const float* x, const float* g_z, float* x_out, int n_img, int elems, float w_hat,
+                     float w_tar, float chain, float weight, void* stream) {
+  ARG_CHECK(e_u_src && e_c_src && e_u_tar && e_c_tar && x && g_z && x_out, "step_style args");
+  return step_style_launch(e_u_src, e_c_src, e_u_tar, e_c_tar, (long)stride_img, x, g_z, x_out, n_img, elems, w_hat, w_tar,
+                           chain, weight, S(stream));
+}
+
 int hedit_local_blend(float* const* h_maps, int n_maps, int heads, const float* alpha_layers,
                       const int32_t* enabled, float* xt, int n_img, int C, int H, int W, float th, void* stream) {
   ARG_CHECK(h_maps && alpha_layers && xt, "local_blend args");

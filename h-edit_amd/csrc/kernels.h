@@ -132,5 +132,12 @@ int step_base_launch(const float* eps, const float* xt, const float* z, float* x
 int step_update_launch(const float* e_u_src, const float* e_c_src, const float* e_u_tar,
                        const float* e_c_tar, long stride_img, const float* x_k, const float* x_base,
                        float* x_out, int n_img, int elems, int k_gt0, StepCoef c, hipStream_t st);
+// style guidance (n-style h_edit.py:160-185): Tweedie x0 / scaling_factor for the decoder, and the update
+// x - rho g with g = chain * g_z, rho = rms(correction) / rms(g) * weight (per image)
+int step_tweedie_launch(const float* e_u_tar, const float* e_c_tar, long stride_img, const float* x, float* z0,
+                        int n_img, int elems, float w_tar, float sqrt_ab, float sqrt_1m_ab, float inv_scale, hipStream_t st);
+int step_style_launch(const float* e_u_src, const float* e_c_src, const float* e_u_tar, const float* e_c_tar,
+                      long stride_img, const float* x, const float* g_z, float* x_out, int n_img, int elems, float w_hat,
+                      float w_tar, float chain, float weight, hipStream_t st);
 int local_blend_launch(const float* const* maps, int n_maps, int heads, const float* alpha_layers,
                        const int* enabled, float* xt, int n_img, int C, int H, int W, float th, hipStream_t st);

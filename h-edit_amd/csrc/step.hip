@@ -154,7 +154,66 @@ __global__ __launch_bounds__(256) void local_blend_kernel(BlendMaps maps, int n_
   }
 }
 
+// ---- style guidance (text-guided-n-style/inversion/h_edit.py:160-185) around the decoder / image-encoder pass
+// z0 = (x - sqrt(1-ab) e_tar) / sqrt(ab) * inv_scale : Tweedie x0 at t-1, pre-divided by the VAE scaling factor
+__global__ __launch_bounds__(256) void step_tweedie_kernel(const float* __restrict__ e_u_tar, const float* __restrict__ e_c_tar,
+                                                           long stride_img, const float* __restrict__ x, float* __restrict__ z0,
+                                                           int elems, float w_tar, float sqrt_ab, float sqrt_1m_ab, float inv_scale) {
+  const int img = blockIdx.y;
+  const long eo = (long)img * stride_img;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < elems; i += gridDim.x * 256) {
+    const float etar = e_u_tar[eo + i] + w_tar * (e_c_tar[eo + i] - e_u_tar[eo + i]);
+    z0[(long)img * elems + i] = (x[(long)img * elems + i] - sqrt_1m_ab * etar) / sqrt_ab * inv_scale;
+  }
+}
+
+// x_out = x - rho g,  g = chain * g_z (chain rule through the Tweedie / scaling step),
+// rho = rms(correction) / rms(g) * weight -- per image, no epsilon, as the reference writes it
+__global__ __launch_bounds__(1024) void step_style_kernel(const float* __restrict__ e_u_src, const float* __restrict__ e_c_src,
+                                                          const float* __restrict__ e_u_tar, const float* __restrict__ e_c_tar,
+                                                          long stride_img, const float* __restrict__ x, const float* __restrict__ g_z,
+                                                          float* __restrict__ x_out, int elems, float w_hat, float w_tar,
+                                                          float chain, float weight) {
+  __shared__ float red[16];
+  const int img = blockIdx.x;
+  const long eo = (long)img * stride_img;
+  const float* xi = x + (long)img * elems;
+  const float* gi = g_z + (long)img * elems;
+  float sc = 0.f, sg = 0.f;
+  for (int i = threadIdx.x; i < elems; i += blockDim.x) {
+    const float ehat = e_u_src[eo + i] + w_hat * (e_c_src[eo + i] - e_u_src[eo + i]);
+    const float etar = e_u_tar[eo + i] + w_tar * (e_c_tar[eo + i] - e_u_tar[eo + i]);
+    const float corr = etar - ehat;
+    sc += corr * corr;
+    const float g = gi[i] * chain;
+    sg += g * g;
+  }
+  sc = block_sum(sc, red);
+  sg = block_sum(sg, red);
+  const float invn = 1.0f / (float)elems;
+  const float rho = sqrtf(sc * invn) / sqrtf(sg * invn) * weight;
+  for (int i = threadIdx.x; i < elems; i += blockDim.x) x_out[(long)img * elems + i] = xi[i] - rho * (gi[i] * chain);
+}
+
 }  // namespace
+
+int step_tweedie_launch(const float* e_u_tar, const float* e_c_tar, long stride_img, const float* x, float* z0,
+                        int n_img, int elems, float w_tar, float sqrt_ab, float sqrt_1m_ab, float inv_scale, hipStream_t st) {
+  dim3 grid(cdiv(elems, 256) > 64 ? 64 : cdiv(elems, 256), n_img);
+  hipLaunchKernelGGL(step_tweedie_kernel, grid, dim3(256), 0, st, e_u_tar, e_c_tar, stride_img, x, z0, elems, w_tar, sqrt_ab,
+                     sqrt_1m_ab, inv_scale);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int step_style_launch(const float* e_u_src, const float* e_c_src, const float* e_u_tar, const float* e_c_tar,
+                      long stride_img, const float* x, const float* g_z, float* x_out, int n_img, int elems, float w_hat,
+                      float w_tar, float chain, float weight, hipStream_t st) {
+  hipLaunchKernelGGL(step_style_kernel, dim3(n_img), dim3(1024), 0, st, e_u_src, e_c_src, e_u_tar, e_c_tar, stride_img, x,
+                     g_z, x_out, elems, w_hat, w_tar, chain, weight);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
 
 int step_base_launch(const float* eps, const float* xt, const float* z, float* x_prev, int n_img, int elems,
                      int rows, StepCoef c, hipStream_t st) {

@@ -62,6 +62,10 @@ _SIGS = {
     "hedit_step_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(StepCoef),
                                     C.c_void_p]),
+    "hedit_step_tweedie": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "hedit_step_style": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "hedit_local_blend": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "hedit_vae_create": (C.c_int, [C.POINTER(VaeCfg), C.POINTER(C.c_void_p)]),

@@ -94,6 +94,39 @@ class HEditEngine:
                                               _lib.ptr(out), n, elems, int(k_gt0), C.byref(coef),
                                               _lib.cur_stream()))
 
+    def style_step(self, e_u_src, e_c_src, e_u_tar, e_c_tar, x, tt, cfg_scales, image_encoder, weight):
+        """Style-guidance update of x_{t-1}^k, text-guided-n-style/inversion/h_edit.py:160-188: Tweedie
+        x0 at t-1 (HIP) -> vae.decode (HIP, an autograd node whose backward is hedit_vae_decode_vjp) ->
+        the caller's image encoder (a torch module, like the text encoder it stays on PyTorch-ROCm) ->
+        ||Gram residual|| -> d/dz0 -> x - rho g (HIP).  ``image_encoder``: one object, or one per image
+        (its get_gram_matrix_residual reads batch item 0 only, clip_guidance/base_clip.py:60-65)."""
+        vae = self.model.vae
+        if vae is None:
+            raise RuntimeError("style guidance needs model.vae (hedit.vae.AutoencoderKL)")
+        n, elems = x.shape[0], x[0].numel()
+        ab = float(self.model.scheduler.alphas_cumprod[tt])
+        sab, s1m = ab ** 0.5, (1.0 - ab) ** 0.5
+        inv_scale = 1.0 / 0.18215
+        for t_ in (e_u_src, e_c_src, e_u_tar, e_c_tar, x):
+            assert t_.is_contiguous() and t_.dtype == torch.float32
+        z0 = torch.empty_like(x)
+        _lib.check(self.lib.hedit_step_tweedie(_lib.ptr(e_u_tar), _lib.ptr(e_c_tar), elems, _lib.ptr(x), _lib.ptr(z0),
+                                               n, elems, float(cfg_scales[2]), sab, s1m, inv_scale, _lib.cur_stream()))
+        encs = image_encoder if isinstance(image_encoder, (list, tuple)) else [image_encoder] * n
+        g_z = torch.empty_like(x)
+        with torch.enable_grad():
+            for i in range(n):
+                zi = z0[i:i + 1].clone().requires_grad_(True)
+                img = vae.decode(zi).sample
+                loss = torch.linalg.norm(encs[i].get_gram_matrix_residual(img))
+                g_z[i:i + 1] = torch.autograd.grad(outputs=loss, inputs=zi)[0]
+        out = torch.empty_like(x)
+        _lib.check(self.lib.hedit_step_style(_lib.ptr(e_u_src), _lib.ptr(e_c_src), _lib.ptr(e_u_tar), _lib.ptr(e_c_tar),
+                                             elems, _lib.ptr(x), _lib.ptr(g_z), _lib.ptr(out), n, elems,
+                                             float(cfg_scales[1]), float(cfg_scales[2]), inv_scale / sab, float(weight),
+                                             _lib.cur_stream()))
+        return out
+
     # ------------------------------------------------------------------ text
     def encode(self, prompts):
         tok = self.model.tokenizer(prompts, padding="max_length", max_length=self.model.tokenizer.model_max_length,
@@ -105,7 +138,7 @@ class HEditEngine:
     @torch.no_grad()
     def run(self, xT, zs, prompt_pairs, cfg_scales, controller=None, eta=1.0, p2p=True, implicit=True,
             K=1, w_rec=0.1, after_skip_steps=None, ddim_inv=False, ctx=None, fuse_src_pass=False,
-            reuse_orig_eps=False):
+            reuse_orig_eps=False, style=None):
         """xT: (n,C,H,W); zs: (T',n,C,H,W) or None; prompt_pairs: n x [src, tar].
         ctx: optional precomputed (null, src, tar) embeddings ((1|n,77,D), (n,77,D), (n,77,D)).
         fuse_src_pass: evaluate eps(x^k, t-1, src) (the reference's separate n-row call,
@@ -117,7 +150,12 @@ class HEditEngine:
         (p2p_h_edit.py:604-616) recomputes exactly these two.  Reusing them evaluates 2n instead of
         4n rows in every base pass but the first: 7 instead of 9 sample-forwards per step at K=1.
         Same mathematics, fewer UNet evaluations than the reference issues.
+        style = (image_encoder | None, weight_edit_clip) selects the text + style loop of
+        text-guided-n-style/inversion/h_edit.py (implicit P2P only): no reconstruction pull between
+        inner steps (h_edit.py:149) and one style_step after every text update (h_edit.py:160-188).
         Returns (edit (n,C,H,W), recon (n,C,H,W))."""
+        if style is not None and not (p2p and implicit):
+            raise ValueError("style guidance is defined for the implicit P2P loop only (n-style h_edit.py)")
         sch = self.model.scheduler
         S = Schedule(sch)
         T = sch.num_inference_steps
@@ -207,7 +245,12 @@ class HEditEngine:
                         else:
                             e_src = self.unet.forward_raw(x_k, tt, ctx_src, off)
                             e = p2p_pass(torch.cat([x_orig, x_k, x_orig, x_k]), tt, save)
-                        self.step_update(e[n:2 * n], e_src, e[n:2 * n], e[3 * n:4 * n], x_k, x_base, new, n, k > 0, coef)
+                        self.step_update(e[n:2 * n], e_src, e[n:2 * n], e[3 * n:4 * n], x_k, x_base, new, n,
+                                         k > 0 and style is None, coef)
+                        if style is not None and style[0] is not None:
+                            with torch.enable_grad():
+                                new = self.style_step(e[n:2 * n], e_src, e[n:2 * n], e[3 * n:4 * n], new, tt, cfg_scales,
+                                                      style[0], style[1])
                         if reuse:
                             carry = (e[0:n], e[2 * n:3 * n])
                     else:

@@ -129,6 +129,19 @@ int hedit_step_update(const float* e_u_src, const float* e_c_src, const float* e
                       const float* e_c_tar, int64_t stride_img, const float* x_k,
                       const float* x_base, float* x_out, int n_img, int elems, int k_gt0,
                       const hedit_step_coef* c, void* stream);
+/* Style guidance of the text + style loop (text-guided-n-style/inversion/h_edit.py:160-185), the latent-side
+ * arithmetic either side of the decoder / image-encoder pass:
+ *   step_tweedie: z0 = (x - sqrt(1-ab) e_tar) / sqrt(ab) * inv_scale, e_tar = e_u_tar + w_tar (e_c_tar - e_u_tar)
+ *                 (reverse_step_pred_x0, inversion_utils.py:128-140, and the 1/0.18215 of h_edit.py:173)
+ *   step_style:   x_out = x - rho g, g = chain * g_z, rho = rms(correction) / rms(g) * weight per image
+ *                 (h_edit.py:179-183; g_z = d loss / d z0 from hedit_vae_decode_vjp behind the image encoder,
+ *                 chain = inv_scale / sqrt(ab))
+ * eps operands as in step_update: pointer to image 0, image i at + i * stride_img; x / z0 / g_z / x_out [n_img][elems] */
+int hedit_step_tweedie(const float* e_u_tar, const float* e_c_tar, int64_t stride_img, const float* x, float* z0,
+                       int n_img, int elems, float w_tar, float sqrt_ab, float sqrt_1m_ab, float inv_scale, void* stream);
+int hedit_step_style(const float* e_u_src, const float* e_c_src, const float* e_u_tar, const float* e_c_tar,
+                     int64_t stride_img, const float* x, const float* g_z, float* x_out, int n_img, int elems,
+                     float w_hat, float w_tar, float chain, float weight, void* stream);
 int hedit_local_blend(float* const* h_maps, int n_maps, int heads, const float* alpha_layers,
                       const int32_t* enabled, float* xt, int n_img, int C, int H, int W, float th,
                       void* stream);
