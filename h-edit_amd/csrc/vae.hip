@@ -96,6 +96,9 @@ struct hedit_vae {
   // input-gradient twins of the decoder's head / tail weights, and a zero bias vector
   float *pq_t = nullptr, *d_out_t = nullptr, *zero_bias = nullptr;
   bf16_t* d_in_t = nullptr;
+  // the outstanding tape of hedit_vae_decode_keep (a DecodeTape), consumed by hedit_vae_decode_backward
+  void* tape = nullptr;
+  void (*tape_free)(void*) = nullptr;
 };
 
 namespace {
@@ -498,18 +501,26 @@ int mid_bwd(VF& f, const MidRec& rec, bf16_t** d) {
   return HEDIT_OK;
 }
 
-// forward; with d_image != null also the vector-Jacobian product d_z = (d image / d z)^T d_image: the
-// forward then keeps what the backward needs (block inputs, conv1 outputs, GroupNorm statistics)
-int decode_impl(hedit_vae* h, const float* z, int B, int lh, int lw, float* image, void* ws, size_t ws_bytes,
-                hipStream_t st, bool dry, size_t* peak, const float* d_image = nullptr, float* d_z = nullptr) {
-  VF f{h, B, st, Arena{}};
-  f.ar.dry = dry;
-  f.ar.base = reinterpret_cast<char*>(ws);
-  f.ar.cap = ws_bytes;
-  const bool grad = d_z != nullptr;
+// Everything a decoder backward pass needs from its forward: the arena (with the kept buffers still
+// allocated in it) and the per-block records.
+struct DecodeTape {
+  VF f;
+  MidRec mrec{};
+  std::vector<ResRec> rrec;
+  bf16_t* x = nullptr;       // input of conv_norm_out
+  float* st_out = nullptr;   // its GroupNorm statistics
+  int B = 0, lh = 0, lw = 0, H = 0, W = 0;
+  void* ws = nullptr;
+};
+
+// forward; grad = keep block inputs, conv1 outputs and GroupNorm statistics for decode_backward
+int decode_forward(hedit_vae* h, DecodeTape& T, const float* z, float* image, bool grad) {
+  VF& f = T.f;
+  const int B = f.B;
+  hipStream_t st = f.st;
   const hedit_vae_cfg& c = h->cfg;
   const int L = c.n_levels, LC = c.latent_channels;
-  int H = lh, W = lw;
+  int H = T.lh, W = T.lw;
   int ch = c.block_out_channels[L - 1];
   float* z2;
   TRY(aalloc(f, &z2, (size_t)B * LC * H * W));
@@ -518,16 +529,14 @@ int decode_impl(hedit_vae* h, const float* z, int B, int lh, int lw, float* imag
   TRY(aalloc(f, &x, (size_t)B * H * W * ch));
   RUN(f, conv_in_launch(z2, h->d_in_w, h->d_in_b, x, B, LC, H, W, ch, st));
   f.ar.free(z2);
-  MidRec mrec{};
-  std::vector<ResRec> rrec;
-  TRY(mid(f, h->d_mid, &x, H, W, grad ? &mrec : nullptr));
+  TRY(mid(f, h->d_mid, &x, H, W, grad ? &T.mrec : nullptr));
   for (int i = 0; i < L; ++i) {
     const VStage& s = h->up[i];
     for (const VRes& r : s.res) {
       bf16_t* y;
       if (grad) {
-        rrec.emplace_back();
-        TRY(resblock(f, r, x, H, W, &y, &rrec.back()));
+        T.rrec.emplace_back();
+        TRY(resblock(f, r, x, H, W, &y, &T.rrec.back()));
       } else {
         TRY(resblock(f, r, x, H, W, &y));
         f.ar.free(x);
@@ -545,25 +554,33 @@ int decode_impl(hedit_vae* h, const float* z, int B, int lh, int lw, float* imag
     ch = s.ch;
   }
   bf16_t* xn;
-  float* st_out = nullptr;
   TRY(aalloc(f, &xn, (size_t)B * H * W * ch));
-  TRY(groupnorm(f, x, xn, h->d_gn_g, h->d_gn_b, H * W, ch, 1, grad ? &st_out : nullptr));
+  TRY(groupnorm(f, x, xn, h->d_gn_g, h->d_gn_b, H * W, ch, 1, grad ? &T.st_out : nullptr));
   if (!grad) f.ar.free(x);
   if (image) RUN(f, conv_out_launch(xn, h->d_out_w, h->d_out_b, image, B, H, W, ch, c.in_channels, st));
   f.ar.free(xn);
-  if (!grad) {
-    if (peak) *peak = f.ar.peak;
-    return HEDIT_OK;
-  }
-  // ---------------- backward
+  T.x = x;
+  T.H = H; T.W = W;
+  return HEDIT_OK;
+}
+
+// d_z = (d image / d z)^T d_image from a tape made by decode_forward(grad = true)
+int decode_backward(hedit_vae* h, DecodeTape& T, const float* d_image, float* d_z) {
+  VF& f = T.f;
+  const int B = f.B;
+  hipStream_t st = f.st;
+  const hedit_vae_cfg& c = h->cfg;
+  const int L = c.n_levels, LC = c.latent_channels;
+  int H = T.H, W = T.W;
+  int ch = c.block_out_channels[0];
   bf16_t *d, *t;
   TRY(aalloc(f, &t, (size_t)B * H * W * ch));
   RUN(f, conv_in_launch(d_image, h->d_out_t, h->zero_bias, t, B, c.in_channels, H, W, ch, st));
   TRY(aalloc(f, &d, (size_t)B * H * W * ch));
-  TRY(groupnorm_bwd(f, x, t, nullptr, d, h->d_gn_g, h->d_gn_b, st_out, H * W, ch, 1));
+  TRY(groupnorm_bwd(f, T.x, t, nullptr, d, h->d_gn_g, h->d_gn_b, T.st_out, H * W, ch, 1));
   f.ar.free(t);
-  f.ar.free(x);
-  size_t ri = rrec.size();
+  f.ar.free(T.x);
+  size_t ri = T.rrec.size();
   for (int i = L - 1; i >= 0; --i) {
     const VStage& s = h->up[i];
     if (s.samp_w) {
@@ -579,7 +596,7 @@ int decode_impl(hedit_vae* h, const float* z, int B, int lh, int lw, float* imag
       d = dx;
     }
     for (size_t j = 0; j < s.res.size(); ++j) {
-      const ResRec& rec = rrec[--ri];
+      const ResRec& rec = T.rrec[--ri];
       bf16_t* dx;
       TRY(resblock_bwd(f, rec, d, &dx));
       f.ar.free(d);
@@ -588,7 +605,7 @@ int decode_impl(hedit_vae* h, const float* z, int B, int lh, int lw, float* imag
       d = dx;
     }
   }
-  TRY(mid_bwd(f, mrec, &d));
+  TRY(mid_bwd(f, T.mrec, &d));
   ch = c.block_out_channels[L - 1];
   float* dz2;
   TRY(aalloc(f, &dz2, (size_t)B * LC * H * W));
@@ -596,7 +613,25 @@ int decode_impl(hedit_vae* h, const float* z, int B, int lh, int lw, float* imag
   f.ar.free(d);
   RUN(f, mix1x1_nchw_launch(dz2, h->pq_t, nullptr, d_z, B, LC, LC, (long)H * W, 1.0f, st));
   f.ar.free(dz2);
-  if (peak) *peak = f.ar.peak;
+  return HEDIT_OK;
+}
+
+void tape_init(DecodeTape& T, hedit_vae* h, int B, int lh, int lw, void* ws, size_t ws_bytes, hipStream_t st, bool dry) {
+  T.f.h = h; T.f.B = B; T.f.st = st;
+  T.f.ar.dry = dry;
+  T.f.ar.base = reinterpret_cast<char*>(ws);
+  T.f.ar.cap = ws_bytes;
+  T.B = B; T.lh = lh; T.lw = lw; T.ws = ws;
+}
+
+// one call: forward, and with d_z != null also the backward
+int decode_impl(hedit_vae* h, const float* z, int B, int lh, int lw, float* image, void* ws, size_t ws_bytes,
+                hipStream_t st, bool dry, size_t* peak, const float* d_image = nullptr, float* d_z = nullptr) {
+  DecodeTape T;
+  tape_init(T, h, B, lh, lw, ws, ws_bytes, st, dry);
+  TRY(decode_forward(h, T, z, image, d_z != nullptr));
+  if (d_z) TRY(decode_backward(h, T, d_image, d_z));
+  if (peak) *peak = T.f.ar.peak;
   return HEDIT_OK;
 }
 
@@ -736,8 +771,14 @@ int hedit_vae_create(const hedit_vae_cfg* cfg, hedit_vae** out) {
   return HEDIT_OK;
 }
 
+static void drop_tape(hedit_vae* h) {
+  if (h->tape && h->tape_free) h->tape_free(h->tape);
+  h->tape = nullptr;
+}
+
 void hedit_vae_destroy(hedit_vae* h) {
   if (!h) return;
+  drop_tape(h);
   for (void* p : h->owned) if (p) (void)hipFree(p);
   delete h;
 }
@@ -833,6 +874,45 @@ int hedit_vae_decode_vjp(hedit_vae* h, const float* z, const float* d_image, int
   }
   return decode_impl(h, z, B, latent_h, latent_w, image, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream),
                      false, nullptr, d_image, d_z);
+}
+
+int hedit_vae_decode_keep(hedit_vae* h, const float* z, int B, int latent_h, int latent_w, float* image, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  ARG_CHECK(h && z && image && workspace, "null");
+  ARG_CHECK(B >= 1, "B");
+  TRY(check_latent(h, latent_h, latent_w));
+  if (hedit_vae_missing(h) != 0) {
+    hedit_set_error("VAE has " + std::to_string(hedit_vae_missing(h)) + " unloaded parameters");
+    return HEDIT_ERR_STATE;
+  }
+  drop_tape(h);
+  DecodeTape* T = new DecodeTape();
+  tape_init(*T, h, B, latent_h, latent_w, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), false);
+  const int rc = decode_forward(h, *T, z, image, true);
+  if (rc != HEDIT_OK) {
+    delete T;
+    return rc;
+  }
+  h->tape = T;
+  h->tape_free = [](void* p) { delete reinterpret_cast<DecodeTape*>(p); };
+  return HEDIT_OK;
+}
+
+int hedit_vae_decode_backward(hedit_vae* h, const float* d_image, float* d_z, void* workspace, void* stream) {
+  ARG_CHECK(h && d_image && d_z && workspace, "null");
+  if (!h->tape) {
+    hedit_set_error("hedit_vae_decode_backward: no forward is being kept (call hedit_vae_decode_keep first; one backward per forward)");
+    return HEDIT_ERR_STATE;
+  }
+  DecodeTape* T = reinterpret_cast<DecodeTape*>(h->tape);
+  if (T->ws != workspace) {
+    hedit_set_error("hedit_vae_decode_backward: not the workspace the kept forward ran in");
+    return HEDIT_ERR_ARG;
+  }
+  T->f.st = reinterpret_cast<hipStream_t>(stream);
+  const int rc = decode_backward(h, *T, d_image, d_z);
+  drop_tape(h);
+  return rc;
 }
 
 int hedit_vae_encode(hedit_vae* h, const float* image, int B, int height, int width, float* mean, void* workspace,

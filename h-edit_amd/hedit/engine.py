@@ -78,6 +78,7 @@ class HEditEngine:
         self.unet = model.unet
         self.lib = _lib.lib()
         self.dev = model.unet.device
+        self.style_chunk = 8      # images per decoder forward + backward inside style_step (~1.1 GiB of tape each)
 
     # ------------------------------------------------------------------ kernels
     def step_base(self, eps, xt, z, out, n, rows, coef):
@@ -115,11 +116,15 @@ class HEditEngine:
         encs = image_encoder if isinstance(image_encoder, (list, tuple)) else [image_encoder] * n
         g_z = torch.empty_like(x)
         with torch.enable_grad():
-            for i in range(n):
-                zi = z0[i:i + 1].clone().requires_grad_(True)
-                img = vae.decode(zi).sample
-                loss = torch.linalg.norm(encs[i].get_gram_matrix_residual(img))
-                g_z[i:i + 1] = torch.autograd.grad(outputs=loss, inputs=zi)[0]
+            # the images are independent: decode a chunk in one pass, one loss per image, and the gradient of
+            # the SUM w.r.t. the chunk's latents is the stack of the per-image gradients
+            for lo in range(0, n, self.style_chunk):
+                hi = min(n, lo + self.style_chunk)
+                zc = z0[lo:hi].clone().requires_grad_(True)
+                img = vae.decode(zc).sample
+                loss = sum(torch.linalg.norm(encs[i].get_gram_matrix_residual(img[i - lo:i - lo + 1]))
+                           for i in range(lo, hi))
+                g_z[lo:hi] = torch.autograd.grad(outputs=loss, inputs=zc)[0]
         out = torch.empty_like(x)
         _lib.check(self.lib.hedit_step_style(_lib.ptr(e_u_src), _lib.ptr(e_c_src), _lib.ptr(e_u_tar), _lib.ptr(e_c_tar),
                                              elems, _lib.ptr(x), _lib.ptr(g_z), _lib.ptr(out), n, elems,

@@ -55,18 +55,25 @@ class _DecodeFn(torch.autograd.Function):
     ``torch.autograd.grad(loss, latents)`` through ``model.vae.decode``
     (text-guided-n-style/inversion/h_edit.py:146-185).  The backward is one C call
     (hedit_vae_decode_vjp: forward with kept activations + input-gradient pass, all HIP); only the
-    gradient w.r.t. the latents exists -- the weights are constants here as in the reference."""
+    gradient w.r.t. the latents exists -- the weights are constants here as in the reference.
+    The forward leaves its tape in a workspace of the VAE object (hedit_vae_decode_keep) and the
+    backward consumes it (hedit_vae_decode_backward); if another differentiable decode of the same
+    VAE ran in between, the backward falls back to the one-call form (forward again + backward)."""
 
     @staticmethod
     def forward(ctx, z, vae):
         ctx.vae = vae
         ctx.save_for_backward(z)
-        return vae._decode_raw(z)
+        img, ctx.tape_id = vae._decode_keep(z)
+        return img
 
     @staticmethod
     def backward(ctx, d_image):
         (z,) = ctx.saved_tensors
-        return ctx.vae.decode_vjp(z, d_image), None
+        vae = ctx.vae
+        if vae._tape_id == ctx.tape_id and vae._tape_live:
+            return vae._decode_backward(z, d_image), None
+        return vae.decode_vjp(z, d_image), None
 
 
 class AutoencoderKL:
@@ -97,6 +104,8 @@ class AutoencoderKL:
             _lib.check(self._lib.hedit_vae_param_shape(self._h, i, C.byref(nd), dims))
             self.param_shapes[name] = tuple(dims[k] for k in range(nd.value))
         self._ws = None
+        self._ws_tape = None          # workspace holding the tape of the last differentiable decode
+        self._tape_id, self._tape_live = 0, False
 
     def __del__(self):
         try:
@@ -173,6 +182,34 @@ class AutoencoderKL:
         with torch.cuda.device(self.device):
             _lib.check(self._lib.hedit_vae_decode_vjp(self._h, _lib.ptr(z), _lib.ptr(d_image), B, lh, lw, _lib.ptr(dz),
                                                       None, _lib.ptr(ws), ws.numel(), _lib.cur_stream()))
+        return dz
+
+    def _decode_keep(self, z):
+        z = z.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        B, _, lh, lw = z.shape
+        need = self._lib.hedit_vae_workspace_bytes(self._h, B, lh, lw, 2)
+        if need == 0:
+            raise RuntimeError("hedit_vae_workspace_bytes failed: " + self._lib.hedit_last_error().decode())
+        if self._ws_tape is None or self._ws_tape.numel() < need:
+            self._ws_tape = None
+            self._ws_tape = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._ws_tape
+        img = torch.empty(B, self.config["in_channels"], lh * self.factor, lw * self.factor, dtype=torch.float32,
+                          device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.hedit_vae_decode_keep(self._h, _lib.ptr(z), B, lh, lw, _lib.ptr(img), _lib.ptr(ws),
+                                                       ws.numel(), _lib.cur_stream()))
+        self._tape_id += 1
+        self._tape_live = True
+        return img, self._tape_id
+
+    def _decode_backward(self, z, d_image):
+        d_image = d_image.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        dz = torch.empty(z.shape, dtype=torch.float32, device=self.device)
+        self._tape_live = False
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.hedit_vae_decode_backward(self._h, _lib.ptr(d_image), _lib.ptr(dz),
+                                                           _lib.ptr(self._ws_tape), _lib.cur_stream()))
         return dz
 
     def _decode_raw(self, z):

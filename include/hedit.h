@@ -184,6 +184,13 @@ int hedit_vae_decode(hedit_vae* h, const float* z, int B, int latent_h, int late
  * NULL) receives the decoded image as hedit_vae_decode would. */
 int hedit_vae_decode_vjp(hedit_vae* h, const float* z, const float* d_image, int B, int latent_h, int latent_w,
                          float* d_z, float* image, void* workspace, size_t workspace_bytes, void* stream);
+/* The same product in two calls, so that the caller's image encoder can run between them without a second
+ * decoder forward: decode_keep = hedit_vae_decode that leaves its tape in the workspace (sized with
+ * hedit_vae_workspace_bytes(.., 2)); decode_backward consumes it.  One outstanding forward per handle: a
+ * further decode_keep drops the previous tape; the workspace must not be written in between. */
+int hedit_vae_decode_keep(hedit_vae* h, const float* z, int B, int latent_h, int latent_w, float* image,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int hedit_vae_decode_backward(hedit_vae* h, const float* d_image, float* d_z, void* workspace, void* stream);
 /* image fp32 [B][in_channels][H][W] -> mean of the latent distribution, fp32 [B][latent_channels][H/f][W/f] */
 int hedit_vae_encode(hedit_vae* h, const float* image, int B, int height, int width, float* mean,
                      void* workspace, size_t workspace_bytes, void* stream);

@@ -191,3 +191,26 @@ def test_decode_vjp_sd15_shape_adjoint_identity():
     rhs = (v.double() * jtu.double()).sum().item()
     assert lhs > 0
     assert abs(lhs - rhs) / lhs < 2e-2      # measured 3e-4; the decoder is visibly nonlinear beyond eps ~ 0.1
+
+
+def test_kept_tape_backward_equals_one_call_vjp(tiny):
+    """autograd path (decode_keep + decode_backward) == hedit_vae_decode_vjp bit for bit, and an
+    interleaved second differentiable decode makes the first backward fall back, not misfire."""
+    hip, _ = tiny
+    dev = G.dev()
+    g = torch.Generator().manual_seed(21)
+    z1 = torch.randn(2, 4, 8, 8, generator=g).to(dev)
+    z2 = torch.randn(2, 4, 8, 8, generator=g).to(dev)
+    u = torch.randn(2, 3, 16, 16, generator=g).to(dev)
+    a = z1.clone().requires_grad_(True)
+    (ga,) = torch.autograd.grad((hip.decode(a).sample * u).sum(), a)
+    assert torch.equal(ga, hip.decode_vjp(z1, u))
+    a = z1.clone().requires_grad_(True)
+    b = z2.clone().requires_grad_(True)
+    ia = hip.decode(a).sample
+    ib = hip.decode(b).sample              # takes the tape slot
+    (gb,) = torch.autograd.grad((ib * u).sum(), b)
+    (ga2,) = torch.autograd.grad((ia * u).sum(), a)
+    G.sync()
+    assert torch.equal(gb, hip.decode_vjp(z2, u))
+    assert torch.equal(ga2, ga)
