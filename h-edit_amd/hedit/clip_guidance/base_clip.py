@@ -1,0 +1,189 @@
+"""The style image encoder of the combined text + style task -- drop-in for the reference's
+text-guided-n-style/clip_guidance/base_clip.py:30-66 (``CLIPEncoder``) on the slice of
+clip_guidance/clip/model.py it actually exercises.
+
+``get_gram_matrix_residual`` reads ``feats[2]`` only: the token features after the THIRD residual
+attention block of the CLIP ViT (base_clip.py:60-65, model.py:339-365), so this module holds the
+patch embedding, ln_pre and the first ``n_blocks`` = 3 blocks; the other nine blocks, ln_post, the
+projection and the text tower cannot influence the residual or its gradient and are not built.
+Parameters carry the OpenAI CLIP state_dict names (``visual.conv1.weight`` ...), so a local
+checkpoint of the reference's model (ViT-B/16) loads directly; nothing is ever downloaded.
+
+Like the CLIP text encoder this small network stays on PyTorch-ROCm
+(fp16 weights, LayerNorm in fp32, QuickGELU, as model.py:153-164,414-435): it is ~0.1 % of the
+FLOPs of a guided step and torch autograd differentiates it exactly as in the reference; the
+decoder it back-propagates into is the HIP executor (hedit.vae, hedit_vae_decode_backward)."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+VIT_B16 = dict(width=768, layers=3, heads=12, patch_size=16, input_resolution=224)
+
+
+class _Block(nn.Module):
+    """ResidualAttentionBlock (model.py:167-190): x + MHA(LN(x)); x + MLP(LN(x)), QuickGELU."""
+
+    def __init__(self, d, heads):
+        super().__init__()
+        self.heads = heads
+        self.ln_1 = nn.LayerNorm(d)
+        self.attn = nn.Module()
+        self.attn.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.attn.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.attn.out_proj = nn.Linear(d, d)
+        self.ln_2 = nn.LayerNorm(d)
+        self.mlp = nn.Module()
+        self.mlp.c_fc = nn.Linear(d, 4 * d)
+        self.mlp.c_proj = nn.Linear(4 * d, d)
+
+    @staticmethod
+    def _ln(ln, x):                      # LayerNorm computed in fp32 whatever the stream dtype (model.py:153-159)
+        return F.layer_norm(x.float(), ln.normalized_shape, ln.weight.float(), ln.bias.float(), ln.eps).to(x.dtype)
+
+    def forward(self, x):                # x: (N, L, D)
+        N, L, D = x.shape
+        h = self.heads
+        qkv = F.linear(self._ln(self.ln_1, x), self.attn.in_proj_weight, self.attn.in_proj_bias)
+        q, k, v = (t.reshape(N, L, h, D // h).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+        p = torch.softmax((q * (D // h) ** -0.5) @ k.transpose(-1, -2), dim=-1)
+        a = (p @ v).transpose(1, 2).reshape(N, L, D)
+        x = x + self.attn.out_proj(a)
+        y = self.mlp.c_fc(self._ln(self.ln_2, x))
+        return x + self.mlp.c_proj(y * torch.sigmoid(1.702 * y))
+
+
+class _Visual(nn.Module):
+    def __init__(self, width, layers, heads, patch_size, input_resolution):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, width, patch_size, stride=patch_size, bias=False)
+        self.class_embedding = nn.Parameter(torch.zeros(width))
+        self.positional_embedding = nn.Parameter(torch.zeros((input_resolution // patch_size) ** 2 + 1, width))
+        self.ln_pre = nn.LayerNorm(width)
+        self.transformer = nn.Module()
+        self.transformer.resblocks = nn.ModuleList(_Block(width, heads) for _ in range(layers))
+
+
+class ClipVisualPrefix(nn.Module):
+    """conv1 -> [class; patches] + positional -> ln_pre -> the first ``layers`` blocks (model.py:339-357)."""
+
+    def __init__(self, width=768, layers=3, heads=12, patch_size=16, input_resolution=224):
+        super().__init__()
+        self.input_resolution = input_resolution
+        self.visual = _Visual(width, layers, heads, patch_size, input_resolution)
+
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    def block_features(self, x):
+        """-> token features after the last kept block, (N, L, D) (the reference's ``feats[layers-1]`` is
+        the same tensor in (L, N, D) layout)."""
+        v = self.visual
+        x = v.conv1(x.type(self.dtype))
+        x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+        cls = v.class_embedding.to(x.dtype) + torch.zeros(x.shape[0], 1, x.shape[-1], dtype=x.dtype, device=x.device)
+        x = torch.cat([cls, x], dim=1) + v.positional_embedding.to(x.dtype)
+        x = _Block._ln(v.ln_pre, x)
+        for blk in v.transformer.resblocks:
+            x = blk(x)
+        return x
+
+    def load_clip_state_dict(self, sd):
+        """Load from a full OpenAI-CLIP state_dict (extra keys -- later blocks, text tower -- are ignored)."""
+        own = self.state_dict()
+        missing = [k for k in own if k not in sd]
+        if missing:
+            raise KeyError(f"CLIP state_dict lacks {missing[:4]} ({len(missing)} keys)")
+        self.load_state_dict({k: sd[k].to(own[k].dtype) for k in own})
+        return self
+
+    def init_random(self, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.endswith("ln_1.weight") or name.endswith("ln_2.weight") or name.endswith("ln_pre.weight"):
+                    p.fill_(1.0)
+                elif p.dim() == 1 and "embedding" not in name:
+                    p.zero_()
+                else:
+                    fan = p.shape[-1] if p.dim() == 2 else (p[0].numel() if p.dim() > 2 else p.shape[0])
+                    p.copy_((torch.randn(p.shape, generator=g) * fan ** -0.5).to(p.dtype))
+        return self
+
+
+def read_clip_checkpoint(path):
+    """A local OpenAI CLIP file: TorchScript archive (ViT-B-16.pt as the reference downloads it,
+    base_clip.py:14-27) or a plain state_dict."""
+    try:
+        return torch.jit.load(path, map_location="cpu").state_dict()
+    except RuntimeError:
+        sd = torch.load(path, map_location="cpu")
+        return sd.get("state_dict", sd) if isinstance(sd, dict) else sd.state_dict()
+
+
+class CLIPEncoder(nn.Module):
+    """Reference signature ``CLIPEncoder(need_ref=False, ref_path=None)`` plus where the weights come
+    from (the reference downloads them; this build is offline): ``clip_path`` = local checkpoint,
+    or ``clip_model`` = a ready ClipVisualPrefix, else seeded random weights (synthetic runs)."""
+
+    def __init__(self, need_ref=False, ref_path=None, clip_path=None, clip_model=None, device=None,
+                 dtype=torch.float16, seed=0):
+        super().__init__()
+        if clip_model is None:
+            if clip_path is not None:
+                sd = read_clip_checkpoint(clip_path)
+                w = sd["visual.conv1.weight"]
+                cfg = dict(width=w.shape[0], layers=3, heads=w.shape[0] // 64, patch_size=w.shape[-1],
+                           input_resolution=w.shape[-1] * round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5))
+                clip_model = ClipVisualPrefix(**cfg).load_clip_state_dict(sd)
+            else:
+                clip_model = ClipVisualPrefix(**VIT_B16).init_random(seed)
+            clip_model = clip_model.to(dtype)
+        self.clip_model = clip_model.eval()
+        self.size = self.clip_model.input_resolution
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        # images arrive in [-1, 1]: Normalize(mean*2-1, std*2) of base_clip.py:38-41
+        self.register_buffer("_mean", torch.tensor([m * 2 - 1 for m in CLIP_MEAN]).view(1, 3, 1, 1))
+        self.register_buffer("_std", torch.tensor([s * 2 for s in CLIP_STD]).view(1, 3, 1, 1))
+        self._gram_ref = None
+        if device is not None:
+            self.to(device)
+        if need_ref:
+            self.set_reference(load_style_reference(ref_path, self.size).to(self._mean.device))
+
+    def preprocess(self, im):
+        return (im - self._mean.to(im.dtype)) / self._std.to(im.dtype)
+
+    def set_reference(self, ref):
+        """ref: (1, 3, S, S), already CLIP-normalised (base_clip.py:43-53)."""
+        self.ref = ref
+        self._gram_ref = None
+
+    def _tokens(self, im):
+        return self.clip_model.block_features(im)[0, 1:, :]        # batch item 0, class token dropped
+
+    def get_gram_matrix_residual(self, im1):
+        """Gram matrix (D x D) of the block-3 patch tokens of ``im1`` minus that of the style reference
+        (base_clip.py:55-66).  The reference's Gram matrix does not depend on ``im1``; it is computed
+        on first use and kept (the reference recomputes it every call with the same result)."""
+        im1 = F.interpolate(im1, size=(self.size, self.size), mode="bicubic")
+        feat1 = self._tokens(self.preprocess(im1))
+        if self._gram_ref is None:
+            with torch.no_grad():
+                feat2 = self._tokens(self.ref)
+                self._gram_ref = torch.mm(feat2.t(), feat2)
+        return torch.mm(feat1.t(), feat1) - self._gram_ref
+
+
+def load_style_reference(path, size=224):
+    """PIL RGB -> bilinear resize to size x size -> [0,1] CHW -> Normalize(CLIP mean, std) -> (1,3,S,S)
+    (base_clip.py:43-53: torchvision ToTensor + Normalize restated with numpy)."""
+    from PIL import Image
+    img = Image.open(path).convert("RGB").resize((size, size), Image.Resampling.BILINEAR)
+    x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255)
+    mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
+    std = torch.tensor(CLIP_STD).view(3, 1, 1)
+    return ((x - mean) / std).unsqueeze(0)

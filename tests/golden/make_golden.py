@@ -471,6 +471,87 @@ def gen_style_child(out):
     np.savez_compressed(os.path.join(out, "g9_style.npz"), **d)
     with open(os.path.join(out, "g9_style.json"), "w") as f:
         json.dump(meta, f, indent=0)
+    gen_clip(out)
+
+
+def name_seed(name):
+    import zlib
+    return zlib.crc32(name.encode()) % 100003
+
+
+def gen_clip(out):
+    """G10: the reference's CLIPEncoder.get_gram_matrix_residual (clip_guidance/base_clip.py:55-66) and its
+    CLIP ViT (clip_guidance/clip/model.py, UNMODIFIED) at toy width: 4 blocks of width 64, patch 32 at
+    the 224 x 224 the encoder always resizes to.  Third-party imports missing here are stubbed
+    (torchvision.transforms: Normalize / ToTensor / Compose with their documented arithmetic; ftfy), the
+    download is replaced by a locally built CLIP with hash-seeded weights, and Tensor.cuda() is the
+    identity (no GPU in the build container).  Runs inside the n-style child interpreter."""
+    from PIL import Image
+    from helpers.tiny import hash_normal
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean = torch.tensor(mean).view(-1, 1, 1)
+            self.std = torch.tensor(std).view(-1, 1, 1)
+
+        def __call__(self, x):
+            return (x - self.mean.to(x)) / self.std.to(x)
+
+    class ToTensor:
+        def __call__(self, pic):
+            return torch.from_numpy(np.asarray(pic, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255)
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms", Normalize=Normalize, ToTensor=ToTensor, Compose=Compose,
+                          Resize=object, CenterCrop=object, InterpolationMode=types.SimpleNamespace(BICUBIC=3))
+    _stub("ftfy", fix_text=lambda s: s)
+    sys.path.insert(0, REF_STYLE)
+    import clip_guidance.base_clip as bc
+    from clip_guidance.clip import model as cm
+    clip = cm.CLIP(embed_dim=32, image_resolution=224, vision_layers=4, vision_width=64, vision_patch_size=32,
+                   context_length=8, vocab_size=16, transformer_width=64, transformer_heads=1, transformer_layers=1)
+    with torch.no_grad():
+        for name, p in clip.named_parameters():
+            if not name.startswith("visual."):
+                continue
+            v = hash_normal(tuple(p.shape), name_seed(name))
+            if name.endswith(("ln_1.weight", "ln_2.weight", "ln_pre.weight", "ln_post.weight")):
+                v = 1.0 + 0.1 * v
+            elif p.dim() == 1:
+                v = 0.1 * v
+            else:
+                v = v * (float(p[0].numel()) ** -0.5 if p.dim() > 1 else 1.0)
+            p.copy_(v)
+    clip.eval()
+    bc.load_clip_to_cpu = lambda: clip
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    ref_rgb = synthetic_rgb(40, 56, 3)
+    tmp = os.path.join(out, "_style_ref_tmp.png")
+    Image.fromarray(ref_rgb).save(tmp)
+    enc = bc.CLIPEncoder(need_ref=True, ref_path=tmp)
+    os.remove(tmp)
+    d = {"ref_rgb": ref_rgb, "ref_tensor_sub": npy(enc.ref[0, :, ::8, ::8])}
+    for i, hw in enumerate(((64, 64), (96, 80))):
+        im = (hash_normal((1, 3) + hw, 900 + i) * 0.6).requires_grad_(True)
+        res = enc.get_gram_matrix_residual(im)
+        loss = torch.linalg.norm(res)
+        (g,) = torch.autograd.grad(loss, im)
+        x = torch.nn.functional.interpolate(im.detach(), size=(224, 224), mode="bicubic")
+        _, feats = clip.encode_image_with_features(enc.preprocess(x))
+        d[f"residual{i}"] = npy(res)
+        d[f"loss{i}"] = np.array([loss.item()], dtype=np.float64)
+        d[f"grad{i}"] = npy(g)
+        d[f"feat{i}"] = npy(feats[2][:, 0, :])
+    np.savez_compressed(os.path.join(out, "g10_clip.npz"), **d)
 
 
 def gen_style(out):

@@ -1,0 +1,90 @@
+"""hedit.clip_guidance.CLIPEncoder (the style image encoder) against
+vectors produced by RUNNING the reference's CLIPEncoder.get_gram_matrix_residual and CLIP ViT
+(text-guided-n-style/clip_guidance/base_clip.py, clip/model.py) at toy width -- tests/golden/g10_clip.npz,
+generator tests/golden/make_golden.py::gen_clip.  fp32 on CPU here; the GPU runs use fp16 weights."""
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers.tiny import hash_normal  # noqa: E402
+from hedit.clip_guidance import CLIPEncoder  # noqa: E402
+from hedit.clip_guidance.base_clip import ClipVisualPrefix, load_style_reference  # noqa: E402
+
+G10 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_clip.npz")
+
+
+def toy_prefix():
+    m = ClipVisualPrefix(width=64, layers=3, heads=1, patch_size=32, input_resolution=224)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            v = hash_normal(tuple(p.shape), zlib.crc32(name.encode()) % 100003)
+            if name.endswith(("ln_1.weight", "ln_2.weight", "ln_pre.weight")):
+                v = 1.0 + 0.1 * v
+            elif p.dim() == 1:
+                v = 0.1 * v
+            else:
+                v = v * float(p[0].numel()) ** -0.5
+            p.copy_(v)
+    return m
+
+
+@pytest.fixture(scope="module")
+def enc(tmp_path_factory):
+    from PIL import Image
+    g = np.load(G10)
+    path = str(tmp_path_factory.mktemp("style") / "ref.png")
+    Image.fromarray(g["ref_rgb"]).save(path)
+    return CLIPEncoder(need_ref=True, ref_path=path, clip_model=toy_prefix()), g
+
+
+def test_style_reference_preprocessing(enc):
+    e, g = enc
+    assert e.ref.shape == (1, 3, 224, 224)
+    assert np.allclose(e.ref[0, :, ::8, ::8].numpy(), g["ref_tensor_sub"], atol=1e-6)
+
+
+@pytest.mark.parametrize("i,hw", [(0, (64, 64)), (1, (96, 80))])
+def test_gram_residual_and_gradient_match_reference(enc, i, hw):
+    e, g = enc
+    im = (hash_normal((1, 3) + hw, 900 + i) * 0.6).requires_grad_(True)
+    x = torch.nn.functional.interpolate(im.detach(), size=(224, 224), mode="bicubic")
+    feat = e.clip_model.block_features(e.preprocess(x))[0]
+    assert np.allclose(feat.detach().numpy(), g[f"feat{i}"], atol=2e-5, rtol=1e-5)     # feats[2][:, 0, :]
+    res = e.get_gram_matrix_residual(im)
+    loss = torch.linalg.norm(res)
+    (grad,) = torch.autograd.grad(loss, im)
+    assert res.shape == (64, 64)
+    assert np.allclose(res.detach().numpy(), g[f"residual{i}"], atol=2e-3, rtol=1e-4)
+    assert abs(loss.item() - g[f"loss{i}"][0]) < 1e-4 * g[f"loss{i}"][0]
+    assert np.allclose(grad.numpy(), g[f"grad{i}"], atol=1e-4 * np.abs(g[f"grad{i}"]).max(), rtol=1e-3)
+
+
+def test_reads_full_clip_state_dict_names():
+    """a full OpenAI-CLIP state_dict (12 blocks + text tower) loads; only the first three blocks are used"""
+    m = toy_prefix()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["visual.transformer.resblocks.7.ln_1.weight"] = torch.ones(64)
+    sd["visual.proj"] = torch.zeros(64, 32)
+    sd["token_embedding.weight"] = torch.zeros(16, 64)
+    m2 = ClipVisualPrefix(width=64, layers=3, heads=1, patch_size=32, input_resolution=224).load_clip_state_dict(sd)
+    x = hash_normal((1, 3, 224, 224), 5)
+    assert torch.equal(m.block_features(x), m2.block_features(x))
+    del sd["visual.ln_pre.bias"]
+    with pytest.raises(KeyError):
+        ClipVisualPrefix(width=64, layers=3, heads=1, patch_size=32, input_resolution=224).load_clip_state_dict(sd)
+
+
+def test_vit_b16_shape():
+    m = ClipVisualPrefix()          # the reference's model_name = "ViT-B/16" (base_clip.py:11)
+    sd = m.state_dict()
+    assert sd["visual.conv1.weight"].shape == (768, 3, 16, 16)
+    assert sd["visual.positional_embedding"].shape == (197, 768)
+    assert sd["visual.transformer.resblocks.2.attn.in_proj_weight"].shape == (2304, 768)
+    assert len(m.visual.transformer.resblocks) == 3
