@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--images", type=int, default=24, help="images edited in lock-step per GPU (one 'step'); 24 = 120-row UNet calls: +5 % over 8 and +2.5 % over 16, flat beyond")
     ap.add_argument("--diffusion-steps", type=int, default=50)
     ap.add_argument("--opt-steps", type=int, default=1, help="implicit optimisation ('Langevin') steps K")
+    ap.add_argument("--workload", choices=("p2p", "style"), default="p2p",
+                    help="p2p = BASELINE configs[1] (the quoted metric, default); style = configs[4], combined "
+                         "text + CLIP-style editing: every step adds VAE decode forward + backward and the style encoder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-every", type=int, default=25, help="bracket every n-th UNet call with HIP events")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny network instead of SD-1.5 shape")
@@ -115,6 +118,18 @@ def main():
     enc = ClipTextEncoder(dim=cfg["cross_attention_dim"], layers=2 if args.tiny else 12,
                           heads=4 if args.tiny else 12, seed=7).to(dev)
     model = HEditPipeline(unet, DDIMScheduler(), tok, enc, None, dev)
+    style = None
+    if args.workload == "style":
+        from hedit.clip_guidance import CLIPEncoder
+        from hedit.clip_guidance.base_clip import ClipVisualPrefix
+        from hedit.vae import AutoencoderKL, TINY_VAE_CONFIG
+        model.vae = AutoencoderKL(TINY_VAE_CONFIG if args.tiny else None, device=dev)
+        model.vae.init_random(11)
+        clip = (ClipVisualPrefix(width=64, layers=3, heads=1, patch_size=32, input_resolution=224) if args.tiny
+                else ClipVisualPrefix()).init_random(13).half()
+        senc = CLIPEncoder(clip_model=clip, device=dev)
+        senc.set_reference(torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(17)).to(dev))
+        style = (senc, 0.5)
     T = args.diffusion_steps
     model.scheduler.set_timesteps(T)
     eng = HEditEngine(model)
@@ -173,7 +188,7 @@ def main():
         register_attention_control(model, cb)
         return eng.run(xT, zs, prompt_pairs, cfg_scales, cb, eta=1.0, p2p=True, implicit=True, K=K, w_rec=0.1,
                        after_skip_steps=T, ddim_inv=False, ctx=(null, src, tar), fuse_src_pass=not args.no_fuse_src,
-                       reuse_orig_eps=args.reuse_orig_eps)
+                       reuse_orig_eps=args.reuse_orig_eps, style=style)
 
     for _ in range(args.warmup):
         one_step()
@@ -200,7 +215,7 @@ def main():
 
     # auxiliary (outside the timed region): BASELINE configs[1] read literally = ONE image; latency
     single_s = None
-    if not args.no_single:
+    if not args.no_single and style is None:
         def one_image():
             c1 = PCU.make_controller(prompts=list(prompt_pairs[0]), is_replace_controller=pairs[0][3],
                                      cross_replace_steps=0.4, self_replace_steps=0.35,
@@ -232,6 +247,9 @@ def main():
     sample_fwd_per_img = (4 + 5 * K) * T          # the reference's count (algorithmic work of the metric)
     evaluated_per_img = sample_fwd_per_img - (2 * (T - 1) if args.reuse_orig_eps else 0)
     total_flops = imgs * evaluated_per_img * (FLOP_PER_SAMPLE_FWD if not args.tiny else 0.0)
+    if style is not None and not args.tiny:
+        # per image and inner step: decoder forward (1257.5 GMAC) + its input-gradient pass (same convs, transposed)
+        total_flops += imgs * T * K * 2 * (2 * 1.2575e12)
     # dominant kernel = the class with the largest sampled time
     dom = max(prof.items(), key=lambda kv: kv[1][0])
     dk, (dms, dfl, dcnt) = dom
@@ -257,18 +275,22 @@ def main():
             pass
 
     cpu = None
-    if world == 1 and not args.no_cpu_baseline and not args.tiny:
+    if world == 1 and not args.no_cpu_baseline and not args.tiny and style is None:
         cpu = cpu_baseline(cfg, sd_cpu, T, K)
 
     out = {
-        "metric": "edited images/sec (512^2, 50 steps, K Langevin)", "value": round(imgs / elapsed, 4),
+        "metric": "edited images/sec (512^2, 50 steps, K Langevin)" + (" + style guidance" if style else ""), "value": round(imgs / elapsed, 4),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: text-guided h_Edit_p2p_implicit (h-Edit-R + P2P), "
-                               "SD-1.5-shaped random-init UNet (859.5M), 64x64 latent (512^2 image), "
-                               f"{T} DDIM steps, K={K} implicit step(s), CFG (1,5,7.5), xa 0.4, sa 0.35; "
-                               f"{n} independent images per GPU in lock-step",
+        "config": {"workload": ("BASELINE configs[1]: text-guided h_Edit_p2p_implicit (h-Edit-R + P2P), "
+                                "SD-1.5-shaped random-init UNet (859.5M), 64x64 latent (512^2 image), "
+                                f"{T} DDIM steps, K={K} implicit step(s), CFG (1,5,7.5), xa 0.4, sa 0.35; "
+                                f"{n} independent images per GPU in lock-step") if style is None else
+                               ("BASELINE configs[4] per GPU: text-guided-n-style h_Edit_p2p_implicit (text + CLIP-style "
+                                "editing), SD-1.5-shaped random-init UNet + SD VAE decoder forward/backward in every "
+                                f"step + ViT-B/16 style encoder (fp16, first 3 blocks), {T} steps, K={K}, "
+                                f"weight_edit_clip 0.5; {n} independent images per GPU in lock-step"),
                    "images_per_gpu": n, "unet_sample_forwards_per_image": sample_fwd_per_img,
                    "unet_sample_forwards_evaluated_per_image": evaluated_per_img,
                    "reuse_orig_eps": bool(args.reuse_orig_eps),

@@ -163,7 +163,9 @@ class CLIPEncoder(nn.Module):
         self._gram_ref = None
 
     def _tokens(self, im):
-        return self.clip_model.block_features(im)[0, 1:, :]        # batch item 0, class token dropped
+        # batch item 0, class token dropped.  The Gram matrices and their norm are accumulated in fp32: with
+        # fp16 tokens (the reference's dtype) sums over 196 tokens x 768^2 entries leave the fp16 range easily
+        return self.clip_model.block_features(im)[0, 1:, :].float()
 
     def get_gram_matrix_residual(self, im1):
         """Gram matrix (D x D) of the block-3 patch tokens of ``im1`` minus that of the style reference

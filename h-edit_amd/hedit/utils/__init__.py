@@ -1,1 +1,1 @@
-from .utils import image_grid, load_512, tensor_to_pil  # noqa: F401
+from .utils import dataset_from_json, image_grid, load_512, tensor_to_pil  # noqa: F401

@@ -79,3 +79,10 @@ def image_grid(imgs, rows=1, cols=None, size=None, titles=None, text_pos=(0, 0))
         y = i // cols * h + (delta if delta and i > 0 else 0)
         grid.paste(im, box=(i % cols * w, y))
     return grid
+
+
+def dataset_from_json(json_location):
+    """text-guided-n-style/utils/utils.py:107-111."""
+    import json
+    with open(json_location, 'r') as stream:
+        return json.load(stream)

@@ -96,3 +96,38 @@ def test_from_pretrained_round_trip(tmp_path):
     assert back.scheduler.config.steps_offset == 1
     with pytest.raises(FileNotFoundError):
         HEditPipeline.from_pretrained(str(tmp_path / "nope"), device=dev)
+
+
+def test_style_driver_writes_edited_images(tmp_path, capsys):
+    """main_edit.py (reference text-guided-n-style/main_edit.py:103-247): demo.json with a style image per
+    entry -> encode, DDPM inversion, text + style editing, decode, PNG per entry; prints the CLIP loss."""
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("hedit_main_edit", os.path.join(ROOT, "h-edit_amd", "main_edit.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    d = tmp_path / "demo"
+    (d / "styles").mkdir(parents=True)
+    y, x = np.mgrid[0:96, 0:128]
+    data = {}
+    for i, (src, tar, blend) in enumerate([("an orange van with surfboards on top", "an orange van with flowers on top",
+                                            "surfboards flowers"),
+                                           ("a round cake on a plate", "a square cake on a wooden plate", "")]):
+        img = np.stack([(x * (i + 2)) % 256, (y * 3 + i * 40) % 256, (x + y) % 256], -1).astype(np.uint8)
+        Image.fromarray(img).save(d / f"{i:012d}.jpg")
+        sty = np.stack([(x * y + i) % 256, (x * 7) % 256, (y * 5) % 256], -1).astype(np.uint8)
+        Image.fromarray(sty).save(d / "styles" / f"s{i}.png")
+        data[f"{i:012d}"] = dict(image_path=f"{i:012d}.jpg", original_prompt=src, editing_prompt=tar,
+                                 editing_instruction="", blended_word=blend, style=f"styles/s{i}.png")
+    with open(d / "demo.json", "w") as f:
+        json.dump(data, f)
+    out = tmp_path / "results"
+    written = drv.main(["--dataset", str(d) + "/", "--output_path", str(out), "--random_init", "--tiny",
+                        "--num_diffusion_steps", "4", "--weight_edit_clip", "0.5"])
+    assert len(written) == 2
+    for p in written:
+        assert p.startswith(str(out)) and "_w_style_0.5_" in p and os.path.exists(p)
+        im = np.array(Image.open(p))
+        assert im.shape == (256, 256, 3) and im.std() > 0
+    assert capsys.readouterr().out.count("loss from CLIP:") == 2
+    with pytest.raises(NotImplementedError):
+        drv.main(["--dataset", str(d) + "/", "--random_init", "--tiny", "--mode", "ef_p2p"])

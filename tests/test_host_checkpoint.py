@@ -64,3 +64,21 @@ def test_driver_flags_match_the_reference_cli():
     assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed"}
     b = vars(m.build_parser().parse_args(["--implicit", "--mode", "h_edit_D_p2p", "--eta", "0.0", "--edit_category_list", "0", "3"]))
     assert b["implicit"] is True and b["eta"] == 0.0 and b["edit_category_list"] == ["0", "3"]
+
+
+def test_style_driver_flags_match_the_reference_cli():
+    """h-edit_amd/main_edit.py keeps the flag names and defaults of the reference's
+    text-guided-n-style/main_edit.py:33-73 (note --implicit is store_false there: implicit by default)."""
+    import importlib.util
+    sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+    spec = importlib.util.spec_from_file_location("hedit_main_edit_cli", os.path.join(ROOT, "h-edit_amd", "main_edit.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    a = vars(m.build_parser().parse_args([]))
+    reference_defaults = dict(device_num=0, dataset="./assets/demo/", output_path="./results/demo/", mode="h_edit_R_p2p",
+                              num_diffusion_steps=50, skip=0, eta=1.0, cfg_src=1.0, cfg_src_edit=5.0, cfg_tar=7.5,
+                              implicit=True, optimization_steps=1, xa=0.4, sa=0.35, weight_edit_clip=0.5,
+                              weight_edit_clip_for_ef=1.5)
+    for k, v in reference_defaults.items():
+        assert a[k] == v, k
+    assert set(a) - set(reference_defaults) == {"model_path", "clip_path", "random_init", "tiny", "seed"}
