@@ -84,9 +84,13 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const bf16_t* __res
   }
 }
 
-// stage 2: fold the slabs in a fixed order -> (mean_g(t), mean_g(t xh)) per (batch, group)
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, float* __restrict__ ms,
-                                                              int HW, int C, int G, int nslab) {
+// stage 2: fold the slabs in a fixed order -> m1 = mean_g(t), m2 = mean_g(t xh) per (batch, group), then
+// the per-(batch, channel) coefficients of stage 3.  With A = r gamma, D = beta - mu A (so z = A x + D):
+//   dx = A dz - B x + E,   B = r^2 m2,   E = mu r^2 m2 - r m1
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ stats,
+                                                              float* __restrict__ coef, int HW, int C, int G, int nslab) {
+  __shared__ float m1s[64], m2s[64];
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int g = wave; g < G; g += 4) {
@@ -100,42 +104,55 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
     q = wave_sum(q);
     if (lane == 0) {
       const float n = (float)HW * (float)(C / G);
-      *reinterpret_cast<float2*>(ms + ((long)b * G + g) * 2) = make_float2(s / n, q / n);
+      m1s[g] = s / n;
+      m2s[g] = q / n;
     }
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    const float2 st = *reinterpret_cast<const float2*>(stats + ((long)b * G + g) * 2);
+    const float mu = st.x, r = st.y;
+    const float A = r * gamma[c];
+    const float Bc = r * r * m2s[g];
+    *reinterpret_cast<float4*>(coef + ((long)b * C + c) * 4) = make_float4(A, Bc, mu * Bc - r * m1s[g], beta[c] - mu * A);
   }
 }
 
-// stage 3: dx = r (t - m1 - xh m2) (+ add)
+// stage 3: dx = A dz - B x + E (+ add), dz = dy * silu'(A x + D).  Same thread layout as stage 1: a thread
+// keeps the coefficients of its 8 channels in registers over the pixels of its slab.
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                            const bf16_t* __restrict__ add, bf16_t* __restrict__ dx,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ stats, const float* __restrict__ ms,
-                                                           long total_v, int HW, int C, int G, int silu) {
+                                                           const float* __restrict__ coef, int HW, int C, int nslab, int silu) {
   const int CV = C / 8;
-  const int cpg = C / G;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_v; i += (long)gridDim.x * 256) {
-    const long pix = i / CV;
-    const int cv = (int)(i - pix * CV);
-    const int b = (int)(pix / HW);
-    float xf[8], df[8], af[8], o[8];
-    unpack8(*reinterpret_cast<const uint4*>(x + i * 8), xf);
-    unpack8(*reinterpret_cast<const uint4*>(dy + i * 8), df);
-    if (add) unpack8(*reinterpret_cast<const uint4*>(add + i * 8), af);
+  const int slab = blockIdx.x, b = blockIdx.y;
+  const int pix_per = (HW + nslab - 1) / nslab;
+  const int p0 = slab * pix_per;
+  int p1 = p0 + pix_per;
+  if (p1 > HW) p1 = HW;
+  const int R = 256 / CV;
+  const int r = threadIdx.x / CV, cv = threadIdx.x % CV;
+  if (r >= R) return;
+  float4 k[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) k[j] = *reinterpret_cast<const float4*>(coef + ((long)b * C + cv * 8 + j) * 4);
+  const long base = (long)b * HW * C + cv * 8;
+  for (int p = p0 + r; p < p1; p += R) {
+    const long o = base + (long)p * C;
+    float xf[8], df[8], af[8], out[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + o), xf);
+    unpack8(*reinterpret_cast<const uint4*>(dy + o), df);
+    if (add) unpack8(*reinterpret_cast<const uint4*>(add + o), af);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = cv * 8 + j;
-      const int g = c / cpg;
-      const float2 st = *reinterpret_cast<const float2*>(stats + ((long)b * G + g) * 2);
-      const float2 m = *reinterpret_cast<const float2*>(ms + ((long)b * G + g) * 2);
-      const float ga = gamma[c];
-      const float xh = (xf[j] - st.x) * st.y;
       float dz = df[j];
-      if (silu) dz *= silu_grad(ga * xh + beta[c]);
-      float v = st.y * (dz * ga - m.x - xh * m.y);
+      if (silu) dz *= silu_grad(k[j].x * xf[j] + k[j].w);
+      float v = k[j].x * dz - k[j].y * xf[j] + k[j].z;
       if (add) v += af[j];
-      o[j] = v;
+      out[j] = v;
     }
-    *reinterpret_cast<uint4*>(dx + i * 8) = pack8(o);
+    *reinterpret_cast<uint4*>(dx + o) = pack8(out);
   }
 }
 
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(256) void flip_oihw_kernel(const float* __restrict_
 }  // namespace
 
 size_t groupnorm_bwd_ws_bytes(int B, int HW, int C) {
-  return ((size_t)B * gb_nslab(B, HW, C) * 64 * 2 + (size_t)B * 64 * 2) * sizeof(float);
+  return ((size_t)B * gb_nslab(B, HW, C) * 64 * 2 + (size_t)B * C * 4) * sizeof(float);
 }
 
 int groupnorm_bwd_launch(const bf16_t* x, const bf16_t* dy, const bf16_t* add, bf16_t* dx, const float* gamma,
@@ -272,17 +289,19 @@ int groupnorm_bwd_launch(const bf16_t* x, const bf16_t* dy, const bf16_t* add, b
             "groupnorm_bwd: C % 8, C % G, G <= 64, C/8 a divisor of 256");
   const int nslab = gb_nslab(B, HW, C);
   float* part = ws;
-  float* ms = ws + (size_t)B * nslab * 64 * 2;
+  float* coef = ws + (size_t)B * nslab * 64 * 2;
   const int R = 256 / (C / 8);
   const size_t lds = (size_t)R * C * 2 * sizeof(float);
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nslab, B), dim3(256), lds, st, x, dy, gamma, beta, stats, part, HW, C, G,
                      nslab, silu);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, part, ms, HW, C, G, nslab);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, part, gamma, beta, stats, coef, HW, C, G, nslab);
   LAUNCH_CHECK();
-  const long total_v = (long)B * HW * (C / 8);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_grid(total_v)), dim3(256), 0, st, x, dy, add, dx, gamma, beta, stats, ms,
-                     total_v, HW, C, G, silu);
+  // stage 3 wants more, smaller slabs than the reduction: ~16 pixel rows per thread
+  int na = HW / (R * 16);
+  if (na > 2048) na = 2048;
+  if (na < 1) na = 1;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(na, B), dim3(256), 0, st, x, dy, add, dx, coef, HW, C, na, silu);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }

@@ -82,8 +82,14 @@ class ClipVisualPrefix(nn.Module):
         """-> token features after the last kept block, (N, L, D) (the reference's ``feats[layers-1]`` is
         the same tensor in (L, N, D) layout)."""
         v = self.visual
-        x = v.conv1(x.type(self.dtype))
-        x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+        # conv1 has kernel = stride = patch: it is one linear map per non-overlapping patch.  Written as
+        # unfold + matmul, forward and backward are plain GEMMs (MIOpen's backward-data search for this
+        # 16x16/16 fp16 conv ran a naive 7 s kernel per call on gfx950)
+        x = x.type(self.dtype)
+        N, C, H, W = x.shape
+        p = v.conv1.kernel_size[0]
+        x = x.reshape(N, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(N, (H // p) * (W // p), C * p * p)
+        x = x @ v.conv1.weight.reshape(v.conv1.weight.shape[0], -1).t()
         cls = v.class_embedding.to(x.dtype) + torch.zeros(x.shape[0], 1, x.shape[-1], dtype=x.dtype, device=x.device)
         x = torch.cat([cls, x], dim=1) + v.positional_embedding.to(x.dtype)
         x = _Block._ln(v.ln_pre, x)
@@ -178,6 +184,18 @@ class CLIPEncoder(nn.Module):
                 feat2 = self._tokens(self.ref)
                 self._gram_ref = torch.mm(feat2.t(), feat2)
         return torch.mm(feat1.t(), feat1) - self._gram_ref
+
+
+    def gram_residuals(self, ims):
+        """Batched form for images that share this style reference: (N, 3, H, W) -> (N, D, D), row i equal to
+        get_gram_matrix_residual(ims[i:i+1]) (one encoder pass for the N images of a lock-step batch)."""
+        ims = F.interpolate(ims, size=(self.size, self.size), mode="bicubic")
+        f = self.clip_model.block_features(self.preprocess(ims))[:, 1:, :].float()
+        if self._gram_ref is None:
+            with torch.no_grad():
+                feat2 = self._tokens(self.ref)
+                self._gram_ref = torch.mm(feat2.t(), feat2)
+        return f.transpose(1, 2) @ f - self._gram_ref
 
 
 def load_style_reference(path, size=224):

@@ -113,7 +113,8 @@ class HEditEngine:
         z0 = torch.empty_like(x)
         _lib.check(self.lib.hedit_step_tweedie(_lib.ptr(e_u_tar), _lib.ptr(e_c_tar), elems, _lib.ptr(x), _lib.ptr(z0),
                                                n, elems, float(cfg_scales[2]), sab, s1m, inv_scale, _lib.cur_stream()))
-        encs = image_encoder if isinstance(image_encoder, (list, tuple)) else [image_encoder] * n
+        shared = not isinstance(image_encoder, (list, tuple))
+        encs = [image_encoder] * n if shared else image_encoder
         g_z = torch.empty_like(x)
         with torch.enable_grad():
             # the images are independent: decode a chunk in one pass, one loss per image, and the gradient of
@@ -122,8 +123,11 @@ class HEditEngine:
                 hi = min(n, lo + self.style_chunk)
                 zc = z0[lo:hi].clone().requires_grad_(True)
                 img = vae.decode(zc).sample
-                loss = sum(torch.linalg.norm(encs[i].get_gram_matrix_residual(img[i - lo:i - lo + 1]))
-                           for i in range(lo, hi))
+                if shared and hasattr(image_encoder, "gram_residuals"):
+                    loss = torch.linalg.norm(image_encoder.gram_residuals(img), dim=(1, 2)).sum()
+                else:
+                    loss = sum(torch.linalg.norm(encs[i].get_gram_matrix_residual(img[i - lo:i - lo + 1]))
+                               for i in range(lo, hi))
                 g_z[lo:hi] = torch.autograd.grad(outputs=loss, inputs=zc)[0]
         out = torch.empty_like(x)
         _lib.check(self.lib.hedit_step_style(_lib.ptr(e_u_src), _lib.ptr(e_c_src), _lib.ptr(e_u_tar), _lib.ptr(e_c_tar),

@@ -132,3 +132,31 @@ def test_style_guidance_moves_the_edit(setup):
     G.sync()
     assert G.rel_err(outs[1][0], outs[0][0]) > 2e-2
     assert outs[1][1] < outs[0][1]
+
+
+def test_style_step_batched_encoder_equals_per_image(setup):
+    """n images in lock-step sharing one CLIPEncoder (batched gram_residuals, one decoder pass per chunk) ==
+    the per-image path (a list of encoders), and a chunk size of 1 == one chunk."""
+    from hedit.clip_guidance import CLIPEncoder
+    from hedit.clip_guidance.base_clip import ClipVisualPrefix
+    from hedit.engine import HEditEngine
+    hip, _, _, _, _ = setup
+    dev = G.dev()
+    clip = ClipVisualPrefix(width=64, layers=3, heads=1, patch_size=32, input_resolution=224).init_random(3)
+    enc = CLIPEncoder(clip_model=clip.float(), device=dev)
+    enc.set_reference(torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(2)).to(dev))
+    g = torch.Generator().manual_seed(8)
+    n = 3
+    e_u, e_cs, e_ct, x = (G.f32(torch.randn(n, 4, 32, 32, generator=g)) for _ in range(4))
+    cfg = [1.0, 5.0, 7.5]
+    tt = int(hip.scheduler.timesteps[4])
+    eng = HEditEngine(hip)
+    a = eng.style_step(e_u, e_cs, e_u, e_ct, x, tt, cfg, enc, 0.5)
+    b = eng.style_step(e_u, e_cs, e_u, e_ct, x, tt, cfg, [enc] * n, 0.5)
+    eng.style_chunk = 1
+    c = eng.style_step(e_u, e_cs, e_u, e_ct, x, tt, cfg, enc, 0.5)
+    G.sync()
+    # measured 1.2e-3: the decoder's split-K / GroupNorm slab partitions depend on the batch size
+    assert G.rel_err(a - x, b - x) < 5e-3
+    assert G.rel_err(a - x, c - x) < 5e-3
+    assert G.rel_err(a, x) > 1e-2

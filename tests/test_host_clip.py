@@ -88,3 +88,11 @@ def test_vit_b16_shape():
     assert sd["visual.positional_embedding"].shape == (197, 768)
     assert sd["visual.transformer.resblocks.2.attn.in_proj_weight"].shape == (2304, 768)
     assert len(m.visual.transformer.resblocks) == 3
+
+
+def test_batched_residuals_equal_per_image(enc):
+    e, _ = enc
+    ims = hash_normal((3, 3, 48, 40), 77) * 0.5
+    got = e.gram_residuals(ims)
+    for i in range(3):
+        assert torch.allclose(got[i], e.get_gram_matrix_residual(ims[i:i + 1]), atol=1e-4, rtol=1e-5)
