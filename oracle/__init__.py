@@ -12,7 +12,8 @@ Who may import this package: ``tests/``, ``__graft_entry__.smoke()`` and ``bench
 Pinning status
   * loops, scheduler algebra, controller, LocalBlend, processor: PINNED against golden vectors
     produced by running the reference's own modules (tests/golden/make_golden.py, committed
-    fixtures tests/golden/g1..g6).
+    fixtures tests/golden/g1..g7); the text + style loop of text-guided-n-style
+    (loops.h_edit_p2p_implicit_style) likewise on g9, reproduced bit for bit.
   * SD-1.x UNet arithmetic (oracle/sd_unet.py): the reference delegates it to the third-party
     package diffusers==0.18.0 (text-guided/environment_p2p.yaml:88), which is absent from
     /root/reference and from this image, and the reference holds no test or golden vector for
