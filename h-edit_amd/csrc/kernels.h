@@ -51,6 +51,7 @@ int ctx_pad_launch(const float* x, bf16_t* y, int B, int dim, hipStream_t st);
 int gemv_launch(const bf16_t* W, const float* x, const float* b0, const float* b1, float* out,
                 int N, int K, int silu, hipStream_t st);
 int timestep_embed_launch(float t, float* out, int dim, hipStream_t st);
+int timestep_embed_ddpm_launch(float t, float* out, int dim, hipStream_t st);   // [sin | cos], exponent / (half-1)
 // conv_in: x fp32 NCHW [B][Cin<=8][H][W], w fp32 [Cout][Cin][3][3] -> y NHWC bf16 [B][H][W][Cout]
 int conv_in_launch(const float* x, const float* w, const float* bias, bf16_t* y, int B, int Cin,
                    int H, int W, int Cout, hipStream_t st);

@@ -345,6 +345,19 @@ __global__ void timestep_embed_kernel(float t, float* out, int dim) {
   }
 }
 
+// the DDPM code base's variant (face model, face-swapping/diffusion/diffusion.py:6-24):
+// [sin | cos](t * 10000^(-i/(half-1)))
+__global__ void timestep_embed_ddpm_kernel(float t, float* out, int dim) {
+  const int half = dim / 2;
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float fr = expf(-9.210340371976184f / (float)(half - 1) * (float)i);
+    const float a = t * fr;
+    out[i] = sinf(a);
+    out[half + i] = cosf(a);
+  }
+  if ((dim & 1) && threadIdx.x == 0) out[dim - 1] = 0.f;
+}
+
 // ------------------------------------------------------------------ conv_in (Cin <= 8, K = 9 Cin tiny -> VALU)
 // Block = 64 consecutive pixels x all output channels.  The 9*Cin input taps of the block's pixels
 // and the whole (transposed) weight matrix live in LDS; a thread produces 8 consecutive output
@@ -534,6 +547,13 @@ int gemv_launch(const bf16_t* W, const float* x, const float* b0, const float* b
 
 int timestep_embed_launch(float t, float* out, int dim, hipStream_t st) {
   hipLaunchKernelGGL(timestep_embed_kernel, dim3(1), dim3(256), 0, st, t, out, dim);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int timestep_embed_ddpm_launch(float t, float* out, int dim, hipStream_t st) {
+  ARG_CHECK(dim >= 4, "timestep_embed_ddpm: dim >= 4");
+  hipLaunchKernelGGL(timestep_embed_ddpm_kernel, dim3(1), dim3(256), 0, st, t, out, dim);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }

@@ -23,6 +23,12 @@ class VaeCfg(C.Structure):
                 ("norm_num_groups", C.c_int)]
 
 
+class DdpmCfg(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_ch", C.c_int), ("ch", C.c_int), ("n_levels", C.c_int),
+                ("ch_mult", C.c_int * 8), ("attn_level", C.c_int * 8), ("num_res_blocks", C.c_int),
+                ("image_size", C.c_int)]
+
+
 class P2PPlan(C.Structure):
     _fields_ = [("mode", C.c_int), ("n_pairs", C.c_int),
                 ("pair_src", C.c_void_p), ("pair_tar", C.c_void_p),
@@ -68,6 +74,16 @@ _SIGS = {
                                    C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "hedit_local_blend": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "hedit_ddpm_create": (C.c_int, [C.POINTER(DdpmCfg), C.POINTER(C.c_void_p)]),
+    "hedit_ddpm_destroy": (None, [C.c_void_p]),
+    "hedit_ddpm_num_params": (C.c_int, [C.c_void_p]),
+    "hedit_ddpm_param_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "hedit_ddpm_param_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "hedit_ddpm_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hedit_ddpm_missing": (C.c_int, [C.c_void_p]),
+    "hedit_ddpm_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "hedit_ddpm_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]),
     "hedit_vae_create": (C.c_int, [C.POINTER(VaeCfg), C.POINTER(C.c_void_p)]),
     "hedit_vae_destroy": (None, [C.c_void_p]),
     "hedit_vae_num_params": (C.c_int, [C.c_void_p]),

@@ -227,6 +227,33 @@ int hedit_k_cross_attn(const void* q, int ldq, const void* k, int ldk, const voi
 int hedit_k_pack_conv3x3(const float* w_oihw, void* out, int O, int I, void* stream);
 int hedit_k_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Pixel-space DDPM UNet of the face-swapping task: `Model.forward(x, t)` of
+ * face-swapping/diffusion/diffusion.py:192-341, evaluated by face-swapping/inversion/h_edit_R.py:71,96,118
+ * and inversion/sde_inversion.py:121.  Parameters by the state_dict names of that class
+ * (temb.dense.0.weight, down.{i}.block.{j}.conv1.weight, down.{i}.attn.{j}.q.weight, mid.attn_1.proj_out.bias,
+ * up.{i}.upsample.conv.weight, norm_out.weight, ...), fp32 device tensors in torch layouts.
+ * attn_level[i] != 0 <=> the level's resolution is in the config's attn_resolutions. */
+typedef struct hedit_ddpm hedit_ddpm;
+typedef struct {
+  int in_channels, out_ch, ch, n_levels;
+  int ch_mult[8];
+  int attn_level[8];
+  int num_res_blocks, image_size;
+} hedit_ddpm_cfg;
+int hedit_ddpm_create(const hedit_ddpm_cfg* cfg, hedit_ddpm** out);
+void hedit_ddpm_destroy(hedit_ddpm* h);
+int hedit_ddpm_num_params(const hedit_ddpm* h);
+const char* hedit_ddpm_param_name(const hedit_ddpm* h, int i);
+int hedit_ddpm_param_shape(const hedit_ddpm* h, int i, int* ndim, int* dims4);
+int hedit_ddpm_load(hedit_ddpm* h, const char* name, const float* dev_w, size_t numel, void* stream);
+int hedit_ddpm_missing(const hedit_ddpm* h);
+size_t hedit_ddpm_workspace_bytes(hedit_ddpm* h, int B);
+/* x fp32 [B][in_channels][S][S], one timestep t for the batch (the reference passes ones(n) * t)
+ * -> eps fp32 [B][out_ch][S][S] */
+int hedit_ddpm_forward(hedit_ddpm* h, const float* x, float t, int B, float* eps, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

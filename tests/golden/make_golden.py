@@ -554,6 +554,78 @@ def gen_clip(out):
     np.savez_compressed(os.path.join(out, "g10_clip.npz"), **d)
 
 
+# --------------------------------------------------------------------------- G11: face-swapping path
+REF_FACE = "/root/reference/face-swapping"
+FACE_TINY = dict(type="simple", in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16],
+                 dropout=0.0, image_size=32, resamp_with_conv=True, num_diffusion_timesteps=1000)
+
+
+def face_state_dict(shapes):
+    """hash-seeded weights by parameter name (regenerated identically by the tests)"""
+    from helpers.tiny import hash_normal
+    sd = {}
+    for name, shape in shapes.items():
+        v = hash_normal(tuple(shape), name_seed(name))
+        if "norm" in name and name.endswith("weight"):
+            v = 1.0 + 0.1 * v
+        elif len(shape) == 1:
+            v = 0.05 * v
+        else:
+            v = v * float(np.prod(shape[1:])) ** -0.5
+        sd[name] = v
+    return sd
+
+
+def gen_face_child(out):
+    """Runs in its own interpreter with face-swapping/ on sys.path: the reference's pixel UNet
+    (diffusion/diffusion.py::Model), SDE inversion and h_Edit_R, all UNMODIFIED, at toy size."""
+    sys.path.insert(0, REF_FACE)
+    import warnings
+    warnings.filterwarnings("ignore")
+    from diffusion.diffusion import Model
+    from diffusion.diffusion_utils import get_beta_schedule
+    import inversion.h_edit_R as he
+    import inversion.sde_inversion as si
+    he.tqdm = lambda x, *a, **k: x
+    si.tqdm = lambda x, *a, **k: x
+    from helpers.tiny import hash_normal, TinyIdLoss, TinyLpips
+    model = Model(dict(FACE_TINY)).eval()
+    sd = face_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict(sd)
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    d = {}
+    x = hash_normal((2, 3, 32, 32), 321) * 0.8
+    for t in (1, 501, 991):
+        with torch.no_grad():
+            d[f"unet_t{t}"] = npy(model(x, torch.ones(2) * t))
+    betas = torch.from_numpy(get_beta_schedule(beta_schedule="linear", beta_start=0.0001, beta_end=0.02,
+                                               num_diffusion_timesteps=1000)).float()
+    T = 10
+    seq = (np.arange(0, 1000, 1000 // T) + 1)[::-1]
+    x0 = hash_normal((1, 3, 32, 32), 654) * 0.6
+    _, zs, xts, _ = si.inversion_forward_process_sde(model, x0, betas, seq, etas=1.0, num_inference_steps=T, device="cpu")
+    d["zs"], d["xts"] = npy(zs), npy(xts)
+    idl, lp = TinyIdLoss(), TinyLpips()
+    mask = (hash_normal((1, 1, 32, 32), 77) > 0).float()
+    for name, skip, K, w, use_id, use_lp, m in (("face_k2", 0, 2, 4.0, True, True, None),
+                                                ("face_k1_skip3_mask", 3, 1, 6.0, True, True, mask),
+                                                ("face_idonly", 0, 1, 4.0, True, False, None),
+                                                ("face_lponly", 2, 2, 4.0, False, True, None)):
+        after = T - skip
+        out_x = he.h_Edit_R(model, lp if use_lp else None, idl if use_id else None, xts[after].clone(), betas, seq, eta=1.0,
+                            zs=zs[:after], weight_edit_face=w, optimization_steps=K, after_skip_steps=after,
+                            num_inference_steps=T, soft_face_mask=m)
+        d[name] = npy(out_x)
+    d["mask"] = npy(mask)
+    np.savez_compressed(os.path.join(out, "g11_face.npz"), **d)
+
+
+def gen_face(out):
+    import subprocess
+    subprocess.run([sys.executable, os.path.abspath(__file__), "--face-child"], check=True)
+
+
 def gen_style(out):
     import subprocess
     subprocess.run([sys.executable, os.path.abspath(__file__), "--style-child"], check=True)
@@ -566,8 +638,14 @@ def main():
         if not os.path.isdir(REF_STYLE):
             raise SystemExit("reference tree not present")
         return gen_style_child(HERE)
+    if "--face-child" in sys.argv:
+        if not os.path.isdir(REF_FACE):
+            raise SystemExit("reference tree not present")
+        return gen_face_child(HERE)
     if "--only-style" in sys.argv:
         return gen_style(HERE)
+    if "--only-face" in sys.argv:
+        return gen_face(HERE)
     ref = import_reference()
     out = HERE
     gen_scheduler(ref, out)
@@ -578,6 +656,7 @@ def main():
     gen_ddim(ref, out)
     gen_load512(ref, out)
     gen_style(out)
+    gen_face(out)
     for f in sorted(os.listdir(out)):
         if f.endswith((".npz", ".json")):
             print(f"{f:32s} {os.path.getsize(os.path.join(out, f)) / 1024:9.1f} KiB")

@@ -379,3 +379,40 @@ class TinyStyleEncoder(nn.Module):
         a = self._tokens(im1)
         b = self._tokens(self.ref)
         return a.t() @ a - b.t() @ b
+
+
+# --------------------------------------------------------------------------- face-swapping toys
+class TinyIdLoss(nn.Module):
+    """Stand-in for the reference's IDLoss (face-swapping/arcface/arcface_model.py:40-67): the loop only
+    calls ``get_cosine_loss(x0) -> scalar`` = 1 - cos(features(x0), features(reference face))."""
+
+    def __init__(self, size=32, seed=61):
+        super().__init__()
+        self.conv = nn.Conv2d(3, 8, 5, stride=4, padding=2)
+        with torch.no_grad():
+            self.conv.weight.copy_(hash_normal(tuple(self.conv.weight.shape), seed) * 0.2)
+            self.conv.bias.copy_(hash_normal(tuple(self.conv.bias.shape), seed + 1) * 0.1)
+        self.register_buffer("ref", hash_normal((1, 3, size, size), seed + 2) * 0.5)
+
+    def _feat(self, x):
+        f = torch.tanh(self.conv(x.float())).flatten(1)
+        return f / f.norm(dim=1, keepdim=True)
+
+    def get_cosine_loss(self, x):
+        return (1 - (self._feat(x) * self._feat(self.ref)).sum(1)).mean()
+
+
+class TinyLpips(nn.Module):
+    """Stand-in for LPIPS_Loss (arcface_model.py:69-94): ``get_lpips_loss(x0) -> scalar`` distance of conv
+    features to those of the source image."""
+
+    def __init__(self, size=32, seed=71):
+        super().__init__()
+        self.conv = nn.Conv2d(3, 6, 3, stride=2, padding=1)
+        with torch.no_grad():
+            self.conv.weight.copy_(hash_normal(tuple(self.conv.weight.shape), seed) * 0.3)
+            self.conv.bias.zero_()
+        self.register_buffer("src", hash_normal((1, 3, size, size), seed + 2) * 0.5)
+
+    def get_lpips_loss(self, x):
+        return ((F.relu(self.conv(x.float())) - F.relu(self.conv(self.src))) ** 2).mean()
