@@ -309,26 +309,38 @@ int attention(VF& f, const VAttn& a, const bf16_t* x, int H, int W, bf16_t** out
   TRY(aalloc(f, &k, M * C));
   TRY(linear(f, xn, (int)M, C, a.w_k, C, nullptr, nullptr, k, C));
   TRY(aalloc(f, &o, M * C));
-  TRY(aalloc(f, &vt, (size_t)C * T));
-  TRY(aalloc(f, &s, (size_t)T * T));
-  TRY(aalloc(f, &pb, (size_t)T * T));
-  for (int b = 0; b < B; ++b) {
+  // Images per pass: when the stacked score matrix is small (B*T <= 4096) all images go through ONE
+  // Q.K^T GEMM, a block-diagonal softmax (zeros off the diagonal blocks) and ONE P.V GEMM over K = G*T --
+  // the off-diagonal products are wasted MFMA work (a few GFLOP) bought back many times over in launches
+  // (the pixel UNet has six such layers at 16x16 / 8x8 tokens).  Large T (the VAE's 64x64) goes image by image.
+  int G = 4096 / T;
+  G = G < 1 ? 1 : (G > B ? B : G);
+  TRY(aalloc(f, &vt, (size_t)C * T * G));
+  TRY(aalloc(f, &s, (size_t)T * G * T * G));
+  TRY(aalloc(f, &pb, (size_t)T * G * T * G));
+  for (int b = 0; b < B; b += G) {
+    const int g = B - b < G ? B - b : G;
+    const int TG = T * g;
     const bf16_t* xb = xn + (size_t)b * T * C;
-    {   // V^T [C][T] = W_v . xn_b^T
+    {   // V^T [C][TG] = W_v . xn_b^T
       GemmParams p{};
-      p.A = a.w_v; p.W = xb; p.M = C; p.N = T; p.K = C; p.lda = C; p.C = vt; p.ldc = T;
+      p.A = a.w_v; p.W = xb; p.M = C; p.N = TG; p.K = C; p.lda = C; p.C = vt; p.ldc = TG;
       TRY(run_gemm(f, p));
     }
-    {   // S [T][T] = q_b . k_b^T in fp32
+    {   // S [TG][TG] = q_b . k_b^T in fp32
       GemmParams p{};
-      p.A = q + (size_t)b * T * C; p.W = k + (size_t)b * T * C; p.M = T; p.N = T; p.K = C; p.lda = C;
-      p.raw_f32 = s; p.ldc = T;
+      p.A = q + (size_t)b * T * C; p.W = k + (size_t)b * T * C; p.M = TG; p.N = TG; p.K = C; p.lda = C;
+      p.raw_f32 = s; p.ldc = TG;
       TRY(run_gemm(f, p));
     }
-    RUN(f, softmax_rows_launch(s, pb, T, T, 1.0f / sqrtf((float)C), f.st));
-    {   // O_b [T][C] = P . V
+    if (g == 1) {
+      RUN(f, softmax_rows_launch(s, pb, T, T, 1.0f / sqrtf((float)C), f.st));
+    } else {
+      RUN(f, softmax_blockdiag_launch(s, pb, TG, T, TG, 1.0f / sqrtf((float)C), f.st));
+    }
+    {   // O_b [TG][C] = P . V
       GemmParams p{};
-      p.A = pb; p.W = vt; p.M = T; p.N = C; p.K = T; p.lda = T; p.C = o + (size_t)b * T * C; p.ldc = C;
+      p.A = pb; p.W = vt; p.M = TG; p.N = C; p.K = TG; p.lda = TG; p.C = o + (size_t)b * T * C; p.ldc = C;
       TRY(run_gemm(f, p));
     }
   }

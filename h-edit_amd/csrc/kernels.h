@@ -61,6 +61,8 @@ int conv_out_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* 
 // VAE helpers: row softmax of fp32 scores (p = softmax(scale * s), bf16), 1x1 channel mixing of a
 // small fp32 NCHW tensor (x scaled by pre_scale first), encoder tail (first Cout channels of quant_conv)
 int softmax_rows_launch(const float* s, bf16_t* p, long rows, int N, float scale, hipStream_t st);
+// several images stacked in one score matrix [rows = B*T][ld = B*T]: softmax inside each image's diagonal block, 0 elsewhere
+int softmax_blockdiag_launch(const float* s, bf16_t* p, long rows, int T, int ld, float scale, hipStream_t st);
 int mix1x1_nchw_launch(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, long HW,
                        float pre_scale, hipStream_t st);
 int quant_mean_launch(const bf16_t* h, const float* w, const float* bias, float* y, int B, long HW, int Cm, int Cout, hipStream_t st);

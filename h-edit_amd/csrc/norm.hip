@@ -613,6 +613,48 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   }
 }
 
+// block-diagonal variant for several images stacked along both axes of one score matrix [rows][ld], rows = B*T:
+// row r attends only to columns [b*T, (b+1)*T) of its own image b = r / T; every other entry of P is written 0,
+// so that one P.V GEMM over K = B*T serves all images.
+__global__ __launch_bounds__(256) void softmax_blockdiag_kernel(const float* __restrict__ s, bf16_t* __restrict__ p, long rows, int T,
+                                                                int ld, float scale_log2e) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c0 = (int)(row / T) * T;
+  const float* sr = s + row * ld + c0;
+  float mx = -3.0e38f;
+  for (int i = lane * 4; i < T; i += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(sr + i);
+    mx = fmaxf(fmaxf(fmaxf(mx, v[0]), fmaxf(v[1], v[2])), v[3]);
+  }
+  mx = wave_max(mx) * scale_log2e;
+  float sum = 0.f;
+  for (int i = lane * 4; i < T; i += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(sr + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += __builtin_amdgcn_exp2f(v[j] * scale_log2e - mx);
+  }
+  const float inv = 1.0f / wave_sum(sum);
+  bf16_t* pr = p + row * ld;
+  for (int i = lane * 4; i < ld; i += 256) {
+    uint2 o = make_uint2(0u, 0u);
+    if (i >= c0 && i < c0 + T) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(s + row * ld + i);
+      o.x = pack_bf16x2(__builtin_amdgcn_exp2f(v[0] * scale_log2e - mx) * inv, __builtin_amdgcn_exp2f(v[1] * scale_log2e - mx) * inv);
+      o.y = pack_bf16x2(__builtin_amdgcn_exp2f(v[2] * scale_log2e - mx) * inv, __builtin_amdgcn_exp2f(v[3] * scale_log2e - mx) * inv);
+    }
+    *reinterpret_cast<uint2*>(pr + i) = o;
+  }
+}
+
+int softmax_blockdiag_launch(const float* s, bf16_t* p, long rows, int T, int ld, float scale, hipStream_t st) {
+  ARG_CHECK(T % 4 == 0 && ld % 4 == 0 && rows % T == 0, "softmax_blockdiag: T % 4, ld % 4, rows % T");
+  hipLaunchKernelGGL(softmax_blockdiag_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s, p, rows, T, ld, scale * 1.4426950408889634f);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
 int softmax_rows_launch(const float* s, bf16_t* p, long rows, int N, float scale, hipStream_t st) {
   ARG_CHECK(N % 4 == 0, "softmax_rows: N % 4");
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s, p, rows, N, scale * 1.4426950408889634f);
