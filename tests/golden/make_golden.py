@@ -619,6 +619,67 @@ def gen_face_child(out):
         d[name] = npy(out_x)
     d["mask"] = npy(mask)
     np.savez_compressed(os.path.join(out, "g11_face.npz"), **d)
+    gen_idloss(out)
+
+
+def irse_state_dict(shapes):
+    """hash-seeded IR-SE50 weights / BatchNorm statistics by state_dict name (regenerated by the tests)"""
+    from helpers.tiny import hash_normal
+    sd = {}
+    for name, shape in shapes.items():
+        if name.endswith("num_batches_tracked"):
+            sd[name] = torch.zeros(shape, dtype=torch.long)
+            continue
+        v = hash_normal(tuple(shape) if len(shape) else (1,), name_seed(name)).reshape(shape)
+        if name.endswith("running_var"):
+            v = 1.0 + 0.2 * v.abs()
+        elif len(shape) > 1:
+            v = v * float(np.prod(shape[1:])) ** -0.5
+        elif name.endswith("weight"):
+            v = 1.0 + 0.1 * v          # BatchNorm / PReLU scales
+        else:
+            v = 0.05 * v
+        sd[name] = v
+    return sd
+
+
+def gen_idloss(out):
+    """G12: the reference's IDLoss (face-swapping/arcface/arcface_model.py:11-67) with its IR-SE50 backbone,
+    UNMODIFIED; torchvision.transforms.ToTensor and lpips are stubbed, torch.load returns hash-seeded weights
+    instead of the checkpoint file, Tensor.cuda() is the identity."""
+    from PIL import Image
+    from helpers.tiny import hash_normal
+
+    class ToTensor:
+        def __call__(self, pic):
+            return torch.from_numpy(np.asarray(pic, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255)
+
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms", ToTensor=ToTensor)
+    _stub("lpips", LPIPS=object)
+    from arcface.facial_recognition.model_irse import Backbone
+    probe = Backbone(input_size=112, num_layers=50, drop_ratio=0.6, mode="ir_se")
+    sd = irse_state_dict({k: tuple(v.shape) for k, v in probe.state_dict().items()})
+    real_load = torch.load
+    torch.load = lambda *a, **k: sd
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import arcface.arcface_model as am
+    ref_rgb = synthetic_rgb(70, 90, 9)
+    tmp = os.path.join(out, "_face_ref_tmp.png")
+    Image.fromarray(ref_rgb).save(tmp)
+    idl = am.IDLoss(ref_path=tmp)
+    os.remove(tmp)
+    torch.load = real_load
+    d = {"ref_rgb": ref_rgb, "ref_tensor_sub": npy(idl.ref[0, :, ::16, ::16])}
+    for i, (b, hw) in enumerate(((1, 256), (2, 128))):
+        x = (hash_normal((b, 3, hw, hw), 40 + i) * 0.4).requires_grad_(True)
+        loss = idl.get_cosine_loss(x)
+        (g,) = torch.autograd.grad(loss, x)
+        d[f"feat{i}"] = npy(idl.extract_feats(x.detach()))
+        d[f"sim{i}"] = npy(idl.get_cosine_sim(x.detach()))
+        d[f"loss{i}"] = np.array([loss.item()], dtype=np.float64)
+        d[f"grad_sub{i}"] = npy(g[:, :, ::4, ::4])
+    np.savez_compressed(os.path.join(out, "g12_idloss.npz"), **d)
 
 
 def gen_face(out):
