@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--images", type=int, default=24, help="images edited in lock-step per GPU (one 'step'); 24 = 120-row UNet calls: +5 % over 8 and +2.5 % over 16, flat beyond")
     ap.add_argument("--diffusion-steps", type=int, default=50)
     ap.add_argument("--opt-steps", type=int, default=1, help="implicit optimisation ('Langevin') steps K")
-    ap.add_argument("--workload", choices=("p2p", "style"), default="p2p",
+    ap.add_argument("--workload", choices=("p2p", "style", "face"), default="p2p",
                     help="p2p = BASELINE configs[1] (the quoted metric, default); style = configs[4], combined "
                          "text + CLIP-style editing: every step adds VAE decode forward + backward and the style encoder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -66,6 +66,85 @@ def parse():
                     help="opt-in: reuse eps(x_orig, t-1, {null,src}) of the P2P pass in the next base pass "
                          "(7 instead of 9 sample-forwards per step; NOT the reference's evaluation count)")
     return ap.parse_args()
+
+
+def run_face(args, world, rank, local, dev, dist):
+    """BASELINE configs[3] per GPU: face-swapping h-Edit-R (face-swapping/inversion/h_edit_R.py) -- pixel DDPM UNet
+    (HIP, CelebA-HQ 256 shape, random init) guided by the ArcFace identity reward (IR-SE50, torch), 100 steps,
+    K = 3 implicit steps: 100 + 2*3*99 = 694 eps evaluations per image; --images faces in lock-step per GPU
+    (default 8).  The LPIPS term needs the third-party lpips package (absent offline): lpipsloss=None, which the
+    reference loop guards the same way."""
+    import numpy as np
+    from hedit.arcface import IDLoss
+    from hedit.diffusion import Model, TINY_DDPM_CONFIG
+    from hedit.inversion.h_edit_R import h_Edit_R
+    n = args.images if args.images != 24 else 8
+    T = args.diffusion_steps if args.diffusion_steps != 50 else 100
+    K = args.opt_steps if args.opt_steps != 1 else 3
+    model = Model(TINY_DDPM_CONFIG if args.tiny else None, device=dev)
+    model.init_random(0)
+    S = model.resolution
+    g = torch.Generator().manual_seed(5 + rank)
+    idloss = IDLoss(ref=torch.randn(1, 3, 256, 256, generator=g) * 0.4, device=dev, seed=1)
+    betas = torch.from_numpy(np.linspace(0.0001, 0.02, 1000, dtype=np.float64)).float().to(dev)
+    seq = (np.arange(0, 1000, 1000 // T) + 1)[::-1]
+    xT = torch.randn(n, 3, S, S, generator=g).to(dev)
+    zs = torch.randn(T, n, 3, S, S, generator=g).to(dev)
+
+    def one_step():
+        return h_Edit_R(model, None, idloss, xT, betas, seq, eta=1.0, zs=zs, weight_edit_face=50.0, optimization_steps=K,
+                        after_skip_steps=T, num_inference_steps=T, per_image=True)
+
+    for _ in range(args.warmup):
+        one_step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        from hedit import dist as HD
+        elapsed = HD.max_over_ranks(elapsed, device=dev)
+    # the eps-network alone, same batch, HIP events on the launch stream
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        model(xT, 501.0)
+    ev1.record()
+    torch.cuda.synchronize()
+    unet_ms = ev0.elapsed_time(ev1) / 10
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    evals = T + 2 * K * (T - 1)
+    flop_fwd = 0.497e12 if not args.tiny else 0.0
+    imgs = args.steps * n * world
+    ach = flop_fwd * n / (unet_ms * 1e-3) / 1e12 if unet_ms > 0 else None
+    out_json = {
+        "metric": "face-swapped images/sec (256^2, 100 steps, K=3)", "value": round(imgs / elapsed, 4), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3] per GPU: face-swapping h_Edit_R, CelebA-HQ-256-shaped random-init pixel DDPM "
+                               f"UNet (113.7M), ArcFace IR-SE50 identity reward (torch, random init), no LPIPS term, {T} steps, "
+                               f"K={K}; {n} faces per GPU in lock-step",
+                   "images_per_gpu": n, "eps_evaluations_per_image": evals, "parallelism": f"replica-dp{world}"},
+        "achieved_tflops_per_s_per_gpu": round(imgs * evals * flop_fwd / elapsed / 1e12 / world, 1),
+        "ms_per_eps_evaluation_batch": round(unet_ms, 3),
+        "unet_share_of_step": round(evals * unet_ms * 1e-3 / (elapsed / args.steps), 4),
+        "roofline": {"bound": "mfma", "kernel": "hedit_ddpm_forward (all kernels of one eps evaluation)", "achieved": None if ach is None else round(ach, 1),
+                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None if ach is None else round(ach / MFMA_PEAK_TFLOPS, 4),
+                     "traffic": None},
+        "cpu_baseline": None, "finite": bool(torch.isfinite(out).all()),
+    }
+    print(json.dumps(out_json))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -85,6 +164,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    if args.workload == "face":
+        return run_face(args, world, rank, local, dev, dist)
 
     from hedit.engine import HEditEngine
     from hedit.p2p import ptp_controller_utils as PCU

@@ -9,7 +9,11 @@ import torch
 
 
 def h_Edit_R(model, lpipsloss, idloss, xT, betas, seq, eta=1.0, zs=None, weight_edit_face=50.0,
-             optimization_steps=3, after_skip_steps=100, num_inference_steps=100, soft_face_mask=None):
+             optimization_steps=3, after_skip_steps=100, num_inference_steps=100, soft_face_mask=None,
+             per_image=False):
+    """per_image (addition, default off = the reference's arithmetic): with n > 1 images in lock-step
+    (xT (n,3,S,S), zs (T,n,3,S,S)) the losses are batch MEANS, so each image's gradient carries a factor
+    1/n; per_image=True multiplies it back so that every image is edited exactly as it would be alone."""
     if type(eta) in [int, float]:
         etas = [eta] * num_inference_steps
     else:
@@ -21,6 +25,7 @@ def h_Edit_R(model, lpipsloss, idloss, xT, betas, seq, eta=1.0, zs=None, weight_
     t_to_idx = {int(v): k for k, v in enumerate(timesteps[-after_skip_steps:])}
     alpha_bar = (1.0 - betas).cumprod(dim=0)
     n = xt.size(0)
+    gscale = float(n) if per_image else 1.0
 
     def eps_at(x, t):
         with torch.no_grad():
@@ -48,7 +53,7 @@ def h_Edit_R(model, lpipsloss, idloss, xT, betas, seq, eta=1.0, zs=None, weight_
                     x0_pred = (xt_prev_opt - s1 * eps_tm1) / sa          # Tweedie; eps is a constant here
                     id_loss = idloss.get_cosine_loss(x0_pred)
                     g = torch.autograd.grad(outputs=id_loss, inputs=xt_prev_opt)[0]
-                    step = rho * g.detach()
+                    step = (rho * gscale) * g.detach()
                     if soft_face_mask is not None:
                         step = step * soft_face_mask
                     xt_prev_opt = (xt_prev_opt - step).detach().requires_grad_(True)
@@ -57,6 +62,6 @@ def h_Edit_R(model, lpipsloss, idloss, xT, betas, seq, eta=1.0, zs=None, weight_
                     x0_pred = (xt_prev_opt - s1 * eps_tm1) / sa
                     lpips_loss = lpipsloss.get_lpips_loss(x0_pred)
                     g = torch.autograd.grad(outputs=lpips_loss, inputs=xt_prev_opt)[0]
-                    xt_prev_opt = (xt_prev_opt - rho * g.detach()).detach().requires_grad_(True)
+                    xt_prev_opt = (xt_prev_opt - (rho * gscale) * g.detach()).detach().requires_grad_(True)
         xt = xt_prev_opt.detach().requires_grad_(True)
     return xt

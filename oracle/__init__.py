@@ -14,6 +14,9 @@ Pinning status
     produced by running the reference's own modules (tests/golden/make_golden.py, committed
     fixtures tests/golden/g1..g7); the text + style loop of text-guided-n-style
     (loops.h_edit_p2p_implicit_style) likewise on g9, reproduced bit for bit.
+  * face-swapping path: the pixel DDPM UNet (oracle/ddpm_unet.py) and the SDE inversion / h_Edit_R face loop
+    (oracle/face_loops.py) are PINNED on vectors from running the reference's own in-tree
+    face-swapping/diffusion/diffusion.py, inversion/sde_inversion.py and inversion/h_edit_R.py (g11).
   * SD-1.x UNet arithmetic (oracle/sd_unet.py): the reference delegates it to the third-party
     package diffusers==0.18.0 (text-guided/environment_p2p.yaml:88), which is absent from
     /root/reference and from this image, and the reference holds no test or golden vector for
