@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 31, hi = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int bqk = p.qk_src ? p.qk_src[b] : b;
+  const int bqk = p.qk_src ? p.qk_src[b] : b;                       // P2P self-replace: q and k of another row
+  const int bk = p.kv_src ? p.kv_src[b] : bqk;                      // mutual self-attention: k and v of another row
+  const int bv = p.kv_src ? p.kv_src[b] : b;
   const int q_base = blockIdx.x * (128 * QG) + wave * (32 * QG) + ql;
 
   // zero LDS once (pad rows of V^T must be finite zeros), then the row of ones
@@ -172,9 +174,9 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
   bool dma_is_k[C::NI];
 #if defined(__HIP_DEVICE_COMPILE__)     // (the resource type only exists in the device pass)
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(p.k + (long)bqk * p.N * p.ldk + h * D), (short)0, 0x7fffffff, 0x00020000);
+      const_cast<bf16_t*>(p.k + (long)bk * p.N * p.ldk + h * D), (short)0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(p.vt + (long)h * D * p.ldvt + (long)b * p.N), (short)0, 0x7fffffff, 0x00020000);
+      const_cast<bf16_t*>(p.vt + (long)h * D * p.ldvt + (long)bv * p.N), (short)0, 0x7fffffff, 0x00020000);
 #endif
 #pragma unroll
   for (int n = 0; n < C::NI; ++n) {

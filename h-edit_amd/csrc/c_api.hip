@@ -123,14 +123,14 @@ int hedit_k_geglu(const void* x, void* y, int64_t rows, int inner, void* stream)
 }
 
 int hedit_k_self_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int64_t ldvt, void* out, int ldo,
-                      int B, int N, int heads, int d, const int32_t* qk_src, void* stream) {
+                      int B, int N, int heads, int d, const int32_t* qk_src, const int32_t* kv_src, void* stream) {
   ARG_CHECK(q && k && vt && out, "self_attn args");
   SelfAttnParams p{};
   p.q = reinterpret_cast<const bf16_t*>(q); p.ldq = ldq;
   p.k = reinterpret_cast<const bf16_t*>(k); p.ldk = ldk;
   p.vt = reinterpret_cast<const bf16_t*>(vt); p.ldvt = (long)ldvt;
   p.out = reinterpret_cast<bf16_t*>(out); p.ldo = ldo;
-  p.B = B; p.N = N; p.heads = heads; p.d = d; p.qk_src = qk_src;
+  p.B = B; p.N = N; p.heads = heads; p.d = d; p.qk_src = qk_src; p.kv_src = kv_src;
   return self_attn_launch(p, S(stream));
 }
 

@@ -98,6 +98,7 @@ struct SelfAttnParams {
   bf16_t* out; int ldo;         // [B*N][ldo]
   int B, N, heads, d;
   const int* qk_src;            // [B] batch index whose q,k are used (P2P self-replace) or null
+  const int* kv_src;            // [B] batch index whose k,v are used (MasaCtrl mutual self-attention) or null
 };
 int self_attn_launch(const SelfAttnParams& p, hipStream_t st);
 

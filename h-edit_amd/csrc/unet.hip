@@ -189,6 +189,7 @@ struct Fwd {
   const float* temb_all;     // fused (time_emb_proj(silu(temb)) + conv1.bias) of every ResBlock
   const bf16_t* ctxb;        // [B*80][ctx_dim]
   int store_idx = 0;
+  int tblock = 0;            // transformer blocks visited so far in this call (MasaCtrl layer gate)
   bool dry() const { return ar.dry; }
 };
 
@@ -326,6 +327,8 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
     sp.q = qk; sp.ldq = 2 * C; sp.k = qk + C; sp.ldk = 2 * C; sp.vt = vt; sp.ldvt = (long)M;
     sp.out = ao; sp.ldo = C; sp.B = B; sp.N = N; sp.heads = heads; sp.d = d;
     sp.qk_src = (pl && pl->qk_src && N <= 1024) ? pl->qk_src : nullptr;
+    sp.kv_src = (pl && pl->kv_src && f.tblock >= pl->kv_first_block) ? pl->kv_src : nullptr;
+    ++f.tblock;
     ProfScope ps(f, PK_SELF_ATTN, 4.0 * B * (double)N * N * C);
     RUN(f, self_attn_launch(sp, f.st));
   }

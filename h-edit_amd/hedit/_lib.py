@@ -34,7 +34,8 @@ class P2PPlan(C.Structure):
                 ("pair_src", C.c_void_p), ("pair_tar", C.c_void_p),
                 ("singles", C.c_void_p), ("n_single", C.c_int),
                 ("qk_src", C.c_void_p), ("mixT", C.c_void_p), ("bvec", C.c_void_p),
-                ("h_store", C.POINTER(C.c_void_p)), ("n_store", C.c_int)]
+                ("h_store", C.POINTER(C.c_void_p)), ("n_store", C.c_int),
+                ("kv_src", C.c_void_p), ("kv_first_block", C.c_int)]
 
 
 class StepCoef(C.Structure):
@@ -114,7 +115,7 @@ _SIGS = {
                                     C.c_float, C.c_void_p]),
     "hedit_k_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "hedit_k_self_attn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
-                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hedit_k_cross_attn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(P2PPlan), C.c_void_p,
                                      C.c_void_p]),

@@ -147,7 +147,7 @@ class HEditEngine:
     @torch.no_grad()
     def run(self, xT, zs, prompt_pairs, cfg_scales, controller=None, eta=1.0, p2p=True, implicit=True,
             K=1, w_rec=0.1, after_skip_steps=None, ddim_inv=False, ctx=None, fuse_src_pass=False,
-            reuse_orig_eps=False, style=None):
+            reuse_orig_eps=False, style=None, rec_pull=True):
         """xT: (n,C,H,W); zs: (T',n,C,H,W) or None; prompt_pairs: n x [src, tar].
         ctx: optional precomputed (null, src, tar) embeddings ((1|n,77,D), (n,77,D), (n,77,D)).
         fuse_src_pass: evaluate eps(x^k, t-1, src) (the reference's separate n-row call,
@@ -162,6 +162,9 @@ class HEditEngine:
         style = (image_encoder | None, weight_edit_clip) selects the text + style loop of
         text-guided-n-style/inversion/h_edit.py (implicit P2P only): no reconstruction pull between
         inner steps (h_edit.py:149) and one style_step after every text update (h_edit.py:160-188).
+        rec_pull=False drops the L1 reconstruction pull of inner steps k > 0 (the MasaCtrl loop,
+        masactrl_h_edit.py:139-150); ``controller`` may be any object with _plan / _after_pass /
+        step_callback (P2P controllers, hedit.masactrl.MutualSelfAttentionControl).
         Returns (edit (n,C,H,W), recon (n,C,H,W))."""
         if style is not None and not (p2p and implicit):
             raise ValueError("style guidance is defined for the implicit P2P loop only (n-style h_edit.py)")
@@ -255,7 +258,7 @@ class HEditEngine:
                             e_src = self.unet.forward_raw(x_k, tt, ctx_src, off)
                             e = p2p_pass(torch.cat([x_orig, x_k, x_orig, x_k]), tt, save)
                         self.step_update(e[n:2 * n], e_src, e[n:2 * n], e[3 * n:4 * n], x_k, x_base, new, n,
-                                         k > 0 and style is None, coef)
+                                         k > 0 and style is None and rec_pull, coef)
                         if style is not None and style[0] is not None:
                             with torch.enable_grad():
                                 new = self.style_step(e[n:2 * n], e_src, e[n:2 * n], e[3 * n:4 * n], new, tt, cfg_scales,

@@ -71,6 +71,11 @@ typedef struct {
   float* const* h_store;    /* HOST array of n_store device pointers, one per cross-attention layer
                                with <= 32*32 tokens in call order; each [n_pairs][2][heads][N][77]  */
   int n_store;
+  /* MasaCtrl mutual self-attention (text-guided/masactrl/masactrl.py:53-69): in the transformer blocks with
+   * index >= kv_first_block (call order, 16 in SD-1.x) row b of every self-attention uses the keys and values
+   * of row kv_src[b] (its own queries).  NULL = off. */
+  const int32_t* kv_src;    /* [B] */
+  int kv_first_block;
 } hedit_p2p_plan;
 
 typedef struct {
@@ -219,7 +224,7 @@ int hedit_k_layernorm(const void* x, void* y, const float* gamma, const float* b
                       int C, float eps, void* stream);
 int hedit_k_geglu(const void* x, void* y, int64_t rows, int inner, void* stream);
 int hedit_k_self_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int64_t ldvt,
-                      void* out, int ldo, int B, int N, int heads, int d, const int32_t* qk_src,
+                      void* out, int ldo, int B, int N, int heads, int d, const int32_t* qk_src, const int32_t* kv_src,
                       void* stream);
 int hedit_k_cross_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int64_t ldvt,
                        void* out, int ldo, int B, int N, int heads, int d,

@@ -9,6 +9,7 @@ Restates, against the same duck-typed ``model`` object the reference uses:
   h_edit_p2p_explicit           text-guided/inversion/p2p_h_edit.py:380-523
   h_edit_p2p_implicit           text-guided/inversion/p2p_h_edit.py:529-701
   h_edit_p2p_implicit_style     text-guided-n-style/inversion/h_edit.py:14-192 (text + style editing)
+  h_edit_masactrl_implicit      text-guided/inversion/masactrl_h_edit.py:10-155 (editor from oracle/masactrl.py)
 The four loops share one skeleton here (``_loop``); the per-variant differences are the UNet
 batches and which eps feeds the three CFG mixes.
 """
@@ -162,7 +163,7 @@ def _style_step(model, image_encoder, x, e_tar, corr, tt, weight):
 
 
 def _loop(model, xT, eta, prompts, cfg_scales, zs, controller, after_skip_steps, ddim_inv,
-          p2p, implicit, K=1, w_rec=0.1, style=None):
+          p2p, implicit, K=1, w_rec=0.1, style=None, masactrl=False):
     """style = (image_encoder | None, weight_edit_clip) selects the n-style variant of the implicit
     P2P loop: no reconstruction pull between inner steps (rec_term = x^k, h_edit.py:149) and one
     style-guidance update after every text update (h_edit.py:160-188)."""
@@ -171,7 +172,9 @@ def _loop(model, xT, eta, prompts, cfg_scales, zs, controller, after_skip_steps,
     T = sch.num_inference_steps
     if not p2p:
         assert not ddim_inv, "only support prompt editing and DDPM sampling"
-    off = {"use_controller": False}
+    # masactrl: same skeleton as the implicit P2P loop; the registered attention editor is switched off with
+    # `use_editor`, the edit pass carries no kwargs, no reconstruction pull, no LocalBlend callback
+    off = {"use_editor": False} if masactrl else {"use_controller": False}
     pos = {int(v): k for k, v in enumerate(op)}
 
     def unet(x, t, ctx, kw):
@@ -224,19 +227,19 @@ def _loop(model, xT, eta, prompts, cfg_scales, zs, controller, after_skip_steps,
                     save = not (k < K - 1 and K > 1)
                     e_c_src = unet(x_k, tt, txt[:1], off)
                     e = unet(torch.cat([x_orig, x_k] * 2), tt, torch.cat([unc, txt]),
-                             {"save_attn": save})
+                             {} if masactrl else {"save_attn": save})
                     corr = mixes(e[1:2], e_c_src, e[1:2], e[3:4])
                 else:
                     e = unet(torch.cat([x_k] * 4), tt, torch.cat([unc, txt]), off)
                     corr = mixes(e[0:1], e[2:3], e[1:2], e[3:4])
-                rec = _l1_pull(x_k, x_base, corr, w_rec) if (k > 0 and style is None) else x_k
+                rec = _l1_pull(x_k, x_base, corr, w_rec) if (k > 0 and style is None and not masactrl) else x_k
                 x_k = rec + coeff * corr
                 if style is not None and style[0]:
                     e_tar = e[1:2] + w_tar * (e[3:4] - e[1:2])
                     x_k = _style_step(model, style[0], x_k, e_tar, corr, tt, style[1])
 
         xt = torch.cat([x_orig, x_k.detach()])
-        if controller is not None:
+        if controller is not None and not masactrl:
             xt = controller.step_callback(xt)
     return xt[1].unsqueeze(0), xt[0].unsqueeze(0)
 
@@ -276,3 +279,10 @@ def h_edit_p2p_implicit_style(model, image_encoder, xT, eta=1.0, prompts="", cfg
     return _loop(model, xT, eta, prompts, cfg_scales, zs, controller, after_skip_steps,
                  is_ddim_inversion, p2p=True, implicit=True, K=optimization_steps,
                  style=(image_encoder, weight_edit_clip))
+
+
+def h_edit_masactrl_implicit(model, xT, eta=0, prompts="", cfg_scales=None, zs=None, optimization_steps=1,
+                             after_skip_steps=35, is_ddim_inversion=True):
+    """text-guided/inversion/masactrl_h_edit.py:10-155; the editor is the one registered on model.unet."""
+    return _loop(model, xT, eta, prompts, cfg_scales, zs, None, after_skip_steps, is_ddim_inversion,
+                 p2p=True, implicit=True, K=optimization_steps, masactrl=True)

@@ -377,6 +377,53 @@ def gen_ddim(ref, out):
 
 
 # --------------------------------------------------------------------------- G8
+# --------------------------------------------------------------------------- G13: MasaCtrl
+def gen_masactrl(ref, out):
+    """The reference's MutualSelfAttentionControl + regiter_attention_editor_diffusers + h_Edit_masactrl_implicit
+    (text-guided/masactrl/, inversion/masactrl_h_edit.py), UNMODIFIED, on the toy UNet whose module hierarchy the
+    registration walks (helpers.tiny.TinyMasaUNet).  The reference imports its own package under a second name
+    (`masa_ctrl`): aliased here; torchvision.utils.save_image (unused on this path) is stubbed."""
+    from helpers.tiny import make_tiny_masa_model, PROMPT_PAIRS
+    tv = _stub("torchvision")
+    tv.utils = _stub("torchvision.utils", save_image=lambda *a, **k: None)
+    import masactrl.masactrl_utils as mu
+    pkg = _stub("masa_ctrl")
+    pkg.masactrl_utils = mu
+    sys.modules["masa_ctrl.masactrl_utils"] = mu
+    import masactrl.masactrl as mm
+    import inversion.masactrl_h_edit as mh
+    mh.tqdm = lambda x, *a, **k: x
+    T = 10
+    d = {}
+    torch.manual_seed(1234)
+    w0 = torch.randn(1, 4, 16, 16) * 0.8
+    d["w0"] = npy(w0)
+    meta = []
+    for name, pi, skip, K, ddim, step, layer in (("masa_k1", 0, 0, 1, False, 2, 3), ("masa_k2_skip2", 2, 2, 2, False, 1, 5),
+                                                 ("masa_ddim", 0, 0, 1, True, 0, 0), ("masa_off", 0, 0, 1, False, 99, 3)):
+        model = make_tiny_masa_model(T)
+        torch.manual_seed(4321 + pi)
+        if ddim:
+            _, zs, wts = ref.dd.ddim_inversion(model, w0, PROMPT_PAIRS[pi][0], 1.0)
+        else:
+            _, zs, wts, _ = ref.di.inversion_forward_process_ddpm(model, w0, etas=1.0, prog_bar=False, prompt=PROMPT_PAIRS[pi][0],
+                                                                  cfg_scale_src=1.0, num_inference_steps=T)
+        d[f"{name}_zs"], d[f"{name}_wts"] = npy(zs), npy(wts)
+        model = make_tiny_masa_model(T)
+        editor = mm.MutualSelfAttentionControl(step, layer)
+        mu.regiter_attention_editor_diffusers(model, editor)
+        after = T - skip
+        edit, recon = mh.h_Edit_masactrl_implicit(model, xT=wts[after], eta=1.0, prompts=[PROMPT_PAIRS[pi][0], PROMPT_PAIRS[pi][1]],
+                                                  cfg_scales=[1.0, 5.0, 7.5], prog_bar=False, zs=zs[:after], optimization_steps=K,
+                                                  after_skip_steps=after, is_ddim_inversion=ddim)
+        d[f"{name}_edit"], d[f"{name}_recon"] = npy(edit), npy(recon)
+        meta.append({"name": name, "pair": pi, "skip": skip, "K": K, "ddim": ddim, "start_step": step, "start_layer": layer,
+                     "cur_step": editor.cur_step, "num_att_layers": editor.num_att_layers})
+    np.savez_compressed(os.path.join(out, "g13_masactrl.npz"), **d)
+    with open(os.path.join(out, "g13_masactrl.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+
+
 def synthetic_rgb(h, w, seed):
     """smooth-ish deterministic uint8 image from integer arithmetic only (regenerated by the test)"""
     y, x = np.mgrid[0:h, 0:w].astype(np.int64)
@@ -707,6 +754,8 @@ def main():
         return gen_style(HERE)
     if "--only-face" in sys.argv:
         return gen_face(HERE)
+    if "--only-masactrl" in sys.argv:
+        return gen_masactrl(import_reference(), HERE)
     ref = import_reference()
     out = HERE
     gen_scheduler(ref, out)
@@ -716,6 +765,7 @@ def main():
     gen_loops(ref, out)
     gen_ddim(ref, out)
     gen_load512(ref, out)
+    gen_masactrl(ref, out)
     gen_style(out)
     gen_face(out)
     for f in sorted(os.listdir(out)):

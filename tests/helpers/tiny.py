@@ -416,3 +416,87 @@ class TinyLpips(nn.Module):
 
     def get_lpips_loss(self, x):
         return ((F.relu(self.conv(x.float())) - F.relu(self.conv(self.src))) ** 2).mean()
+
+
+# --------------------------------------------------------------------------- MasaCtrl toys
+class Attention(TinyAttention):
+    """Same module under the class NAME the reference's editor registration looks for
+    (text-guided/masactrl/masactrl_utils.py:90: ``net.__class__.__name__ == 'Attention'``)."""
+
+
+class _MasaBlock(nn.Module):
+    def __init__(self, ch, ctx_dim, heads, gen):
+        super().__init__()
+        self.mix = nn.Conv2d(ch, ch, 3, padding=1)
+        self.attn1 = Attention(ch, None, heads, gen)
+        self.attn2 = Attention(ch, ctx_dim, heads, gen)
+
+
+class TinyMasaUNet(nn.Module):
+    """TinyUNet with the module hierarchy the MasaCtrl registration walks: children named down_blocks /
+    mid_block / up_blocks (masactrl_utils.py:97-104) holding ``Attention`` modules; 8 blocks of
+    (self-attention, cross-attention), so ``cur_att_layer // 2`` is the block index as in SD."""
+
+    def __init__(self, ch=16, ctx_dim=32, heads=2, size=16, seed=5):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.in_channels, self.sample_size, self.ch = 4, size, ch
+        self.conv_in = nn.Conv2d(4, ch, 3, padding=1)
+        self.conv_out = nn.Conv2d(ch, 4, 3, padding=1)
+        self.t_proj = nn.Linear(ch, ch)
+        self.down_blocks = nn.ModuleList(_MasaBlock(ch, ctx_dim, heads, g) for _ in range(4))
+        self.mid_block = _MasaBlock(ch, ctx_dim, heads, g)
+        self.up_blocks = nn.ModuleList(_MasaBlock(ch, ctx_dim, heads, g) for _ in range(3))
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if ".attn" in name:
+                    continue
+                fan = p[0].numel() if p.dim() > 1 else 1
+                p.copy_(torch.randn(p.shape, generator=g) * (0.8 / math.sqrt(fan) if p.dim() > 1 else 0.05))
+        self.set_attn_processor({k: PlainProcessor() for k in self._proc_names()})
+
+    def _blocks(self):
+        return ([(f"down_blocks.{i}", b) for i, b in enumerate(self.down_blocks)] + [("mid_block", self.mid_block)] +
+                [(f"up_blocks.{i}", b) for i, b in enumerate(self.up_blocks)])
+
+    def _proc_names(self):
+        return [f"{n}.attentions.0.transformer_blocks.0.{a}.processor" for n, _ in self._blocks() for a in ("attn1", "attn2")]
+
+    @property
+    def attn_processors(self):
+        return {f"{n}.attentions.0.transformer_blocks.0.{a}.processor": getattr(b, a).processor
+                for n, b in self._blocks() for a in ("attn1", "attn2")}
+
+    def set_attn_processor(self, procs):
+        byname = dict(self._blocks())
+        for name, p in procs.items():
+            blk = name.split(".attentions")[0]
+            setattr(getattr(byname[blk], "attn1" if ".attn1." in name else "attn2"), "processor", p)
+
+    _temb = TinyUNet._temb
+
+    def forward(self, sample, timestep=None, encoder_hidden_states=None, cross_attention_kwargs=None):
+        kw = dict(cross_attention_kwargs or {})
+        b = sample.shape[0]
+        h = self.conv_in(sample) + self._temb(timestep, b, sample.dtype)[:, :, None, None]
+        for n, blk in self._blocks():
+            hh = F.avg_pool2d(h, 2) if n == "mid_block" else h
+            hh = hh + torch.tanh(blk.mix(hh))
+            bb, c, H, W = hh.shape
+            tok = hh.reshape(bb, c, H * W).transpose(1, 2)
+            tok = tok + blk.attn1(tok, None, **kw)
+            tok = tok + blk.attn2(tok, encoder_hidden_states, **kw)
+            hh = tok.transpose(1, 2).reshape(bb, c, H, W)
+            h = h + F.interpolate(hh, scale_factor=2.0, mode="nearest") if n == "mid_block" else hh
+        return UNetOutput(sample=0.5 * torch.tanh(0.1 * self.conv_out(h)) + 0.25 * sample)
+
+    def zero_grad(self, *a, **k):
+        return None
+
+
+def make_tiny_masa_model(num_inference_steps, seed=5):
+    m = make_tiny_model(num_inference_steps, seed=seed)
+    m.unet = TinyMasaUNet(seed=seed).eval()
+    for p in m.unet.parameters():
+        p.requires_grad_(False)
+    return m

@@ -160,7 +160,7 @@ def test_self_attention(lib, d, heads, N, B):
     out = torch.zeros(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
     k_view = qk.reshape(B * N, 2 * Cc)[:, Cc:]
     _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * Cc, C.c_void_p(k_view.data_ptr()), 2 * Cc, _lib.ptr(vt),
-                                     B * N, _lib.ptr(out), Cc, B, N, heads, d, None, None))
+                                     B * N, _lib.ptr(out), Cc, B, N, heads, d, None, None, None))
     G.sync()
     _, want = attn_ref(q.float(), k.float(), v.float(), heads)
     assert G.rel_err(out.float(), want) < 1.2e-2
@@ -170,7 +170,7 @@ def test_self_attention(lib, d, heads, N, B):
     idx = torch.tensor(src, dtype=torch.int32, device=G.dev())
     out2 = torch.zeros_like(out)
     _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * Cc, C.c_void_p(k_view.data_ptr()), 2 * Cc, _lib.ptr(vt),
-                                     B * N, _lib.ptr(out2), Cc, B, N, heads, d, _lib.ptr(idx), None))
+                                     B * N, _lib.ptr(out2), Cc, B, N, heads, d, _lib.ptr(idx), None, None))
     G.sync()
     _, want2 = attn_ref(q.float()[src], k.float()[src], v.float(), heads)
     assert G.rel_err(out2.float(), want2) < 1.2e-2
@@ -193,7 +193,7 @@ def test_self_attention_is_deterministic(lib, d, heads, N):
     for _ in range(3):
         out = torch.zeros(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
         _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * Cc, C.c_void_p(k_view.data_ptr()), 2 * Cc, _lib.ptr(vt),
-                                         B * N, _lib.ptr(out), Cc, B, N, heads, d, None, None))
+                                         B * N, _lib.ptr(out), Cc, B, N, heads, d, None, None, None))
         G.sync()
         outs.append(out)
     for b in range(1, B):
@@ -216,7 +216,7 @@ def test_self_attention_online_softmax_rescale(lib):
     out = torch.zeros(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
     k_view = qk.reshape(B * N, 2 * Cc)[:, Cc:]
     _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * Cc, C.c_void_p(k_view.data_ptr()), 2 * Cc, _lib.ptr(vt),
-                                     B * N, _lib.ptr(out), Cc, B, N, heads, d, None, None))
+                                     B * N, _lib.ptr(out), Cc, B, N, heads, d, None, None, None))
     G.sync()
     _, want = attn_ref(q.float(), k.float(), v.float(), heads)
     assert G.max_err(out.float(), want) < 3e-2

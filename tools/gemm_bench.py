@@ -70,7 +70,7 @@ for (N, c) in [(4096, 320), (1024, 640), (256, 1280)]:
     out = torch.empty(B * N, c, device=dev, dtype=torch.bfloat16)
     kv = qk[:, c:]
     f = lambda: _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * c, C.c_void_p(kv.data_ptr()), 2 * c, _lib.ptr(vt), B * N,
-                                                 _lib.ptr(out), c, B, N, heads, d, None, None))
+                                                 _lib.ptr(out), c, B, N, heads, d, None, None, None))
     us = timeit(f, 10)
     fl = 4.0 * B * N * N * c
     print(f"self_attn N={N} d={d} {us:9.1f} us {fl / us / 1e6:8.1f} TF/s")

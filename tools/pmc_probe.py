@@ -27,5 +27,5 @@ vt = torch.randn(c, B * N, device=dev).to(torch.bfloat16)
 out = torch.empty(B * N, c, device=dev, dtype=torch.bfloat16)
 kv = qk[:, c:]
 for _ in range(3):
-    _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * c, C.c_void_p(kv.data_ptr()), 2 * c, _lib.ptr(vt), B * N, _lib.ptr(out), c, B, N, 8, 40, None, None))
+    _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * c, C.c_void_p(kv.data_ptr()), 2 * c, _lib.ptr(vt), B * N, _lib.ptr(out), c, B, N, 8, 40, None, None, None))
 torch.cuda.synchronize()

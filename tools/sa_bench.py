@@ -17,7 +17,7 @@ for (N, c) in [(4096, 320), (1024, 640), (256, 1280)]:
     out = torch.empty(B * N, c, device=dev, dtype=torch.bfloat16)
     kv = qk[:, c:]
     f = lambda: _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * c, C.c_void_p(kv.data_ptr()), 2 * c, _lib.ptr(vt), B * N,
-                                                 _lib.ptr(out), c, B, N, heads, d, None, None))
+                                                 _lib.ptr(out), c, B, N, heads, d, None, None, None))
     f(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

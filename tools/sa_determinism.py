@@ -19,7 +19,7 @@ for (N, c, heads, B) in [(4096, 320, 8, 4), (1024, 640, 8, 4), (256, 1280, 8, 4)
     for rep in range(3):
         out = torch.zeros(B * N, c, device=dev, dtype=torch.bfloat16)
         _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * c, C.c_void_p(kv.data_ptr()), 2 * c, _lib.ptr(vt), B * N,
-                                         _lib.ptr(out), c, B, N, heads, d, None, None))
+                                         _lib.ptr(out), c, B, N, heads, d, None, None, None))
         torch.cuda.synchronize()
         outs.append(out.reshape(B, N, c).clone())
     rows = max((outs[0][b].float() - outs[0][0].float()).abs().max().item() for b in range(1, B))
