@@ -131,3 +131,23 @@ def test_style_driver_writes_edited_images(tmp_path, capsys):
     assert capsys.readouterr().out.count("loss from CLIP:") == 2
     with pytest.raises(NotImplementedError):
         drv.main(["--dataset", str(d) + "/", "--random_init", "--tiny", "--mode", "ef_p2p"])
+
+
+@pytest.mark.parametrize("extra", [[], ["--mode", "h_edit_R_masactrl", "--eta", "1.0", "--optimization_steps", "2"]])
+def test_masactrl_driver_writes_edited_images(tmp_path, extra):
+    """main_masactrl.py (reference text-guided/main_masactrl.py:128-241) on the PIE-Bench-style dataset"""
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("hedit_main_masactrl", os.path.join(ROOT, "h-edit_amd", "main_masactrl.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    d = _dataset(tmp_path)
+    out = tmp_path / "results"
+    written = drv.main(["--data_path", str(d), "--output_path", str(out), "--random_init", "--tiny", "--num_diffusion_steps", "4",
+                        "--edit_category_list", "0", "7", "--step", "1", "--layer", "2"] + extra)
+    assert len(written) == 2
+    for p in written:
+        assert "_step_1_layer_2_" in p and os.path.exists(p)
+        im = np.array(Image.open(p))
+        assert im.shape == (256, 256, 3) and im.std() > 0
+    with pytest.raises(NotImplementedError):
+        drv.main(["--data_path", str(d), "--random_init", "--tiny", "--mode", "ef_masactrl"])

@@ -82,3 +82,20 @@ def test_style_driver_flags_match_the_reference_cli():
     for k, v in reference_defaults.items():
         assert a[k] == v, k
     assert set(a) - set(reference_defaults) == {"model_path", "clip_path", "random_init", "tiny", "seed"}
+
+
+def test_masactrl_driver_flags_match_the_reference_cli():
+    """h-edit_amd/main_masactrl.py keeps the flag names and defaults of text-guided/main_masactrl.py:55-88."""
+    import importlib.util
+    sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+    spec = importlib.util.spec_from_file_location("hedit_main_masactrl_cli", os.path.join(ROOT, "h-edit_amd", "main_masactrl.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    a = vars(m.build_parser().parse_args([]))
+    reference_defaults = dict(device_num=0, data_path="./PIE_Bench_Data", output_path="./results/masactrl",
+                              edit_category_list=[str(i) for i in range(10)], mode="h_edit_D_masactrl", num_diffusion_steps=50,
+                              skip=0, eta=0.0, cfg_src=1.0, cfg_src_edit=5.0, cfg_tar=7.5, implicit=False, optimization_steps=1,
+                              weight_reconstruction=0.1, layer=10, step=4)
+    for k, v in reference_defaults.items():
+        assert a[k] == v, k
+    assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed"}
