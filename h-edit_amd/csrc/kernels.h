@@ -50,6 +50,7 @@ int ctx_pad_launch(const float* x, bf16_t* y, int B, int dim, hipStream_t st);
 // out[n] = sum_k W[n][k] * act(x[k]) + b0[n] + b1[n]   (act = SiLU if silu), x/out fp32, W bf16
 int gemv_launch(const bf16_t* W, const float* x, const float* b0, const float* b1, float* out,
                 int N, int K, int silu, hipStream_t st);
+int copy_rows_launch(bf16_t* x, const int* src, int B, long row_elems, hipStream_t st);   // x[b] <- x[src[b]]
 int timestep_embed_launch(float t, float* out, int dim, hipStream_t st);
 int timestep_embed_ddpm_launch(float t, float* out, int dim, hipStream_t st);   // [sin | cos], exponent / (half-1)
 // conv_in: x fp32 NCHW [B][Cin<=8][H][W], w fp32 [Cout][Cin][3][3] -> y NHWC bf16 [B][H][W][Cout]

@@ -551,6 +551,25 @@ int timestep_embed_launch(float t, float* out, int dim, hipStream_t st) {
   return HEDIT_OK;
 }
 
+// x[b] <- x[src[b]] for the rows with src[b] != b (Plug-and-Play feature injection: target rows take the source
+// row's activations); rows that are read are never written (src[src[b]] == src[b])
+__global__ __launch_bounds__(256) void copy_rows_kernel(bf16_t* __restrict__ x, const int* __restrict__ src, long row_v) {
+  const int b = blockIdx.y;
+  const int s = src[b];
+  if (s == b) return;
+  const uint4* from = reinterpret_cast<const uint4*>(x) + (long)s * row_v;
+  uint4* to = reinterpret_cast<uint4*>(x) + (long)b * row_v;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < row_v; i += (long)gridDim.x * 256) to[i] = from[i];
+}
+
+int copy_rows_launch(bf16_t* x, const int* src, int B, long row_elems, hipStream_t st) {
+  ARG_CHECK(row_elems % 8 == 0, "copy_rows: row size must be a multiple of 8 elements");
+  const long row_v = row_elems / 8;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_grid(row_v) > 256 ? 256 : ew_grid(row_v), B), dim3(256), 0, st, x, src, row_v);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
 int timestep_embed_ddpm_launch(float t, float* out, int dim, hipStream_t st) {
   ARG_CHECK(dim >= 4, "timestep_embed_ddpm: dim >= 4");
   hipLaunchKernelGGL(timestep_embed_ddpm_kernel, dim3(1), dim3(256), 0, st, t, out, dim);

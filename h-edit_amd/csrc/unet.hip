@@ -189,7 +189,8 @@ struct Fwd {
   const float* temb_all;     // fused (time_emb_proj(silu(temb)) + conv1.bias) of every ResBlock
   const bf16_t* ctxb;        // [B*80][ctx_dim]
   int store_idx = 0;
-  int tblock = 0;            // transformer blocks visited so far in this call (MasaCtrl layer gate)
+  int tblock = 0;            // transformer blocks visited so far in this call (MasaCtrl / PnP layer gates)
+  int rblock = 0;            // ResNet blocks visited so far (PnP feature injection)
   bool dry() const { return ar.dry; }
 };
 
@@ -291,6 +292,11 @@ int resblock(Fwd& f, const Res& r, const bf16_t* x, int H, int W, bf16_t** out) 
     TRY(linear(f, x, (int)M, r.cin, r.sc_w, r.cout, r.sc_b, nullptr, sc, r.cout));
     res = sc;
   }
+  {   // Plug-and-Play feature injection: the target rows' conv2 input becomes the source rows'
+    const hedit_p2p_plan* pl = (f.plan && f.plan->mode > 0) ? f.plan : nullptr;
+    if (pl && pl->feat_src && f.rblock == pl->feat_resblock) RUN(f, copy_rows_launch(a2, pl->feat_src, f.B, (long)H * W * r.cout, f.st));
+    ++f.rblock;
+  }
   TRY(aalloc(f, &y, M * r.cout));
   TRY(conv3x3(f, a2, H, W, r.cout, r.conv2, r.cout, r.conv2_b, res, y, 1));
   f.ar.free(a2);
@@ -326,7 +332,8 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
     SelfAttnParams sp{};
     sp.q = qk; sp.ldq = 2 * C; sp.k = qk + C; sp.ldk = 2 * C; sp.vt = vt; sp.ldvt = (long)M;
     sp.out = ao; sp.ldo = C; sp.B = B; sp.N = N; sp.heads = heads; sp.d = d;
-    sp.qk_src = (pl && pl->qk_src && N <= 1024) ? pl->qk_src : nullptr;
+    sp.qk_src = (pl && pl->qk_src && N <= (pl->qk_max_tokens > 0 ? pl->qk_max_tokens : 1024) && f.tblock >= pl->qk_first_block)
+                    ? pl->qk_src : nullptr;
     sp.kv_src = (pl && pl->kv_src && f.tblock >= pl->kv_first_block) ? pl->kv_src : nullptr;
     ++f.tblock;
     ProfScope ps(f, PK_SELF_ATTN, 4.0 * B * (double)N * N * C);

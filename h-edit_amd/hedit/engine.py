@@ -275,6 +275,59 @@ class HEditEngine:
                 xt = controller.step_callback(xt)
         return xt[n:].clone(), xt[:n].clone()
 
+    # ------------------------------------------------------------------ Plug-and-Play loop
+    @torch.no_grad()
+    def run_pnp(self, xT, zs, prompts, cfg_scales, eta=1.0, K=1, after_skip_steps=None, ddim_inv=True):
+        """h-Edit with Plug-and-Play injection, text-guided/inversion/pnp_h_edit.py:24-167 (one image: the
+        reference's injection rule only fires for a batch of two).  Per step: the 4-row base pass (plain; with four
+        rows the hooks stay silent, pnp_utils.py:46-50), then per inner step eps(x^k, t-1, null) and eps(x^k, t-1, src)
+        -- two 1-row calls in the reference, one plain 2-row call here -- and the 2-row pass
+        [x^orig | src, x^k | tar] under the registered injection plan.  Returns (edit, recon)."""
+        from .plug_n_play.pnp_utils import register_time
+        sch = self.model.scheduler
+        S = Schedule(sch)
+        T = sch.num_inference_steps
+        if after_skip_steps is None:
+            after_skip_steps = T
+        dev = self.dev
+        xT = xT.to(device=dev, dtype=torch.float32)
+        if xT.shape[0] != 1:
+            raise ValueError("Plug-and-Play edits one image per call")
+        if zs is not None:
+            zs = zs.to(device=dev, dtype=torch.float32).contiguous()
+        null, src, tar = self.encode([""]), self.encode([prompts[0]]), self.encode([prompts[1]])
+        ctx_base4 = torch.cat([null, null, src, src]).contiguous()
+        ctx_k2 = torch.cat([null, src]).contiguous()
+        ctx_pair = torch.cat([src, tar]).contiguous()
+        editor = getattr(self.unet, "_attention_editor", None)
+        ts = [int(v) for v in sch.timesteps]
+        op = ts[-after_skip_steps:]
+        xt = torch.cat([xT, xT]).contiguous()
+        x_prev = torch.empty_like(xt)
+        H, W = xT.shape[2], xT.shape[3]
+        for i, t in enumerate(op):
+            idx = T - i - (T - after_skip_steps + 1)
+            z = zs[idx] if zs is not None else None
+            tt = op[i + 1] if i < len(op) - 1 else 0
+            coef = S.step_coef(t, tt, eta, ddim_inv, cfg_scales, 0.0)
+            register_time(self.model, t)
+            e = self.unet.forward_raw(torch.cat([xt, xt]), t, ctx_base4, None)
+            self.step_base(e, xt, z, x_prev, 1, 4, coef)
+            x_orig, x_base = x_prev[:1], x_prev[1:]
+            x_k = x_base.clone()
+            for _ in range(K):
+                register_time(self.model, tt)
+                e2 = self.unet.forward_raw(torch.cat([x_k, x_k]), tt, ctx_k2, None)
+                plan = editor._plan(self.unet, 2, H, W, True) if editor is not None else None
+                ep = self.unet.forward_raw(torch.cat([x_orig, x_k]), tt, ctx_pair, plan)
+                if editor is not None:
+                    editor._after_pass(True)
+                new = torch.empty_like(x_k)
+                self.step_update(e2[0:1], e2[1:2], e2[0:1], ep[1:2], x_k, x_base, new, 1, False, coef)
+                x_k = new
+            xt = torch.cat([x_orig, x_k]).contiguous()
+        return xt[1:].clone(), xt[:1].clone()
+
     # ------------------------------------------------------------------ DDPM inversion
     @torch.no_grad()
     def ddpm_inversion(self, x0, prompts, eta=1.0, cfg_src=1.0, noise=None, generator=None):

@@ -254,6 +254,7 @@ class UNet2DConditionModel:
         kw = dict(cross_attention_kwargs or {})
         use_controller = kw.pop("use_controller", True)
         save_attn = kw.pop("save_attn", True)
+        use_editor = kw.pop("use_editor", True)          # MasaCtrl's switch (masactrl_utils.py:40)
         if kw:
             raise TypeError(f"unsupported cross_attention_kwargs {sorted(kw)}")
         if isinstance(timestep, torch.Tensor):
@@ -266,6 +267,10 @@ class UNet2DConditionModel:
         sample = sample.to(device=self.device, dtype=torch.float32)
         ctx = encoder_hidden_states.to(device=self.device, dtype=torch.float32)
         controller = self._controller() if use_controller else None
+        if controller is None and use_editor:
+            # an attention editor registered on the UNet (MasaCtrl: regiter_attention_editor_diffusers; Plug-and-Play:
+            # register_attention_control_efficient / register_conv_control_efficient)
+            controller = getattr(self, "_attention_editor", None)
         plan = None
         if controller is not None:
             plan = controller._plan(self, sample.shape[0], sample.shape[2], sample.shape[3], save_attn)

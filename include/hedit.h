@@ -76,6 +76,13 @@ typedef struct {
    * of row kv_src[b] (its own queries).  NULL = off. */
   const int32_t* kv_src;    /* [B] */
   int kv_first_block;
+  /* Plug-and-Play injection (text-guided/plug_n_play/pnp_utils.py:29-154): the qk_src map above, restricted to the
+   * transformer blocks with index >= qk_first_block and to layers with <= qk_max_tokens tokens (0 = the P2P
+   * default, 32*32); and feat_src: before conv2 of ResNet block number feat_resblock (call order) row b takes the
+   * activations of row feat_src[b], i.e. its conv2 output becomes the source row's (pnp_utils.py:131-140).  NULL = off. */
+  int qk_first_block, qk_max_tokens;
+  const int32_t* feat_src;  /* [B] */
+  int feat_resblock;
 } hedit_p2p_plan;
 
 typedef struct {

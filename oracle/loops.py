@@ -10,6 +10,7 @@ Restates, against the same duck-typed ``model`` object the reference uses:
   h_edit_p2p_implicit           text-guided/inversion/p2p_h_edit.py:529-701
   h_edit_p2p_implicit_style     text-guided-n-style/inversion/h_edit.py:14-192 (text + style editing)
   h_edit_masactrl_implicit      text-guided/inversion/masactrl_h_edit.py:10-155 (editor from oracle/masactrl.py)
+  h_edit_pnp_implicit           text-guided/inversion/pnp_h_edit.py:24-167 (hooks from oracle/pnp.py)
 The four loops share one skeleton here (``_loop``); the per-variant differences are the UNet
 batches and which eps feeds the three CFG mixes.
 """
@@ -286,3 +287,39 @@ def h_edit_masactrl_implicit(model, xT, eta=0, prompts="", cfg_scales=None, zs=N
     """text-guided/inversion/masactrl_h_edit.py:10-155; the editor is the one registered on model.unet."""
     return _loop(model, xT, eta, prompts, cfg_scales, zs, None, after_skip_steps, is_ddim_inversion,
                  p2p=True, implicit=True, K=optimization_steps, masactrl=True)
+
+
+def h_edit_pnp_implicit(model, xT, eta=0, prompts="", cfg_scales=None, zs=None, optimization_steps=1,
+                        after_skip_steps=35, is_ddim_inversion=True):
+    """text-guided/inversion/pnp_h_edit.py:24-167: per step the plain 4-row base pass, then per inner step two 1-row
+    passes eps(x^k, t-1, src), eps(x^k, t-1, null) and the 2-row pass [x^orig|src, x^k|tar] in which the
+    registered Plug-and-Play hooks fire; no reconstruction pull, no callback."""
+    from . import pnp
+    sch, (w_src, w_hat, w_tar), txt, unc, xt, op = _prep(model, xT, prompts, cfg_scales, after_skip_steps)
+    T = sch.num_inference_steps
+    pos = {int(v): k for k, v in enumerate(op)}
+
+    def unet(x, t, ctx):
+        with torch.no_grad():
+            return model.unet(x, t, encoder_hidden_states=ctx).sample
+
+    for i, t in enumerate(op):
+        idx = T - pos[int(t)] - (T - after_skip_steps + 1)
+        z = zs[idx] if zs is not None else None
+        tt = op[i + 1] if i < len(op) - 1 else torch.tensor(0)
+        pnp.register_time(model, int(t))
+        e = unet(torch.cat([xt] * 2), t, torch.cat([unc[:1], unc[:1], txt[:1], txt[:1]]))
+        e_u, e_c = e.chunk(2)
+        prev = S.reverse_step(sch, e_u + w_src * (e_c - e_u), t, xt, eta=eta, z=z, ddim_inv=is_ddim_inversion)
+        x_orig, x_k = prev.chunk(2)
+        coeff = S.edit_coeff(sch, t, tt, eta, is_ddim_inversion)
+        for _ in range(optimization_steps):
+            pnp.register_time(model, int(tt))
+            e_c_src = unet(x_k, tt, txt[:1])
+            e_u_tar = unet(x_k, tt, unc[1:])
+            e_c_tar = unet(torch.cat([x_orig, x_k]), tt, txt)[1:2]
+            e_hat = e_u_tar + w_hat * (e_c_src - e_u_tar)
+            e_tar = e_u_tar + w_tar * (e_c_tar - e_u_tar)
+            x_k = x_k + coeff * (e_tar - e_hat)
+        xt = torch.cat([x_orig, x_k.detach()])
+    return xt[1].unsqueeze(0), xt[0].unsqueeze(0)

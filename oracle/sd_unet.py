@@ -164,6 +164,13 @@ class ResnetBlock2D(nn.Module):
         self.norm2 = nn.GroupNorm(groups, cout, eps=1e-5)
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+        # the remaining attribute surface of diffusers' ResnetBlock2D that the reference's Plug-and-Play hook
+        # reads when it replaces this forward (text-guided/plug_n_play/pnp_utils.py:96-150)
+        self.nonlinearity = F.silu
+        self.upsample = self.downsample = None
+        self.time_embedding_norm = "default"
+        self.dropout = nn.Dropout(0.0)
+        self.output_scale_factor = 1.0
 
     def forward(self, x, temb):
         h = self.conv1(F.silu(self.norm1(x)))

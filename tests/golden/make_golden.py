@@ -424,6 +424,43 @@ def gen_masactrl(ref, out):
         json.dump(meta, f, indent=0)
 
 
+# --------------------------------------------------------------------------- G14: Plug-and-Play
+def gen_pnp(ref, out):
+    """The reference's Plug-and-Play hooks (plug_n_play/pnp_utils.py) and h_Edit_PnP_implicit (inversion/pnp_h_edit.py),
+    UNMODIFIED, patched into the ORACLE's SD UNet (oracle/sd_unet.py exposes the diffusers attribute surface the hooks
+    read) at the four-level toy configuration; weights / text encoder are the seeded ones the tests rebuild."""
+    from helpers.tiny import make_oracle_sd_model, PROMPT_PAIRS, TINY4_CONFIG
+    import plug_n_play.pnp_utils as pu
+    import inversion.pnp_h_edit as ph
+    ph.tqdm = lambda x, *a, **k: x
+    T = 4
+    d = {}
+    torch.manual_seed(77)
+    w0 = torch.randn(1, 4, 64, 64) * 0.8
+    d["w0"] = npy(w0)
+    meta = []
+    for name, K, f_t, attn_t in (("pnp_k1", 1, 0.5, 0.5), ("pnp_k2_attn_only", 2, -1.0, 0.75)):
+        model, _ = make_oracle_sd_model(TINY4_CONFIG, T)
+        torch.manual_seed(300)
+        _, zs, wts, _ = ref.di.inversion_forward_process_ddpm(model, w0, etas=1.0, prog_bar=False, prompt=PROMPT_PAIRS[0][0],
+                                                              cfg_scale_src=1.0, num_inference_steps=T)
+        d[f"{name}_zs"], d[f"{name}_wts"] = npy(zs), npy(wts)
+        model, _ = make_oracle_sd_model(TINY4_CONFIG, T)
+        n_f, n_a = int(T * f_t), int(T * attn_t)
+        qk = model.scheduler.timesteps[:n_a] if n_a >= 0 else []
+        conv = model.scheduler.timesteps[:n_f] if n_f >= 0 else []
+        pu.register_attention_control_efficient(model, qk)
+        pu.register_conv_control_efficient(model, conv)
+        edit, recon = ph.h_Edit_PnP_implicit(model, xT=wts[T], eta=1.0, prompts=[PROMPT_PAIRS[0][0], PROMPT_PAIRS[0][1]],
+                                             cfg_scales=[1.0, 5.0, 7.5], prog_bar=False, zs=zs[:T], optimization_steps=K,
+                                             after_skip_steps=T, is_ddim_inversion=False)
+        d[f"{name}_edit"], d[f"{name}_recon"] = npy(edit), npy(recon)
+        meta.append({"name": name, "K": K, "qk": [int(v) for v in qk], "conv": [int(v) for v in conv]})
+    np.savez_compressed(os.path.join(out, "g14_pnp.npz"), **d)
+    with open(os.path.join(out, "g14_pnp.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+
+
 def synthetic_rgb(h, w, seed):
     """smooth-ish deterministic uint8 image from integer arithmetic only (regenerated by the test)"""
     y, x = np.mgrid[0:h, 0:w].astype(np.int64)
@@ -754,6 +791,8 @@ def main():
         return gen_style(HERE)
     if "--only-face" in sys.argv:
         return gen_face(HERE)
+    if "--only-pnp" in sys.argv:
+        return gen_pnp(import_reference(), HERE)
     if "--only-masactrl" in sys.argv:
         return gen_masactrl(import_reference(), HERE)
     ref = import_reference()
@@ -766,6 +805,7 @@ def main():
     gen_ddim(ref, out)
     gen_load512(ref, out)
     gen_masactrl(ref, out)
+    gen_pnp(ref, out)
     gen_style(out)
     gen_face(out)
     for f in sorted(os.listdir(out)):

@@ -500,3 +500,42 @@ def make_tiny_masa_model(num_inference_steps, seed=5):
     for p in m.unet.parameters():
         p.requires_grad_(False)
     return m
+
+
+# --------------------------------------------------------------------------- Plug-and-Play: SD-shaped four-level toy
+# the reference's PnP hooks index down_blocks[0..2].attentions[0..1], up_blocks[1..3].attentions[0..2] and
+# up_blocks[1].resnets[1] (pnp_utils.py:12-27,88-93,152-153): the layout of SD-1.x at toy width
+TINY4_CONFIG = dict(in_channels=4, out_channels=4, sample_size=64, block_out_channels=(64, 64, 128, 128),
+                    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+                    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+                    layers_per_block=2, cross_attention_dim=64, attention_head_dim=2, norm_num_groups=32)
+
+
+def make_oracle_sd_model(config, num_steps, seed=0, text_layers=2, out_scale=0.3):
+    """the CPU half of helpers.models.make_pair: oracle SD UNet + seeded text encoder + scheduler, seeded weights"""
+    import sys as _sys
+    import os as _os
+    root = _os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    for p_ in (root, _os.path.join(root, "h-edit_amd")):
+        if p_ not in _sys.path:
+            _sys.path.insert(0, p_)
+    from hedit.scheduler import DDIMScheduler
+    from hedit.text import ClipTextEncoder, WordTokenizer as WT
+    from hedit.unet import random_state_dict
+    from oracle import sd_unet as OU
+    net = OU.UNet2DConditionModel(**config)
+    sd = random_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed)
+    sd["conv_out.weight"] = sd["conv_out.weight"] * out_scale
+    sd["conv_out.bias"] = sd["conv_out.bias"] * out_scale
+    net.load_state_dict(sd)
+    for p_ in net.parameters():
+        p_.requires_grad_(False)
+    m = types.SimpleNamespace()
+    m.device = torch.device("cpu")
+    m.unet = net.eval()
+    m.scheduler = DDIMScheduler()
+    m.scheduler.set_timesteps(num_steps)
+    m.tokenizer = WT()
+    m.text_encoder = ClipTextEncoder(dim=config["cross_attention_dim"], layers=text_layers, heads=4, seed=seed + 7)
+    m.vae = None
+    return m, sd
