@@ -16,6 +16,8 @@ Pinning status
     (loops.h_edit_p2p_implicit_style) likewise on g9, reproduced bit for bit.
   * MasaCtrl (oracle/masactrl.py + loops.h_edit_masactrl_implicit): PINNED on vectors from running the
     reference's MutualSelfAttentionControl / registration / h_Edit_masactrl_implicit (g13).
+  * Plug-and-Play (oracle/pnp.py + loops.h_edit_pnp_implicit): PINNED on vectors from running the reference's
+    pnp_utils hooks and pnp_h_edit loop patched into the oracle SD UNet (g14).
   * face-swapping path: the pixel DDPM UNet (oracle/ddpm_unet.py) and the SDE inversion / h_Edit_R face loop
     (oracle/face_loops.py) are PINNED on vectors from running the reference's own in-tree
     face-swapping/diffusion/diffusion.py, inversion/sde_inversion.py and inversion/h_edit_R.py (g11).

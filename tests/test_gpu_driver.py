@@ -151,3 +151,23 @@ def test_masactrl_driver_writes_edited_images(tmp_path, extra):
         assert im.shape == (256, 256, 3) and im.std() > 0
     with pytest.raises(NotImplementedError):
         drv.main(["--data_path", str(d), "--random_init", "--tiny", "--mode", "ef_masactrl"])
+
+
+@pytest.mark.parametrize("extra", [[], ["--mode", "h_edit_D_pnp", "--eta", "0.0", "--pnp_f_t", "0.6", "--pnp_attn_t", "0.4"]])
+def test_pnp_driver_writes_edited_images(tmp_path, extra):
+    """main_plugnplay.py (reference text-guided/main_plugnplay.py:124-248) on the PIE-Bench-style dataset"""
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("hedit_main_pnp", os.path.join(ROOT, "h-edit_amd", "main_plugnplay.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    d = _dataset(tmp_path)
+    out = tmp_path / "results"
+    written = drv.main(["--data_path", str(d), "--output_path", str(out), "--random_init", "--tiny", "--num_diffusion_steps", "4",
+                        "--edit_category_list", "0"] + extra)
+    assert len(written) == 1
+    p = written[0]
+    assert "_f_t_" in p and "_attn_t_" in p and os.path.exists(p)
+    im = np.array(Image.open(p))
+    assert im.shape == (256, 256, 3) and im.std() > 0
+    with pytest.raises(NotImplementedError):
+        drv.main(["--data_path", str(d), "--random_init", "--tiny", "--mode", "ef_pnp"])

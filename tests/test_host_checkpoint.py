@@ -99,3 +99,20 @@ def test_masactrl_driver_flags_match_the_reference_cli():
     for k, v in reference_defaults.items():
         assert a[k] == v, k
     assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed"}
+
+
+def test_pnp_driver_flags_match_the_reference_cli():
+    """h-edit_amd/main_plugnplay.py keeps the flag names and defaults of text-guided/main_plugnplay.py:56-87."""
+    import importlib.util
+    sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+    spec = importlib.util.spec_from_file_location("hedit_main_pnp_cli", os.path.join(ROOT, "h-edit_amd", "main_plugnplay.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    a = vars(m.build_parser().parse_args([]))
+    reference_defaults = dict(device_num=0, data_path="./PIE_Bench_Data", output_path="./results/pnp",
+                              edit_category_list=[str(i) for i in range(10)], mode="h_edit_R_pnp", num_diffusion_steps=50,
+                              skip=0, eta=1.0, cfg_src=1.0, cfg_src_edit=5.0, cfg_tar=7.5, implicit=False, optimization_steps=1,
+                              weight_reconstruction=0.1, pnp_f_t=0.45, pnp_attn_t=0.35)
+    for k, v in reference_defaults.items():
+        assert a[k] == v, k
+    assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed"}
