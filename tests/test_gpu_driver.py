@@ -171,3 +171,57 @@ def test_pnp_driver_writes_edited_images(tmp_path, extra):
     assert im.shape == (256, 256, 3) and im.std() > 0
     with pytest.raises(NotImplementedError):
         drv.main(["--data_path", str(d), "--random_init", "--tiny", "--mode", "ef_pnp"])
+
+
+def test_demo_driver_writes_edited_images(tmp_path):
+    """main_demo.py (reference text-guided/main_demo.py:124-262): demo.yaml list -> edited PNGs"""
+    import yaml
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("hedit_main_demo", os.path.join(ROOT, "h-edit_amd", "main_demo.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    d = tmp_path / "demo"
+    d.mkdir()
+    y, x = np.mgrid[0:96, 0:128]
+    Image.fromarray(np.stack([(x * 3) % 256, (y * 5) % 256, (x + y) % 256], -1).astype(np.uint8)).save(d / "lizard.jpg")
+    with open(d / "demo.yaml", "w") as f:
+        yaml.safe_dump([dict(image="/lizard.jpg", source_prompt="a green lizard is sitting on a branch",
+                             target_prompt="a brown lizard is sitting on a branch", blended_word="lizard lizard",
+                             editing_instruction="Change the color of the lizard to brown")], f)
+    out = tmp_path / "results"
+    for extra in (["--implicit"], ["--mode", "h_edit_D_p2p", "--eta", "0.0", "--sa", "0.6"]):
+        written = drv.main(["--data_path", str(d), "--output_path", str(out), "--random_init", "--tiny",
+                            "--num_diffusion_steps", "4"] + extra)
+        assert len(written) == 1 and written[0].endswith("lizard.jpg") and os.path.exists(written[0])
+        assert np.array(Image.open(written[0])).shape == (256, 256, 3)
+
+
+def test_face_driver_writes_swapped_images(tmp_path, capsys):
+    """main_edit_face.py (reference face-swapping/main_edit.py:134-224): {idx, source, ref} pairs -> inversion, h_Edit_R with
+    the identity reward, a [ref | source | result] sheet per pair; with and without the post-processing mask."""
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("hedit_main_face", os.path.join(ROOT, "h-edit_amd", "main_edit_face.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    d = tmp_path / "faces"
+    (d / "masks").mkdir(parents=True)
+    y, x = np.mgrid[0:80, 0:72]
+    for i, name in enumerate(("1368.jpg", "7522.jpg")):
+        Image.fromarray(np.stack([(x * (i + 2)) % 256, (y * 3 + i * 40) % 256, (x + y) % 256], -1).astype(np.uint8)).save(d / name)
+    lab = np.zeros((32, 32), dtype=np.uint8)
+    lab[8:24, 8:24] = 1
+    lab[18:21, 12:20] = 10
+    Image.fromarray(lab).save(d / "masks" / "7522.png")
+    with open(d / "demo.json", "w") as f:
+        json.dump([dict(idx=0, ref="1368.jpg", source="7522.jpg")], f)
+    common = ["--json_file", str(d / "demo.json"), "--image_path", str(d) + "/", "--output_path", str(tmp_path / "out") + "/",
+              "--random_init", "--tiny", "--num_diffusion_steps", "10", "--optimization_steps", "2", "--weight_edit_face", "4.0"]
+    for extra in ([], ["--mask_dir", str(d / "masks")]):
+        written = drv.main(common + extra)
+        assert len(written) == 1 and written[0].endswith("item_1368_7522.png")
+        assert "h_edit_R/steps_10_skip_0_weight_4.0_opts_2" in written[0]
+        im = np.array(Image.open(written[0]))
+        assert im.shape == (32, 96, 3) and im.std() > 0
+    assert capsys.readouterr().out.count("Cosine Similarity:") == 2
+    with pytest.raises(NotImplementedError):
+        drv.main(common + ["--mode", "ef"])

@@ -116,3 +116,52 @@ def test_pnp_driver_flags_match_the_reference_cli():
     for k, v in reference_defaults.items():
         assert a[k] == v, k
     assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed"}
+
+
+def test_demo_driver_flags_match_the_reference_cli():
+    """h-edit_amd/main_demo.py keeps the flag names and defaults of text-guided/main_demo.py:49-84."""
+    import importlib.util
+    sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+    spec = importlib.util.spec_from_file_location("hedit_main_demo_cli", os.path.join(ROOT, "h-edit_amd", "main_demo.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    a = vars(m.build_parser().parse_args([]))
+    reference_defaults = dict(device_num=0, data_path="./assets/demo", output_path="./results/demo", mode="h_edit_R_p2p",
+                              num_diffusion_steps=50, skip=0, eta=1.0, cfg_src=1.0, cfg_src_edit=5.0, cfg_tar=7.5, implicit=False,
+                              optimization_steps=1, weight_reconstruction=0.1, xa=0.4, sa=0.35)
+    for k, v in reference_defaults.items():
+        assert a[k] == v, k
+    assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed"}
+
+
+def test_face_driver_flags_match_the_reference_cli():
+    """h-edit_amd/main_edit_face.py keeps the flag names and defaults of face-swapping/main_edit.py:35-60
+    (--post_processing is store_false there: on by default)."""
+    import importlib.util
+    sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+    spec = importlib.util.spec_from_file_location("hedit_main_face_cli", os.path.join(ROOT, "h-edit_amd", "main_edit_face.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    a = vars(m.build_parser().parse_args([]))
+    reference_defaults = dict(device_num=0, json_file="./assets/demo/demo.json", image_path="./assets/demo/",
+                              output_path="./results/demo/", mode="h_edit_R", num_diffusion_steps=100, skip=0, eta=1.0,
+                              optimization_steps=3, post_processing=True, weight_edit_face=50.0)
+    for k, v in reference_defaults.items():
+        assert a[k] == v, k
+    assert set(a) - set(reference_defaults) == {"ddpm_ckpt", "arcface_ckpt", "mask_dir", "random_init", "tiny", "seed"}
+
+
+def test_soft_erosion_and_segmentation_encoding():
+    """face_utils: class ids -> (face, mouth, hair) maps; SoftErosion shrinks the mask, saturates the interior at 1"""
+    import torch
+    from hedit.arcface.face_utils import SoftErosion, encode_segmentation
+    seg = torch.zeros(1, 1, 32, 32, dtype=torch.long)
+    seg[..., 8:24, 8:24] = 1
+    seg[..., 18:21, 12:20] = 10
+    seg[..., 0:4, :] = 13
+    enc = encode_segmentation(seg)
+    assert enc.shape == (1, 3, 32, 32)
+    assert int(enc[0, 0].sum()) == 16 * 16 and int(enc[0, 1].sum()) == 3 * 8 and int(enc[0, 2].sum()) == 4 * 32
+    soft, hard = SoftErosion(kernel_size=5, threshold=0.9, iterations=2)(enc[:, 0, None].float())
+    assert soft.max() == 1.0 and soft.min() >= 0.0 and hard.sum() < 16 * 16 and soft[0, 0, 16, 16] == 1.0
+    assert soft[0, 0, 0, 0] == 0.0
