@@ -131,3 +131,16 @@ def test_sde_inversion_and_face_loop_match_oracle():
         G.sync()
         assert got.shape == (1, 3, 32, 32) and torch.isfinite(got).all()
         assert G.rel_err(got, want) < (6e-2 if after <= 4 else 1.5e-1), (skip, K)
+
+
+def test_unet_batch_grouping_of_the_attention_is_transparent(tiny):
+    """the block-diagonal attention stacks up to 4096 / T images per pass: a batch of 20 at T = 256 runs as groups of
+    16 + 4; every image must come out as in a batch of its own (up to the bf16 rounding of batch-dependent partitions)"""
+    hip, _ = tiny
+    x = (hash_normal((20, 3, 32, 32), 71) * 0.8).to(G.dev())
+    big = hip(x, 401.0)
+    parts = torch.cat([hip(x[i:i + 5], 401.0) for i in range(0, 20, 5)])
+    G.sync()
+    assert torch.isfinite(big).all()
+    for i in (0, 7, 15, 16, 19):
+        assert G.rel_err(big[i:i + 1], parts[i:i + 1]) < 2e-2, i
