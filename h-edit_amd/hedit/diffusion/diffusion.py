@@ -21,6 +21,10 @@ TINY_DDPM_CONFIG = dict(type="simple", in_channels=3, out_ch=3, ch=64, ch_mult=(
 
 
 class Model:
+    # the timestep is a launch parameter: a (n,) tensor that still lives on the host is read without a device
+    # synchronisation, so callers that know t on the host (the loops do) should not move it to the GPU first
+    accepts_host_timesteps = True
+
     def __init__(self, config=None, device="cuda:0"):
         cfg = dict(CELEBA_HQ_CONFIG)
         cfg.update(config or {})

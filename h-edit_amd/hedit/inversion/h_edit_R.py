@@ -27,9 +27,12 @@ def h_Edit_R(model, lpipsloss, idloss, xT, betas, seq, eta=1.0, zs=None, weight_
     n = xt.size(0)
     gscale = float(n) if per_image else 1.0
 
+    host_t = getattr(model, "accepts_host_timesteps", False)
+
     def eps_at(x, t):
-        with torch.no_grad():
-            return model(x.detach(), (torch.ones(n) * t).to(x.device))
+        t_input = torch.ones(n) * t                 # the reference moves it to the GPU (h_edit_R.py:70); the HIP executor
+        with torch.no_grad():                       # reads it on the host, which avoids a device sync per evaluation
+            return model(x.detach(), t_input if host_t else t_input.to(x.device))
 
     for i, t in enumerate(op):
         idx = num_inference_steps - t_to_idx[int(t)] - (num_inference_steps - after_skip_steps + 1)

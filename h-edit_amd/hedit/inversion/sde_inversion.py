@@ -40,7 +40,9 @@ def inversion_forward_process_sde(model, x0, betas, seq, etas=1.0, num_inference
     n = x0.size(0)
     for i, t in enumerate(timesteps):
         idx = num_inference_steps - t_to_idx[int(t)] - 1
-        t_input = (torch.ones(n) * t).to(x0.device)
+        t_input = torch.ones(n) * t
+        if not getattr(model, "accepts_host_timesteps", False):
+            t_input = t_input.to(x0.device)
         xt = xts[idx + 1][None]
         with torch.no_grad():
             eps_t = model(xt, t_input)
