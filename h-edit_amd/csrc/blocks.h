@@ -94,7 +94,10 @@ bf16_t* lin(ParamStore* h, const std::string& name, int O, int I, bool conv1x1 =
   return d;
 }
 bf16_t* conv3(ParamStore* h, const std::string& name, int O, int I) {
-  bf16_t* d = dalloc<bf16_t>(h, (size_t)O * I * 9);
+  // at least 4 rows (zero beyond O): a conv with <= 4 output channels can then run as an N = 4 GEMM
+  const int rows = O < 4 ? 4 : O;
+  bf16_t* d = dalloc<bf16_t>(h, (size_t)rows * I * 9);
+  if (d && rows != O && hipMemset(d, 0, (size_t)rows * I * 9 * sizeof(bf16_t)) != hipSuccess) h->alloc_failed = true;
   add_slot(h, name, 2, d, (size_t)O * I * 9, O, I, 4, O, I, 3, 3);
   return d;
 }
@@ -218,6 +221,27 @@ int conv3x3(VF& f, const bf16_t* X, int Hin, int Win, int Cin, const bf16_t* W, 
   p.A = X; p.W = W; p.M = f.B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin; p.lda = Cin;
   p.bias = bias; p.residual = residual; p.ldr = Cout; p.C = Y; p.ldc = Cout;
   return run_gemm(f, p);
+}
+
+// conv3x3 (stride 1, pad 1) with Cout <= 4 output channels, fp32 NCHW result: the [*][4] fp32 products of an N = 4 MFMA
+// GEMM (weights [4][9 C], rows beyond Cout zero) + a bias / layout pass.  HEDIT_CONVOUT=valu selects the older
+// one-wave-per-pixel kernel (A/B runs); it is also the path when C is not a multiple of 64.
+int conv_out(VF& f, const bf16_t* x, int H, int W, int C, const bf16_t* w, const float* bias, int Cout, float* y) {
+  static const bool valu = [] { const char* e = getenv("HEDIT_CONVOUT"); return e && std::string(e) == "valu"; }();
+  if (valu || C % 64 != 0) {
+    RUN(f, conv_out_launch(x, w, bias, y, f.B, H, W, C, Cout, f.st));
+    return HEDIT_OK;
+  }
+  const size_t M = (size_t)f.B * H * W;
+  float* prod;
+  TRY(aalloc(f, &prod, M * 4));
+  GemmParams p{};
+  p.mode = 1; p.Hin = H; p.Win = W; p.Cin = C; p.Hout = H; p.Wout = W;
+  p.A = x; p.W = w; p.M = (int)M; p.N = 4; p.K = 9 * C; p.lda = C; p.raw_f32 = prod; p.ldc = 4;
+  TRY(run_gemm(f, p));
+  RUN(f, rows_to_nchw_launch(prod, bias, y, f.B, (long)H * W, 4, Cout, f.st));
+  f.ar.free(prod);
+  return HEDIT_OK;
 }
 
 // stats: if non-null, *stats receives a kept [B][G][2] (mean, rstd) buffer for the backward pass

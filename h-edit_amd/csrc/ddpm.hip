@@ -130,7 +130,7 @@ int forward_impl(hedit_ddpm* h, const float* x, float t, int B, float* out, void
   TRY(aalloc(f, &xn, (size_t)B * H * W * cur_ch));
   TRY(groupnorm(f, cur, xn, h->no_g, h->no_b, H * W, cur_ch, 1));
   f.ar.free(cur);
-  RUN(f, conv_out_launch(xn, h->out_w, h->out_b, out, B, H, W, cur_ch, c.out_ch, st));
+  TRY(conv_out(f, xn, H, W, cur_ch, h->out_w, h->out_b, c.out_ch, out));
   f.ar.free(xn);
   f.ar.free(temb); f.ar.free(t0); f.ar.free(emb);
   if (peak) *peak = f.ar.peak;

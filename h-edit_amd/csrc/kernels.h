@@ -59,6 +59,8 @@ int conv_in_launch(const float* x, const float* w, const float* bias, bf16_t* y,
 // conv_out: x NHWC bf16 [B][H][W][C], w bf16 [Cout<=4][9][C] -> y fp32 NCHW [B][Cout][H][W]
 int conv_out_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* y, int B, int H,
                     int W, int C, int Cout, hipStream_t st);
+// fp32 [B*HW][ld] (ld >= 4, the first Cout <= 4 columns) + bias -> fp32 NCHW [B][Cout][HW]: tail of the MFMA route of conv_out
+int rows_to_nchw_launch(const float* src, const float* bias, float* dst, int B, long HW, int ld, int Cout, hipStream_t st);
 // VAE helpers: row softmax of fp32 scores (p = softmax(scale * s), bf16), 1x1 channel mixing of a
 // small fp32 NCHW tensor (x scaled by pre_scale first), encoder tail (first Cout channels of quant_conv)
 int softmax_rows_launch(const float* s, bf16_t* p, long rows, int N, float scale, hipStream_t st);

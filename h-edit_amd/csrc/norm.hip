@@ -594,6 +594,23 @@ int conv_in_launch(const float* x, const float* w, const float* bias, bf16_t* y,
   return HEDIT_OK;
 }
 
+// fp32 products [B*HW][ld] of a small-N conv GEMM (+ bias) -> fp32 NCHW [B][Cout][HW]
+__global__ __launch_bounds__(256) void rows_to_nchw_kernel(const float* __restrict__ src, const float* __restrict__ bias,
+                                                           float* __restrict__ dst, long total, long HW, int ld, int Cout) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / HW, px = i - b * HW;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + i * ld);
+    for (int c = 0; c < Cout; ++c) dst[(b * Cout + c) * HW + px] = v[c] + (bias ? bias[c] : 0.f);
+  }
+}
+
+int rows_to_nchw_launch(const float* src, const float* bias, float* dst, int B, long HW, int ld, int Cout, hipStream_t st) {
+  ARG_CHECK(Cout >= 1 && Cout <= 4 && ld >= 4 && ld % 4 == 0, "rows_to_nchw: Cout <= 4, ld % 4");
+  hipLaunchKernelGGL(rows_to_nchw_kernel, dim3(ew_grid((long)B * HW)), dim3(256), 0, st, src, bias, dst, (long)B * HW, HW, ld, Cout);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
 int conv_out_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* y, int B, int H, int W, int C,
                     int Cout, hipStream_t st) {
   ARG_CHECK(C % 8 == 0 && Cout <= 4, "conv_out: C % 8, Cout <= 4");

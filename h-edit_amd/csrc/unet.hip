@@ -533,7 +533,22 @@ int forward_impl(hedit_unet* h, const float* x, float t, const float* ctx, int B
     bf16_t* a;
     TRY(aalloc(f, &a, (size_t)B * H * W * ch0));
     TRY(groupnorm(f, cur, a, h->gn_out_g, h->gn_out_b, H * W, ch0, 1e-5f, 1));
-    RUN(f, conv_out_launch(a, h->conv_out_w, h->conv_out_b, eps_out, B, H, W, ch0, c.out_channels, st));
+    static const bool valu = [] { const char* e = getenv("HEDIT_CONVOUT"); return e && std::string(e) == "valu"; }();
+    if (valu || c.out_channels != 4 || ch0 % 64 != 0) {
+      RUN(f, conv_out_launch(a, h->conv_out_w, h->conv_out_b, eps_out, B, H, W, ch0, c.out_channels, st));
+    } else {
+      // conv_out as an N = 4 MFMA GEMM (fp32 products) + bias / NCHW pass: the one-wave-per-pixel kernel re-reads the
+      // activation nine times (0.99 ms at 120 rows)
+      float* prod;
+      const size_t M = (size_t)B * H * W;
+      TRY(aalloc(f, &prod, M * 4));
+      GemmParams p{};
+      p.mode = 1; p.Hin = H; p.Win = W; p.Cin = ch0; p.Hout = H; p.Wout = W;
+      p.A = a; p.W = h->conv_out_w; p.M = (int)M; p.N = 4; p.K = 9 * ch0; p.lda = ch0; p.raw_f32 = prod; p.ldc = 4;
+      TRY(run_gemm(f, p));
+      RUN(f, rows_to_nchw_launch(prod, h->conv_out_b, eps_out, B, (long)H * W, 4, 4, st));
+      f.ar.free(prod);
+    }
     f.ar.free(a);
     f.ar.free(cur);
   }

@@ -151,7 +151,7 @@ int decode_forward(hedit_vae* h, DecodeTape& T, const float* z, float* image, bo
   TRY(aalloc(f, &xn, (size_t)B * H * W * ch));
   TRY(groupnorm(f, x, xn, h->d_gn_g, h->d_gn_b, H * W, ch, 1, grad ? &T.st_out : nullptr));
   if (!grad) f.ar.free(x);
-  if (image) RUN(f, conv_out_launch(xn, h->d_out_w, h->d_out_b, image, B, H, W, ch, c.in_channels, st));
+  if (image) TRY(conv_out(f, xn, H, W, ch, h->d_out_w, h->d_out_b, c.in_channels, image));
   f.ar.free(xn);
   T.x = x;
   T.H = H; T.W = W;
@@ -203,7 +203,11 @@ int decode_backward(hedit_vae* h, DecodeTape& T, const float* d_image, float* d_
   ch = c.block_out_channels[L - 1];
   float* dz2;
   TRY(aalloc(f, &dz2, (size_t)B * LC * H * W));
-  RUN(f, conv_out_launch(d, h->d_in_t, h->zero_bias, dz2, B, H, W, ch, LC, st));
+  if (LC == 4) {
+    TRY(conv_out(f, d, H, W, ch, h->d_in_t, nullptr, LC, dz2));
+  } else {
+    RUN(f, conv_out_launch(d, h->d_in_t, h->zero_bias, dz2, B, H, W, ch, LC, st));
+  }
   f.ar.free(d);
   RUN(f, mix1x1_nchw_launch(dz2, h->pq_t, nullptr, d_z, B, LC, LC, (long)H * W, 1.0f, st));
   f.ar.free(dz2);
