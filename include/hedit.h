@@ -17,6 +17,17 @@
  *                                     its two .item() syncs, and the x_{t-1} update
  *                                     (p2p_h_edit.py:654-692; twins :317-353, :494-514, :125-147)
  *   hedit_local_blend       replaces  LocalBlend.__call__/get_mask (p2p/ptp_classes.py:44-72)
+ *   hedit_p2p_plan          carries   the per-call edit rule of the registered controller / editor: Prompt-to-Prompt
+ *                                     (ptp_classes.py:194-227), MasaCtrl (masactrl/masactrl.py:53-69: kv_src) and
+ *                                     Plug-and-Play (plug_n_play/pnp_utils.py:29-154: qk_first_block, feat_src)
+ *   hedit_vae_encode/decode replaces  model.vae.encode(x).latent_dist.mode() / model.vae.decode(z).sample
+ *                                     (main_p2p.py:159,263)
+ *   hedit_vae_decode_vjp,   replace   the decoder part of torch.autograd.grad(loss, latents) in the style closure
+ *   _keep + _backward                 (text-guided-n-style/inversion/h_edit.py:146-185)
+ *   hedit_step_tweedie,     replace   reverse_step_pred_x0 and the rho-normalised style update
+ *   hedit_step_style                  (inversion_utils.py:128-140, h_edit.py:167-183)
+ *   hedit_ddpm_forward      replaces  Model.forward(x, t) of face-swapping/diffusion/diffusion.py:294-341
+ *                                     (call sites face-swapping/inversion/h_edit_R.py:71,96,118, sde_inversion.py:121)
  *   hedit_k_*               single-kernel entry points used by the parity tests
  *
  * Conventions
