@@ -44,6 +44,7 @@ int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float
 int layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, long rows,
                      int C, float eps, hipStream_t st);
 int geglu_launch(const bf16_t* x, bf16_t* y, long rows, int inner, hipStream_t st);
+// y [rows][ca+cb] = [a | b]; a == nullptr: the left part is already in place, only b is copied
 int concat_launch(const bf16_t* a, int ca, const bf16_t* b, int cb, bf16_t* y, long rows, hipStream_t st);
 int f32_to_bf16_launch(const float* x, bf16_t* y, long n, hipStream_t st);
 int ctx_pad_launch(const float* x, bf16_t* y, int B, int dim, hipStream_t st);

@@ -255,6 +255,18 @@ __global__ __launch_bounds__(256) void geglu_kernel(const bf16_t* __restrict__ x
   }
 }
 
+// a == nullptr: the left ca columns of y are already in place (their producer wrote them with ldc = ca + cb);
+// only b is copied into columns [ca, ca + cb)
+__global__ __launch_bounds__(256) void concat_right_kernel(const bf16_t* __restrict__ b, int ca, int cb, bf16_t* __restrict__ y, long rows) {
+  const int BV = cb / 8;
+  const long total = rows * BV;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / BV;
+    const int v = (int)(i - row * BV);
+    *reinterpret_cast<uint4*>(y + row * (ca + cb) + ca + v * 8) = *reinterpret_cast<const uint4*>(b + row * cb + v * 8);
+  }
+}
+
 __global__ __launch_bounds__(256) void concat_kernel(const bf16_t* __restrict__ a, int ca, const bf16_t* __restrict__ b, int cb,
                                                      bf16_t* __restrict__ y, long rows) {
   const int CV = (ca + cb) / 8, AV = ca / 8;
@@ -501,6 +513,11 @@ int geglu_launch(const bf16_t* x, bf16_t* y, long rows, int inner, hipStream_t s
 
 int concat_launch(const bf16_t* a, int ca, const bf16_t* b, int cb, bf16_t* y, long rows, hipStream_t st) {
   ARG_CHECK(ca % 8 == 0 && cb % 8 == 0, "concat: channels % 8");
+  if (a == nullptr) {
+    hipLaunchKernelGGL(concat_right_kernel, dim3(ew_grid(rows * (cb / 8))), dim3(256), 0, st, b, ca, cb, y, rows);
+    LAUNCH_CHECK();
+    return HEDIT_OK;
+  }
   hipLaunchKernelGGL(concat_kernel, dim3(ew_grid(rows * ((ca + cb) / 8))), dim3(256), 0, st, a, ca, b, cb, y, rows);
   LAUNCH_CHECK();
   return HEDIT_OK;

@@ -252,14 +252,14 @@ int linear(Fwd& f, const bf16_t* A, int M, int K, const bf16_t* W, int N, const 
 }
 
 int conv3x3(Fwd& f, const bf16_t* X, int Hin, int Win, int Cin, const bf16_t* W, int Cout, const float* bias,
-            const bf16_t* residual, bf16_t* Y, int mode) {
+            const bf16_t* residual, bf16_t* Y, int mode, int ldy = 0) {
   GemmParams p{};
   p.mode = mode;
   p.Hin = Hin; p.Win = Win; p.Cin = Cin;
   p.Hout = mode == 2 ? Hin / 2 : (mode == 3 ? Hin * 2 : Hin);
   p.Wout = mode == 2 ? Win / 2 : (mode == 3 ? Win * 2 : Win);
   p.A = X; p.W = W; p.M = f.B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin; p.lda = Cin;
-  p.bias = bias; p.residual = residual; p.ldr = Cout; p.C = Y; p.ldc = Cout;
+  p.bias = bias; p.residual = residual; p.ldr = Cout; p.C = Y; p.ldc = ldy ? ldy : Cout;
   return run_gemm(f, p);
 }
 
@@ -275,7 +275,9 @@ int groupnorm(Fwd& f, const bf16_t* x, bf16_t* y, const float* g, const float* b
 }
 
 // x [M][cin] -> *out [M][cout] (allocated here; x is NOT freed)
-int resblock(Fwd& f, const Res& r, const bf16_t* x, int H, int W, bf16_t** out) {
+// dst / ldd: write the result into an existing buffer with row stride ldd (the left columns of the next
+// skip concatenation) instead of allocating a contiguous [M][cout] one
+int resblock(Fwd& f, const Res& r, const bf16_t* x, int H, int W, bf16_t** out, bf16_t* dst = nullptr, int ldd = 0) {
   const size_t M = (size_t)f.B * H * W;
   bf16_t *a1, *h1, *a2, *sc = nullptr, *y;
   TRY(aalloc(f, &a1, M * r.cin));
@@ -297,8 +299,12 @@ int resblock(Fwd& f, const Res& r, const bf16_t* x, int H, int W, bf16_t** out) 
     if (pl && pl->feat_src && f.rblock == pl->feat_resblock) RUN(f, copy_rows_launch(a2, pl->feat_src, f.B, (long)H * W * r.cout, f.st));
     ++f.rblock;
   }
-  TRY(aalloc(f, &y, M * r.cout));
-  TRY(conv3x3(f, a2, H, W, r.cout, r.conv2, r.cout, r.conv2_b, res, y, 1));
+  if (dst) {
+    y = dst;
+  } else {
+    TRY(aalloc(f, &y, M * r.cout));
+  }
+  TRY(conv3x3(f, a2, H, W, r.cout, r.conv2, r.cout, r.conv2_b, res, y, 1, dst ? ldd : 0));
   f.ar.free(a2);
   if (sc) f.ar.free(sc);
   *out = y;
@@ -306,7 +312,7 @@ int resblock(Fwd& f, const Res& r, const bf16_t* x, int H, int W, bf16_t** out) 
 }
 
 // x [M][C] -> *out [M][C] (allocated here; x is NOT freed)
-int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** out) {
+int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** out, bf16_t* dst = nullptr, int ldd = 0) {
   const int C = a.C, N = H * W, B = f.B, heads = f.h->cfg.heads, d = C / heads;
   const int ctx_dim = f.h->cfg.cross_attention_dim;
   const size_t M = (size_t)B * N;
@@ -400,8 +406,12 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   f.ar.free(gf);
   f.ar.free(t2);
 
-  TRY(aalloc(f, &y, M * C));
-  TRY(linear(f, t3, (int)M, C, a.pout, C, a.pout_b, x, y, C));
+  if (dst) {
+    y = dst;
+  } else {
+    TRY(aalloc(f, &y, M * C));
+  }
+  TRY(linear(f, t3, (int)M, C, a.pout, C, a.pout_b, x, y, dst ? ldd : C));
   f.ar.free(t3);
   *out = y;
   return HEDIT_OK;
@@ -494,7 +504,11 @@ int forward_impl(hedit_unet* h, const float* x, float t, const float* ctx, int B
   }
   int cur_c = c.block_out_channels[c.n_levels - 1];
 
-  // ---- up path
+  // ---- up path.  Every concatenation [cur | skip] is laid out before its left half is produced: the block that
+  // computes `cur` (ResNet conv2, transformer proj_out or the upsampling conv) writes it straight into the left
+  // columns of the next concatenation buffer (row stride = its full width), so only the skip half is copied.
+  bool in_cat = false;         // cur already sits in `cat_next`
+  bf16_t* cat_next = nullptr;
   for (int i = 0; i < c.n_levels; ++i) {
     Block& blk = h->up[i];
     for (size_t j = 0; j < blk.res.size(); ++j) {
@@ -502,29 +516,53 @@ int forward_impl(hedit_unet* h, const float* x, float t, const float* ctx, int B
       skips.pop_back();
       bf16_t* cat;
       const size_t M = (size_t)B * H * W;
-      TRY(aalloc(f, &cat, M * (cur_c + s.C)));
-      { ProfScope ps(f, PK_OTHER, 0.0); RUN(f, concat_launch(cur, cur_c, s.p, s.C, cat, (long)M, st)); }
-      f.ar.free(cur);
-      f.ar.free(s.p);
-      bf16_t* y;
-      TRY(resblock(f, blk.res[j], cat, H, W, &y));
-      f.ar.free(cat);
-      cur = y;
-      cur_c = blk.ch;
-      if (blk.has_attn) {
-        bf16_t* z;
-        TRY(transformer(f, blk.attn[j], cur, H, W, &z));
+      if (in_cat) {
+        cat = cat_next;
+        { ProfScope ps(f, PK_OTHER, 0.0); RUN(f, concat_launch(nullptr, cur_c, s.p, s.C, cat, (long)M, st)); }
+      } else {
+        TRY(aalloc(f, &cat, M * (cur_c + s.C)));
+        { ProfScope ps(f, PK_OTHER, 0.0); RUN(f, concat_launch(cur, cur_c, s.p, s.C, cat, (long)M, st)); }
         f.ar.free(cur);
-        cur = z;
       }
+      f.ar.free(s.p);
+      // where does this block's output go next?
+      const bool last_res = j + 1 == blk.res.size();
+      const bool to_cat = !last_res;                      // next consumer is the next ResNet block of this level
+      bf16_t* dst = nullptr;
+      int ldd = 0;
+      if (to_cat) {
+        ldd = blk.ch + skips.back().C;
+        TRY(aalloc(f, &dst, M * ldd));
+      }
+      bf16_t* y;
+      if (blk.has_attn) {
+        TRY(resblock(f, blk.res[j], cat, H, W, &y));
+        f.ar.free(cat);
+        bf16_t* z;
+        TRY(transformer(f, blk.attn[j], y, H, W, &z, dst, ldd));
+        f.ar.free(y);
+        cur = z;
+      } else {
+        TRY(resblock(f, blk.res[j], cat, H, W, &y, dst, ldd));
+        f.ar.free(cat);
+        cur = y;
+      }
+      cur_c = blk.ch;
+      in_cat = to_cat;
+      cat_next = dst;
     }
     if (blk.has_sampler) {
-      bf16_t* y;
-      TRY(aalloc(f, &y, (size_t)B * (H * 2) * (W * 2) * blk.ch));
-      TRY(conv3x3(f, cur, H, W, blk.ch, blk.samp_w, blk.ch, blk.samp_b, nullptr, y, 3));
+      // the upsampled tensor is the left half of the next level's first concatenation
+      const size_t M4 = (size_t)B * H * W * 4;
+      const int ldd = blk.ch + skips.back().C;
+      bf16_t* dst;
+      TRY(aalloc(f, &dst, M4 * ldd));
+      TRY(conv3x3(f, cur, H, W, blk.ch, blk.samp_w, blk.ch, blk.samp_b, nullptr, dst, 3, ldd));
       f.ar.free(cur);
       H *= 2; W *= 2;
-      cur = y;
+      cur = dst;
+      in_cat = true;
+      cat_next = dst;
     }
   }
 
