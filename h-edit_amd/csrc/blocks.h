@@ -211,7 +211,7 @@ int linear(VF& f, const bf16_t* A, int M, int K, const bf16_t* W, int N, const f
 
 // mode 1: stride 1; 2: stride 2 with pad (0,1,0,1); 3: on the 2x nearest-upsampled input
 int conv3x3(VF& f, const bf16_t* X, int Hin, int Win, int Cin, const bf16_t* W, int Cout, const float* bias,
-            const bf16_t* residual, bf16_t* Y, int mode) {
+            const bf16_t* residual, bf16_t* Y, int mode, int ldy = 0) {
   GemmParams p{};
   p.mode = mode;
   p.asym = mode == 2 ? 1 : 0;
@@ -219,7 +219,7 @@ int conv3x3(VF& f, const bf16_t* X, int Hin, int Win, int Cin, const bf16_t* W, 
   p.Hout = mode == 2 ? Hin / 2 : (mode == 3 ? Hin * 2 : Hin);
   p.Wout = mode == 2 ? Win / 2 : (mode == 3 ? Win * 2 : Win);
   p.A = X; p.W = W; p.M = f.B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin; p.lda = Cin;
-  p.bias = bias; p.residual = residual; p.ldr = Cout; p.C = Y; p.ldc = Cout;
+  p.bias = bias; p.residual = residual; p.ldr = Cout; p.C = Y; p.ldc = ldy ? ldy : Cout;
   return run_gemm(f, p);
 }
 
@@ -277,8 +277,10 @@ struct AttnRec {
 // x [M][cin] -> *out [M][cout] (allocated here; x is NOT freed)
 // temb: the network's timestep embedding (fp32 [temb_ch], shared by the batch) for blocks with temb_proj:
 // h = conv1(.) + conv1.bias + temb_proj(silu(temb)), folded into the conv's epilogue bias
+// dst / ldd: write the result into an existing buffer with row stride ldd (the left columns of the next skip
+// concatenation) instead of allocating a contiguous [M][cout] one
 int resblock(VF& f, const VRes& r, const bf16_t* x, int H, int W, bf16_t** out, ResRec* rec = nullptr,
-             const float* temb = nullptr) {
+             const float* temb = nullptr, bf16_t* dst = nullptr, int ldd = 0) {
   const size_t M = (size_t)f.B * H * W;
   bf16_t *a1, *h1, *a2, *sc = nullptr, *y;
   float* bias1 = r.c1b;
@@ -312,8 +314,12 @@ int resblock(VF& f, const VRes& r, const bf16_t* x, int H, int W, bf16_t** out, 
     TRY(linear(f, x, (int)M, r.cin, r.sc_w, r.cout, r.sc_b, nullptr, sc, r.cout));
     res = sc;
   }
-  TRY(aalloc(f, &y, M * r.cout));
-  TRY(conv3x3(f, a2, H, W, r.cout, r.conv2, r.cout, r.c2b, res, y, 1));
+  if (dst) {
+    y = dst;
+  } else {
+    TRY(aalloc(f, &y, M * r.cout));
+  }
+  TRY(conv3x3(f, a2, H, W, r.cout, r.conv2, r.cout, r.c2b, res, y, 1, dst ? ldd : 0));
   f.ar.free(a2);
   if (sc) f.ar.free(sc);
   *out = y;
@@ -321,7 +327,8 @@ int resblock(VF& f, const VRes& r, const bf16_t* x, int H, int W, bf16_t** out, 
 }
 
 // single-head attention over the T = H*W tokens of every image; x [B*T][C] -> *out (x is NOT freed)
-int attention(VF& f, const VAttn& a, const bf16_t* x, int H, int W, bf16_t** out, AttnRec* rec = nullptr) {
+int attention(VF& f, const VAttn& a, const bf16_t* x, int H, int W, bf16_t** out, AttnRec* rec = nullptr,
+              bf16_t* dst = nullptr, int ldd = 0) {
   const int C = a.C, T = H * W, B = f.B;
   const size_t M = (size_t)B * T;
   bf16_t *xn, *q, *k, *vt, *pb, *o, *y;
@@ -377,8 +384,12 @@ int attention(VF& f, const VAttn& a, const bf16_t* x, int H, int W, bf16_t** out
   // output bias with the value bias folded in: o_b' = o_b + W_o . v_b
   TRY(aalloc(f, &ob, (size_t)C));
   RUN(f, gemv_launch(a.w_o, a.v_b, a.o_b, nullptr, ob, C, C, 0, f.st));
-  TRY(aalloc(f, &y, M * C));
-  TRY(linear(f, o, (int)M, C, a.w_o, C, ob, x, y, C));
+  if (dst) {
+    y = dst;
+  } else {
+    TRY(aalloc(f, &y, M * C));
+  }
+  TRY(linear(f, o, (int)M, C, a.w_o, C, ob, x, y, dst ? ldd : C));
   f.ar.free(ob); f.ar.free(o);
   *out = y;
   return HEDIT_OK;

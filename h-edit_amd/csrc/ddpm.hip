@@ -94,7 +94,9 @@ int forward_impl(hedit_ddpm* h, const float* x, float t, int B, float* out, void
   f.ar.free(m1);
   TRY(resblock(f, h->mid2, m2, H, W, &cur, nullptr, temb));
   f.ar.free(m2);
-  // up path
+  // up path.  As in unet.hip, the block that produces `cur` writes it straight into the left columns of the next
+  // concatenation buffer; only the skip half is copied.
+  bool in_cat = false;
   for (int i = L - 1; i >= 0; --i) {
     const DLevel& lv = h->up[i];
     for (int j = 0; j < nrb + 1; ++j) {
@@ -102,28 +104,46 @@ int forward_impl(hedit_ddpm* h, const float* x, float t, int B, float* out, void
       hs.pop_back();
       bf16_t *cat, *y;
       const size_t M = (size_t)B * H * W;
-      TRY(aalloc(f, &cat, M * (cur_ch + s.ch)));
-      RUN(f, concat_launch(cur, cur_ch, s.p, s.ch, cat, (long)M, st));
-      f.ar.free(cur);
+      if (in_cat) {
+        cat = cur;
+        RUN(f, concat_launch(nullptr, cur_ch, s.p, s.ch, cat, (long)M, st));
+      } else {
+        TRY(aalloc(f, &cat, M * (cur_ch + s.ch)));
+        RUN(f, concat_launch(cur, cur_ch, s.p, s.ch, cat, (long)M, st));
+        f.ar.free(cur);
+      }
       f.ar.free(s.p);
-      TRY(resblock(f, lv.block[j], cat, H, W, &y, nullptr, temb));
-      f.ar.free(cat);
+      const bool to_cat = j < nrb;          // the next consumer is the next block of this level
+      bf16_t* dst = nullptr;
+      int ldd = 0;
+      if (to_cat) {
+        ldd = lv.ch + hs.back().ch;
+        TRY(aalloc(f, &dst, M * ldd));
+      }
       if (!lv.attn.empty()) {
+        TRY(resblock(f, lv.block[j], cat, H, W, &y, nullptr, temb));
+        f.ar.free(cat);
         bf16_t* a;
-        TRY(attention(f, lv.attn[j], y, H, W, &a));
+        TRY(attention(f, lv.attn[j], y, H, W, &a, nullptr, dst, ldd));
         f.ar.free(y);
         y = a;
+      } else {
+        TRY(resblock(f, lv.block[j], cat, H, W, &y, nullptr, temb, dst, ldd));
+        f.ar.free(cat);
       }
       cur = y;
       cur_ch = lv.ch;
+      in_cat = to_cat;
     }
     if (lv.samp_w) {
+      const int ldd = cur_ch + hs.back().ch;     // left half of the next level's first concatenation
       bf16_t* y;
-      TRY(aalloc(f, &y, (size_t)B * H * W * 4 * cur_ch));
-      TRY(conv3x3(f, cur, H, W, cur_ch, lv.samp_w, cur_ch, lv.samp_b, nullptr, y, 3));
+      TRY(aalloc(f, &y, (size_t)B * H * W * 4 * ldd));
+      TRY(conv3x3(f, cur, H, W, cur_ch, lv.samp_w, cur_ch, lv.samp_b, nullptr, y, 3, ldd));
       f.ar.free(cur);
       cur = y;
       H *= 2; W *= 2;
+      in_cat = true;
     }
   }
   bf16_t* xn;
