@@ -1,7 +1,7 @@
 """Diagnostic (not a test): error growth of the HIP loop vs the oracle loop for several output
 scales of the synthetic network and chain lengths."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "h-edit_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch

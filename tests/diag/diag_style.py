@@ -2,7 +2,7 @@
 tolerances in tests/test_gpu_style.py are derived from."""
 import copy, os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "h-edit_amd")):
     sys.path.insert(0, p)
 import test_gpu_style as TS

@@ -13,7 +13,7 @@ from hedit.unet import TINY_CONFIG  # noqa: E402
 
 T = 8
 # Tolerances (relative L2 of the final latents, HIP bf16 path vs fp32 oracle).  Measured on MI355X
-# with this synthetic network (tools/diag_loops.py, output scale 0.3): one eps evaluation 1.4e-2;
+# with this synthetic network (tests/diag/diag_loops.py, output scale 0.3): one eps evaluation 1.4e-2;
 # 1-step chain 5e-4 (K=1) / 9e-3 (K=2); 4-step chain 2.1e-2 / 3.2e-2 edited, 3e-3 recon;
 # 8-step chain 7e-2 edited, 1.9e-2 recon.  Error grows with chain length because every step
 # re-injects the bf16 rounding of the eps evaluations; limits below are ~2.5x the measurements.

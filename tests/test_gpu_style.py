@@ -76,12 +76,12 @@ def test_style_step_matches_oracle(setup):
     got = HEditEngine(hip).style_step(G.f32(e_u), G.f32(e_cs), G.f32(e_u), G.f32(e_ct), G.f32(x), tt, cfg, enc_g, 0.5)
     G.sync()
     # the update is x - rho g with |rho g| = 0.5 rms(correction): compare the step itself
-    # measured 1.0e-2 (tools/diag_style.py): bf16 decoder forward + backward vs fp32 autograd
+    # measured 1.0e-2 (tests/diag/diag_style.py): bf16 decoder forward + backward vs fp32 autograd
     assert G.rel_err(got - G.f32(x), want - x) < 3e-2
     assert G.rel_err(got, want) < 3e-2
 
 
-# Tolerances: relative L2 of the final latents.  Measured (tools/diag_style.py, three boxes): 4 steps K=1
+# Tolerances: relative L2 of the final latents.  Measured (tests/diag/diag_style.py, three boxes): 4 steps K=1
 # 3.0-3.1e-2 (text only: 2.1e-2); 4 steps K=2 6.3e-2 .. 1.2e-1; 8 steps 5.7-6.1e-2, recon 2.1e-2.  The style
 # update renormalises the gradient to a fixed step length, so differences in its direction are not damped
 # and the K=2 chain shows run-to-run spread (torch's bicubic / conv backward inside the toy encoder use

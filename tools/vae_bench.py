@@ -7,7 +7,7 @@ from hedit.vae import AutoencoderKL
 dev = "cuda:0"
 vae = AutoencoderKL(device=dev)
 vae.init_random(0)
-DEC_MACS = 1.2575e12   # decoder MACs per image at a 64x64 latent (oracle/sd_vae.py count)
+DEC_MACS = 1.2575e12   # decoder MACs per image at a 64x64 latent (counted on the CPU restatement)
 for B in (1, 2, 4, 8):
     z = torch.randn(B, 4, 64, 64, device=dev)
     u = torch.randn(B, 3, 512, 512, device=dev)
