@@ -160,3 +160,42 @@ def test_style_step_batched_encoder_equals_per_image(setup):
     assert G.rel_err(a - x, b - x) < 5e-3
     assert G.rel_err(a - x, c - x) < 5e-3
     assert G.rel_err(a, x) > 1e-2
+
+
+def test_batched_style_engine_equals_single_images(setup):
+    """two images in lock-step (ControllerBatch, one style encoder per image) == two single-image runs of the text + style
+    loop: the decoder tape, the per-image rho normalisation and the per-image losses do not mix images"""
+    from hedit.engine import HEditEngine
+    from hedit.p2p import ptp_controller_utils as PCU
+    from hedit.p2p.ptp_classes import ControllerBatch
+    from hedit.p2p.ptp_utils import register_attention_control
+    hip, _, inv, _, enc_g = setup
+    eng = HEditEngine(hip)
+    A = 4
+
+    def ctrl(pi):
+        src, tar, _, is_replace = PROMPT_PAIRS[pi]
+        return PCU.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=None, equilizer_params=None, num_steps=A,
+                                   tokenizer=hip.tokenizer, device=hip.device)
+    enc2 = copy.deepcopy(enc_g)
+    with torch.no_grad():
+        enc2.ref.mul_(-0.5)                               # a different style reference for the second image
+    encs = [enc_g, enc2]
+    singles = []
+    for k, pi in enumerate((0, 2)):
+        c = ctrl(pi)
+        register_attention_control(hip, c)
+        zs, wts = inv[pi]
+        singles.append(eng.run(G.f32(wts[A][None]), G.f32(zs[:A, None]), [list(PROMPT_PAIRS[pi][:2])], [1.0, 5.0, 7.5], c,
+                               after_skip_steps=A, style=(encs[k], 0.5)))
+    cb = ControllerBatch([ctrl(0), ctrl(2)])
+    register_attention_control(hip, cb)
+    xT = torch.stack([inv[0][1][A], inv[2][1][A]])
+    zs = torch.stack([inv[0][0][:A], inv[2][0][:A]], dim=1)
+    e, r = eng.run(G.f32(xT), G.f32(zs), [list(PROMPT_PAIRS[0][:2]), list(PROMPT_PAIRS[2][:2])], [1.0, 5.0, 7.5], cb,
+                   after_skip_steps=A, style=(encs, 0.5))
+    G.sync()
+    for i in range(2):
+        assert G.rel_err(e[i], singles[i][0][0]) < 8e-2       # batch-size dependent tilings, bf16 rounding only
+        assert G.rel_err(r[i], singles[i][1][0]) < 1e-2
+    assert G.rel_err(e[0], e[1]) > 1e-1
