@@ -144,3 +144,26 @@ def test_unet_batch_grouping_of_the_attention_is_transparent(tiny):
     assert torch.isfinite(big).all()
     for i in (0, 7, 15, 16, 19):
         assert G.rel_err(big[i:i + 1], parts[i:i + 1]) < 2e-2, i
+
+
+def test_lockstep_faces_equal_single_runs():
+    """h_Edit_R(per_image=True) on two faces at once (xT (2,3,S,S), zs (T,2,3,S,S)) == two single-face runs: the batch-mean
+    losses are rescaled so that every face receives its own full gradient"""
+    from hedit.diffusion import TINY_DDPM_CONFIG
+    from hedit.inversion.h_edit_R import h_Edit_R
+    hip, _ = make_pair(TINY_DDPM_CONFIG, seed=2, out_scale=0.3)
+    dev = G.dev()
+    T = 6
+    seq = (np.arange(0, 1000, 1000 // T) + 1)[::-1][:T]
+    betas = linear_betas().to(dev)
+    xT = (hash_normal((2, 3, 32, 32), 5) * 0.9).to(dev)
+    zs = (hash_normal((T, 2, 3, 32, 32), 6)).to(dev)
+    import copy
+    idl, lp = copy.deepcopy(TinyIdLoss()).to(dev), copy.deepcopy(TinyLpips()).to(dev)
+    kw = dict(eta=1.0, weight_edit_face=4.0, optimization_steps=2, after_skip_steps=T, num_inference_steps=T)
+    both = h_Edit_R(hip, lp, idl, xT, betas, seq, zs=zs, per_image=True, **kw)
+    for i in range(2):
+        one = h_Edit_R(hip, lp, idl, xT[i:i + 1], betas, seq, zs=zs[:, i:i + 1], **kw)
+        G.sync()
+        assert G.rel_err(both[i:i + 1], one) < 3e-2, i
+    assert G.rel_err(both[0], both[1]) > 1e-1
