@@ -192,8 +192,16 @@ int aalloc(VF& f, T** out, size_t n) {
   return HEDIT_OK;
 }
 
-int run_gemm(VF& f, GemmParams p) {
-  const int splits = p.raw_f32 ? 1 : gemm_pick_splits(p.M, p.N, p.K, 0);
+// batch_in: which extent carries the batch (1 = M, 2 = N, 0 = neither); the K-chunking comes from the per-image
+// extent times a fixed nominal batch (gemm_canonical_chunk), so results do not depend on the batch size
+int run_gemm(VF& f, GemmParams p, int batch_in = 1, int batch = 0) {
+  if (batch <= 0) batch = f.B;
+  if (!p.raw_f32 && batch_in >= 0) {
+    const int mn = batch_in == 1 ? p.M / batch * GEMM_NOMINAL_BATCH : p.M;
+    const int nn = batch_in == 2 ? p.N / batch * GEMM_NOMINAL_BATCH : p.N;
+    p.chunk_kt = gemm_canonical_chunk(mn, nn, p.K);
+  }
+  const int splits = gemm_plan_splits(p.M, p.N, p.K, p.chunk_kt);
   float* part = nullptr;
   if (splits > 1) TRY(aalloc(f, &part, (size_t)splits * p.M * p.N));
   RUN(f, gemm_launch(p, splits, part, f.st));
@@ -356,7 +364,7 @@ int attention(VF& f, const VAttn& a, const bf16_t* x, int H, int W, bf16_t** out
     {   // V^T [C][TG] = W_v . xn_b^T
       GemmParams p{};
       p.A = a.w_v; p.W = xb; p.M = C; p.N = TG; p.K = C; p.lda = C; p.C = vt; p.ldc = TG;
-      TRY(run_gemm(f, p));
+      TRY(run_gemm(f, p, 2, g));
     }
     {   // S [TG][TG] = q_b . k_b^T in fp32
       GemmParams p{};
@@ -372,7 +380,9 @@ int attention(VF& f, const VAttn& a, const bf16_t* x, int H, int W, bf16_t** out
     {   // O_b [TG][C] = P . V
       GemmParams p{};
       p.A = pb; p.W = vt; p.M = TG; p.N = C; p.K = TG; p.lda = TG; p.C = o + (size_t)b * T * C; p.ldc = C;
-      TRY(run_gemm(f, p));
+      // one plain chain over the stacked keys: the other images' probabilities are exact zeros, so an image's
+      // result is the chain over its own keys whatever else is stacked beside it
+      TRY(run_gemm(f, p, -1));
     }
   }
   f.ar.free(pb); f.ar.free(s); f.ar.free(vt);
@@ -460,29 +470,29 @@ int attention_bwd(VF& f, const AttnRec& rec, const bf16_t* dy, bf16_t** dx_out) 
     const size_t o = (size_t)b * T * C;
     GemmParams p{};
     p.A = rec.q + o; p.W = rec.k + o; p.M = T; p.N = T; p.K = C; p.lda = C; p.raw_f32 = s; p.ldc = T;
-    TRY(run_gemm(f, p));
+    TRY(run_gemm(f, p, 0));
     RUN(f, softmax_rows_launch(s, pb, T, T, scale, f.st));
     p = GemmParams{};   // dP = dO V^T
     p.A = dO + o; p.W = v + o; p.M = T; p.N = T; p.K = C; p.lda = C; p.raw_f32 = dp; p.ldc = T;
-    TRY(run_gemm(f, p));
+    TRY(run_gemm(f, p, 0));
     RUN(f, softmax_bwd_launch(pb, dp, ds, T, T, scale, f.st));
     // dV = P^T dO
     RUN(f, transpose_bf16_launch(pb, tt, T, T, f.st));
     RUN(f, transpose_bf16_launch(dO + o, ct, T, C, f.st));
     p = GemmParams{};
     p.A = tt; p.W = ct; p.M = T; p.N = C; p.K = T; p.lda = T; p.C = dv + o; p.ldc = C;
-    TRY(run_gemm(f, p));
+    TRY(run_gemm(f, p, 0));
     // dQ = dS K
     RUN(f, transpose_bf16_launch(rec.k + o, ct, T, C, f.st));
     p = GemmParams{};
     p.A = ds; p.W = ct; p.M = T; p.N = C; p.K = T; p.lda = T; p.C = dq + o; p.ldc = C;
-    TRY(run_gemm(f, p));
+    TRY(run_gemm(f, p, 0));
     // dK = dS^T Q
     RUN(f, transpose_bf16_launch(ds, tt, T, T, f.st));
     RUN(f, transpose_bf16_launch(rec.q + o, ct, T, C, f.st));
     p = GemmParams{};
     p.A = tt; p.W = ct; p.M = T; p.N = C; p.K = T; p.lda = T; p.C = dk + o; p.ldc = C;
-    TRY(run_gemm(f, p));
+    TRY(run_gemm(f, p, 0));
   }
   f.ar.free(ct); f.ar.free(tt); f.ar.free(ds); f.ar.free(pb); f.ar.free(dp); f.ar.free(s);
   f.ar.free(v); f.ar.free(dO);

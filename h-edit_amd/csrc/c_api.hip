@@ -1,11 +1,31 @@
 // C-ABI glue: error reporting, sampler-step entry points and the single-kernel entry points the
 // parity tests call (see include/hedit.h).
 #include "../../include/hedit.h"
+#include <exception>
+#include <new>
+
 #include "common.h"
 #include "kernels.h"
 
 static thread_local std::string g_last_error;
 void hedit_set_error(const std::string& msg) { g_last_error = msg; }
+
+int hedit_abi_catch() noexcept {
+  try {
+    try {
+      throw;
+    } catch (const std::bad_alloc&) {
+      g_last_error = "out of host memory inside libhedit_hip";
+    } catch (const std::exception& e) {
+      g_last_error = std::string("C++ exception inside libhedit_hip: ") + e.what();
+    } catch (...) {
+      g_last_error = "unknown C++ exception inside libhedit_hip";
+    }
+  } catch (...) {
+    // even the message could not be stored; the code alone reports the failure
+  }
+  return HEDIT_ERR_STATE;
+}
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline StepCoef to_coef(const hedit_step_coef* c) {
@@ -22,48 +42,58 @@ const char* hedit_last_error(void) { return g_last_error.c_str(); }
 int hedit_version(void) { return 1; }
 
 int hedit_step_base(const float* eps, const float* xt, const float* z, float* x_prev, int n_img, int elems,
-                    int eps_rows_per_img, const hedit_step_coef* c, void* stream) {
+                    int eps_rows_per_img, const hedit_step_coef* c, void* stream) try {
   ARG_CHECK(eps && xt && x_prev && c && n_img > 0 && elems > 0, "step_base args");
   return step_base_launch(eps, xt, z, x_prev, n_img, elems, eps_rows_per_img, to_coef(c), S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
+
+int hedit_step_invert(const float* e_u, const float* e_c, const float* xt, float* x_prev, float* z_out, int n_img,
+                      int elems, const hedit_step_coef* c, void* stream) try {
+  ARG_CHECK(e_u && e_c && xt && x_prev && z_out && c && n_img > 0 && elems > 0, "step_invert args");
+  return step_invert_launch(e_u, e_c, xt, x_prev, z_out, n_img, elems, to_coef(c), S(stream));
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_step_update(const float* e_u_src, const float* e_c_src, const float* e_u_tar, const float* e_c_tar,
                       int64_t stride_img, const float* x_k, const float* x_base, float* x_out, int n_img,
-                      int elems, int k_gt0, const hedit_step_coef* c, void* stream) {
+                      int elems, int k_gt0, const hedit_step_coef* c, void* stream) try {
   ARG_CHECK(e_u_src && e_c_src && e_u_tar && e_c_tar && x_k && x_base && x_out && c, "step_update args");
   return step_update_launch(e_u_src, e_c_src, e_u_tar, e_c_tar, (long)stride_img, x_k, x_base, x_out, n_img,
                             elems, k_gt0, to_coef(c), S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_step_tweedie(const float* e_u_tar, const float* e_c_tar, int64_t stride_img, const float* x, float* z0,
-                       int n_img, int elems, float w_tar, float sqrt_ab, float sqrt_1m_ab, float inv_scale, void* stream) {
+                       int n_img, int elems, float w_tar, float sqrt_ab, float sqrt_1m_ab, float inv_scale, void* stream) try {
   ARG_CHECK(e_u_tar && e_c_tar && x && z0 && sqrt_ab > 0.f, "step_tweedie args");
   return step_tweedie_launch(e_u_tar, e_c_tar, (long)stride_img, x, z0, n_img, elems, w_tar, sqrt_ab, sqrt_1m_ab, inv_scale,
                              S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_step_style(const float* e_u_src, const float* e_c_src, const float* e_u_tar, const float* e_c_tar,
                      int64_t stride_img, const float* x, const float* g_z, float* x_out, int n_img, int elems, float w_hat,
-                     float w_tar, float chain, float weight, void* stream) {
+                     float w_tar, float chain, float weight, void* stream) try {
   ARG_CHECK(e_u_src && e_c_src && e_u_tar && e_c_tar && x && g_z && x_out, "step_style args");
   return step_style_launch(e_u_src, e_c_src, e_u_tar, e_c_tar, (long)stride_img, x, g_z, x_out, n_img, elems, w_hat, w_tar,
                            chain, weight, S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_local_blend(float* const* h_maps, int n_maps, int heads, const float* alpha_layers,
-                      const int32_t* enabled, float* xt, int n_img, int C, int H, int W, float th, void* stream) {
+                      const int32_t* enabled, float* xt, int n_img, int C, int H, int W, float th, void* stream) try {
   ARG_CHECK(h_maps && alpha_layers && xt, "local_blend args");
   return local_blend_launch(const_cast<const float* const*>(h_maps), n_maps, heads, alpha_layers, enabled, xt, n_img, C, H, W, th, S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
-size_t hedit_k_gemm_ws_bytes(int M, int N, int K, int splits) {
+size_t hedit_k_gemm_ws_bytes(int M, int N, int K, int splits) try {
   const int s = gemm_pick_splits(M, N, K, splits);
   return gemm_partial_bytes(M, N, s);
-}
+} catch (...) { (void)hedit_abi_catch(); return 0; }
+
+/* the canonical (batch-independent) chunking of a layer and the slab count a launch of the actual shape uses */
+int hedit_k_gemm_canonical_chunk(int M_nominal, int N_nominal, int K) { return gemm_canonical_chunk(M_nominal, N_nominal, K); }
+int hedit_k_gemm_plan_splits(int M, int N, int K, int chunk_kt) { return gemm_plan_splits(M, N, K, chunk_kt); }
 
 int hedit_k_gemm(const void* A, const void* W, const float* bias, const void* residual, void* C, int M, int N,
                  int K, int lda, int ldc, int ldr, int mode, int Hin, int Win, int Cin, int Hout, int Wout,
-                 int splits, void* partial_ws, void* stream) {
+                 int splits, void* partial_ws, void* stream) try {
   ARG_CHECK(A && W && C, "gemm args");
   GemmParams p{};
   p.A = reinterpret_cast<const bf16_t*>(A);
@@ -75,21 +105,28 @@ int hedit_k_gemm(const void* A, const void* W, const float* bias, const void* re
   p.ldr = ldr;
   p.C = reinterpret_cast<bf16_t*>(C);
   p.ldc = ldc;
+  if (splits < 0) {
+    // the same chunking as `-splits` slabs, folded in registers by one launch (bit-identical by construction)
+    const int kt = K / 64;
+    const int s = gemm_pick_splits(M, N, K, -splits);
+    p.chunk_kt = (kt + s - 1) / s;
+    return gemm_launch(p, 1, nullptr, S(stream));
+  }
   const int s = gemm_pick_splits(M, N, K, splits);
   return gemm_launch(p, s, reinterpret_cast<float*>(partial_ws), S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_k_pack_geglu(const float* w, const float* bias, void* w_packed_bf16, float* bias_packed, int inner, int K,
-                       void* stream) {
+                       void* stream) try {
   ARG_CHECK(w && w_packed_bf16, "pack_geglu args");
   int rc = pack_geglu_rows_launch(w, reinterpret_cast<bf16_t*>(w_packed_bf16), nullptr, 2 * inner, K, S(stream));
   if (rc != HEDIT_OK || !bias) return rc;
   ARG_CHECK(bias_packed, "pack_geglu: bias_packed");
   return pack_geglu_rows_launch(bias, nullptr, bias_packed, 2 * inner, 1, S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_k_gemm_geglu(const void* A, const void* w_packed, const float* bias_packed, void* C, int M, int inner, int K,
-                       int lda, int ldc, void* stream) {
+                       int lda, int ldc, void* stream) try {
   ARG_CHECK(A && w_packed && C, "gemm_geglu args");
   GemmParams p{};
   p.A = reinterpret_cast<const bf16_t*>(A);
@@ -100,30 +137,30 @@ int hedit_k_gemm_geglu(const void* A, const void* w_packed, const float* bias_pa
   p.ldc = ldc;
   p.geglu = 1;
   return gemm_launch(p, 1, nullptr, S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
 size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C) { return groupnorm_ws_bytes(B, HW, C); }
 
 int hedit_k_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G,
-                      float eps, int silu, void* ws, void* stream) {
+                      float eps, int silu, void* ws, void* stream) try {
   ARG_CHECK(x && y && gamma && beta && ws, "groupnorm args");
   return groupnorm_launch(reinterpret_cast<const bf16_t*>(x), reinterpret_cast<bf16_t*>(y), gamma, beta, B, HW, C, G,
                           eps, silu, reinterpret_cast<float*>(ws), S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_k_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int C, float eps,
-                      void* stream) {
+                      void* stream) try {
   ARG_CHECK(x && y && gamma && beta, "layernorm args");
   return layernorm_launch(reinterpret_cast<const bf16_t*>(x), reinterpret_cast<bf16_t*>(y), gamma, beta, (long)rows, C, eps, S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
-int hedit_k_geglu(const void* x, void* y, int64_t rows, int inner, void* stream) {
+int hedit_k_geglu(const void* x, void* y, int64_t rows, int inner, void* stream) try {
   ARG_CHECK(x && y, "geglu args");
   return geglu_launch(reinterpret_cast<const bf16_t*>(x), reinterpret_cast<bf16_t*>(y), (long)rows, inner, S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_k_self_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int64_t ldvt, void* out, int ldo,
-                      int B, int N, int heads, int d, const int32_t* qk_src, const int32_t* kv_src, void* stream) {
+                      int B, int N, int heads, int d, const int32_t* qk_src, const int32_t* kv_src, void* stream) try {
   ARG_CHECK(q && k && vt && out, "self_attn args");
   SelfAttnParams p{};
   p.q = reinterpret_cast<const bf16_t*>(q); p.ldq = ldq;
@@ -132,10 +169,10 @@ int hedit_k_self_attn(const void* q, int ldq, const void* k, int ldk, const void
   p.out = reinterpret_cast<bf16_t*>(out); p.ldo = ldo;
   p.B = B; p.N = N; p.heads = heads; p.d = d; p.qk_src = qk_src; p.kv_src = kv_src;
   return self_attn_launch(p, S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_k_cross_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int64_t ldvt, void* out, int ldo,
-                       int B, int N, int heads, int d, const hedit_p2p_plan* plan, float* store, void* stream) {
+                       int B, int N, int heads, int d, const hedit_p2p_plan* plan, float* store, void* stream) try {
   ARG_CHECK(q && k && vt && out && plan, "cross_attn args");
   CrossAttnParams p{};
   p.q = reinterpret_cast<const bf16_t*>(q); p.ldq = ldq;
@@ -148,16 +185,16 @@ int hedit_k_cross_attn(const void* q, int ldq, const void* k, int ldk, const voi
   p.singles = plan->singles; p.n_single = plan->n_single;
   p.store = store;
   return cross_attn_launch(p, S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
-int hedit_k_pack_conv3x3(const float* w, void* out, int O, int I, void* stream) {
+int hedit_k_pack_conv3x3(const float* w, void* out, int O, int I, void* stream) try {
   ARG_CHECK(w && out, "pack args");
   return pack_conv3x3_launch(w, reinterpret_cast<bf16_t*>(out), O, I, S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
-int hedit_k_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+int hedit_k_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) try {
   ARG_CHECK(x && y, "cast args");
   return f32_to_bf16_launch(x, reinterpret_cast<bf16_t*>(y), (long)n, S(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
 }  // extern "C"

@@ -14,6 +14,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // ---- error plumbing: thread-local message, negative return codes, never throws across the ABI
 void hedit_set_error(const std::string& msg);
+// Called from the catch (...) of every extern "C" entry point (they are function-try-blocks): turns whatever the C++
+// runtime threw inside the library (std::bad_alloc from a handle's containers, ...) into an error code + message.
+int hedit_abi_catch() noexcept;
 #define HEDIT_OK 0
 #define HEDIT_ERR_ARG (-1)
 #define HEDIT_ERR_HIP (-2)

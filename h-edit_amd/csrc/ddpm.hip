@@ -161,7 +161,7 @@ int forward_impl(hedit_ddpm* h, const float* x, float t, int B, float* out, void
 
 extern "C" {
 
-int hedit_ddpm_create(const hedit_ddpm_cfg* cfg, hedit_ddpm** out) {
+int hedit_ddpm_create(const hedit_ddpm_cfg* cfg, hedit_ddpm** out) try {
   ARG_CHECK(cfg && out, "null");
   ARG_CHECK(cfg->n_levels >= 1 && cfg->n_levels <= 8, "n_levels in 1..8");
   ARG_CHECK(cfg->in_channels >= 1 && cfg->in_channels <= 8 && cfg->out_ch >= 1 && cfg->out_ch <= 4, "in_channels <= 8, out_ch <= 4");
@@ -240,40 +240,40 @@ int hedit_ddpm_create(const hedit_ddpm_cfg* cfg, hedit_ddpm** out) {
   }
   *out = h;
   return HEDIT_OK;
-}
+} catch (...) { return hedit_abi_catch(); }
 
-void hedit_ddpm_destroy(hedit_ddpm* h) {
+void hedit_ddpm_destroy(hedit_ddpm* h) try {
   if (!h) return;
   store_free(h);
   delete h;
-}
+} catch (...) { (void)hedit_abi_catch(); }
 
 int hedit_ddpm_num_params(const hedit_ddpm* h) { return h ? (int)h->slots.size() : 0; }
-const char* hedit_ddpm_param_name(const hedit_ddpm* h, int i) {
+const char* hedit_ddpm_param_name(const hedit_ddpm* h, int i) try {
   if (!h || i < 0 || i >= (int)h->slots.size()) return nullptr;
   return h->slots[i].name.c_str();
-}
-int hedit_ddpm_param_shape(const hedit_ddpm* h, int i, int* ndim, int* dims4) {
+} catch (...) { (void)hedit_abi_catch(); return nullptr; }
+int hedit_ddpm_param_shape(const hedit_ddpm* h, int i, int* ndim, int* dims4) try {
   ARG_CHECK(h && ndim && dims4 && i >= 0 && i < (int)h->slots.size(), "param index");
   *ndim = h->slots[i].ndim;
   for (int k = 0; k < 4; ++k) dims4[k] = h->slots[i].dims[k];
   return HEDIT_OK;
-}
-int hedit_ddpm_load(hedit_ddpm* h, const char* name, const float* w, size_t numel, void* stream) {
+} catch (...) { return hedit_abi_catch(); }
+int hedit_ddpm_load(hedit_ddpm* h, const char* name, const float* w, size_t numel, void* stream) try {
   ARG_CHECK(h && name && w, "null");
   return store_load(h, "DDPM UNet", name, w, numel, reinterpret_cast<hipStream_t>(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 int hedit_ddpm_missing(const hedit_ddpm* h) { return h ? store_missing(h) : -1; }
 
-size_t hedit_ddpm_workspace_bytes(hedit_ddpm* h, int B) {
+size_t hedit_ddpm_workspace_bytes(hedit_ddpm* h, int B) try {
   if (!h || B < 1) return 0;
   size_t peak = 0;
   const int rc = forward_impl(h, nullptr, 0.f, B, nullptr, nullptr, 0, nullptr, true, &peak);
   return rc == HEDIT_OK ? peak + 4096 : 0;
-}
+} catch (...) { (void)hedit_abi_catch(); return 0; }
 
 int hedit_ddpm_forward(hedit_ddpm* h, const float* x, float t, int B, float* eps, void* workspace, size_t workspace_bytes,
-                       void* stream) {
+                       void* stream) try {
   ARG_CHECK(h && x && eps && workspace, "null");
   ARG_CHECK(B >= 1, "B");
   if (store_missing(h) != 0) {
@@ -281,6 +281,6 @@ int hedit_ddpm_forward(hedit_ddpm* h, const float* x, float t, int B, float* eps
     return HEDIT_ERR_STATE;
   }
   return forward_impl(h, x, t, B, eps, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream), false, nullptr);
-}
+} catch (...) { return hedit_abi_catch(); }
 
 }  // extern "C"

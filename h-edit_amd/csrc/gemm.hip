@@ -53,7 +53,12 @@ struct Smem {
   static constexpr int TOTAL = STAGES * STAGE;
 };
 
-template <int BM, int BN, int MODE>
+// CHUNK: the in-block form of the canonical K-chunking (see gemm_canonical_chunk): the fp32 sum is formed
+// chunk by chunk -- every p.chunk_kt K-tiles the running accumulators are added to a second register set
+// and restart from zero -- which is bit for bit what the split-K path computes (one chunk per slab, slabs
+// added in order by splitk_reduce_kernel).  The result of a layer therefore does not depend on whether a
+// launch was large enough to skip the split, i.e. not on the batch.
+template <int BM, int BN, int MODE, bool CHUNK>
 __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = BM * 2;       // threads: 4 or 8 waves, each owning a 64 x BN/2 sub-tile
@@ -260,6 +265,26 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 tot[CHUNK ? MI : 1][CHUNK ? NI : 1];
+  int next_flush = 0x7fffffff;      // tile index (relative to kt_begin) after which the chunk sum is folded
+  if constexpr (CHUNK) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) tot[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    next_flush = p.chunk_kt - 1;
+  }
+  auto flush = [&]() __attribute__((always_inline)) {
+    if constexpr (CHUNK) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          tot[i][j] += acc[i][j];
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  };
 
   const int fr = lane & 15;   // fragment row within a 16-row sub-tile
   const int fq = lane >> 4;   // k-group (8 bf16 each) within a 32-deep MFMA step
@@ -341,6 +366,9 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       }
       __builtin_amdgcn_s_setprio(0);
       cur = nx;
+      if constexpr (CHUNK) {
+        if (j == next_flush) { flush(); next_flush += p.chunk_kt; }
+      }
     }
     for (; j < nk; ++j) {              // last three tiles: nothing left to fetch
       const int nx = cur == 2 ? 0 : cur + 1;
@@ -357,6 +385,9 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       mfmas(xb, wb);
       __builtin_amdgcn_s_setprio(0);
       cur = nx;
+      if constexpr (CHUNK) {
+        if (j == next_flush && j + 1 < nk) { flush(); next_flush += p.chunk_kt; }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the epilogue
   } else {
@@ -458,6 +489,9 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       mfmas(xb, wb);
       weave_fire();
       __builtin_amdgcn_s_setprio(0);
+      if constexpr (CHUNK) {
+        if (i == next_flush) { flush(); next_flush += p.chunk_kt; }
+      }
     }
     for (; i < nk; ++i) {              // last two tiles: nothing left to fetch
       const int cur = i & 1;
@@ -468,8 +502,17 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
         read_frags(cur ^ 1, 0, xa, wa);
       }
       mfma_group(xb, wb);
+      if constexpr (CHUNK) {
+        if (i == next_flush && i + 1 < nk) { flush(); next_flush += p.chunk_kt; }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the epilogue
+  }
+  if constexpr (CHUNK) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = tot[i][j] + acc[i][j];
   }
 
   // ---- epilogue.  A lane holds 4 consecutive n of column m = mb + fr.
@@ -610,7 +653,9 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   }
 }
 
-// sum the split-K slabs and apply the epilogue; one thread per 4 consecutive n
+// sum the split-K slabs IN ORDER (0 + p0 + p1 + ...: the chain the CHUNK kernel forms in registers) and apply the
+// same epilogue arithmetic as igemm_kernel: bf16(sum + bias), then + residual in fp32 and rounded again.
+// One thread per 4 consecutive n.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const int n4 = p.N / 4;
@@ -621,31 +666,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < p.splits; ++s)
     v += *reinterpret_cast<const f32x4*>(p.partial + ((long)s * p.M + m) * p.N + n);
-  if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-  if (p.residual) {
-    const uint2 r = *reinterpret_cast<const uint2*>(p.residual + (long)m * p.ldr + n);
-    v[0] += bf16_to_f32((bf16_t)(r.x & 0xffff));
-    v[1] += bf16_to_f32((bf16_t)(r.x >> 16));
-    v[2] += bf16_to_f32((bf16_t)(r.y & 0xffff));
-    v[3] += bf16_to_f32((bf16_t)(r.y >> 16));
-  }
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) b = *reinterpret_cast<const f32x4*>(p.bias + n);
+  v = v + b;
   uint2 o;
   o.x = pack_bf16x2(v[0], v[1]);
   o.y = pack_bf16x2(v[2], v[3]);
+  if (p.residual) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p.residual + (long)m * p.ldr + n);
+    o.x = pack_bf16x2(bf16_to_f32((bf16_t)(o.x & 0xffff)) + bf16_to_f32((bf16_t)(r.x & 0xffff)),
+                      bf16_to_f32((bf16_t)(o.x >> 16)) + bf16_to_f32((bf16_t)(r.x >> 16)));
+    o.y = pack_bf16x2(bf16_to_f32((bf16_t)(o.y & 0xffff)) + bf16_to_f32((bf16_t)(r.y & 0xffff)),
+                      bf16_to_f32((bf16_t)(o.y >> 16)) + bf16_to_f32((bf16_t)(r.y >> 16)));
+  }
   *reinterpret_cast<uint2*>(p.C + (long)m * p.ldc + n) = o;
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, bool CHUNK>
 int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
   using S = Smem<BM, BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, S::TOTAL));
     attr_set = true;
   }
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), splits);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE>), grid, dim3(BM * 2), S::TOTAL, st, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, CHUNK>), grid, dim3(BM * 2), S::TOTAL, st, p);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }
@@ -655,6 +702,7 @@ int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
 // (3x3 convs, FF2: 1.17-1.26 vs 1.10-1.16 PF/s) and for the fused FF1+GEGLU at every K (+2 / +9 /
 // +14 % at K = 320 / 640 / 1280: half as many tiles pay the GELU epilogue's LDS pass); plain
 // launches with few K-tiles lose to its longer per-tile prologue / epilogue (K = 320: -3...-9 %).  HEDIT_GEMM_BM=128|256 forces one of them (A/B runs).
+// (The tile shape never changes a result: every output element is the same k-ordered MFMA chain.)
 static int big_tile_mode() {
   static int v = -1;
   if (v < 0) {
@@ -669,7 +717,10 @@ int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
   const int mode = big_tile_mode();
   const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.N, BN);
   const bool big = mode == 256 || (mode != 128 && splits == 1 && (p.geglu || p.K / BK >= 16) && tiles256 >= 200);
-  return big ? launch_igemm_impl<256, BN, MODE>(p, splits, st) : launch_igemm_impl<128, BN, MODE>(p, splits, st);
+  const bool chunk = splits == 1 && p.chunk_kt > 0 && p.chunk_kt < p.K / BK;
+  if (chunk)
+    return big ? launch_igemm_impl<256, BN, MODE, true>(p, splits, st) : launch_igemm_impl<128, BN, MODE, true>(p, splits, st);
+  return big ? launch_igemm_impl<256, BN, MODE, false>(p, splits, st) : launch_igemm_impl<128, BN, MODE, false>(p, splits, st);
 }
 
 }  // namespace
@@ -683,17 +734,42 @@ int gemm_pick_bn(int N) {
   return w160 <= w128 ? 160 : 128;
 }
 
-int gemm_pick_splits(int M, int N, int K, int force) {
-  if (force > 0) return force;
-  const int bn = gemm_pick_bn(N);
-  const long tiles = (long)cdiv(M, BM0) * cdiv(N, bn);
+// Canonical K-chunking of a contraction, a function of its NOMINAL shape only (the caller passes the per-image extent
+// times GEMM_NOMINAL_BATCH on whichever of M / N carries the batch -- never the actual batch): the fp32 result
+// is DEFINED as  ((0 + p_0) + p_1) + ...  with p_c the MFMA chain over the K-tiles [c * chunk, (c+1) * chunk).
+// Small launches run one chunk per split-K slab (parallelism for a handful of images), large ones fold the
+// chunks in registers (CHUNK kernel, no slab traffic) -- same bits either way, so a row's result does not
+// depend on how many other rows share the launch.  Returns the chunk length in K-tiles, 0 = one plain chain.
+int gemm_canonical_chunk(int M_nom, int N_nom, int K) {
+  const int bn = gemm_pick_bn(N_nom);
+  const long tiles = (long)cdiv(M_nom, BM0) * cdiv(N_nom, bn);
   const int kt = K / BK;
-  if (tiles >= 384 || kt < 8) return 1;
-  int s = (int)((640 + tiles - 1) / tiles);     // aim at >= 2 resident blocks per CU
-  int max_s = kt / 4;                            // keep >= 4 K-tiles per split
+  if (tiles >= 256 || kt < 8) return 0;
+  int s = (int)((256 + tiles - 1) / tiles);     // one block per CU at the nominal batch
+  int max_s = kt / 4;                            // keep >= 4 K-tiles per chunk
   if (s > max_s) s = max_s;
-  if (s > 32) s = 32;
-  return s < 1 ? 1 : s;
+  if (s > 16) s = 16;
+  if (s <= 1) return 0;
+  const int chunk = cdiv(kt, s);
+  return chunk >= kt ? 0 : chunk;
+}
+
+// How a launch of the ACTUAL shape executes that chunking: the number of split-K slabs (1 = in one launch, chunks
+// folded in registers).  Speed only -- both forms produce the same bits.
+int gemm_plan_splits(int M, int N, int K, int chunk_kt) {
+  const int kt = K / BK;
+  if (chunk_kt <= 0 || chunk_kt >= kt) return 1;
+  const int s = cdiv(kt, chunk_kt);
+  const long tiles = (long)cdiv(M, BM0) * cdiv(N, gemm_pick_bn(N));
+  return tiles * s <= 1024 ? s : 1;
+}
+
+// (single-kernel C entry points: an explicit split count, no canonical structure)
+int gemm_pick_splits(int M, int N, int K, int force) {
+  (void)M; (void)N;
+  const int kt = K / BK;
+  if (force <= 1) return 1;
+  return force > kt ? kt : force;
 }
 
 size_t gemm_partial_bytes(int M, int N, int splits) {
@@ -738,12 +814,19 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
   const int kt = p.K / BK;
   if (splits < 1) splits = 1;
   if (splits > kt) splits = kt;
-  p.splits = splits;
-  p.kt_per_split = cdiv(kt, splits);
-  p.splits = cdiv(kt, p.kt_per_split);
+  if (p.chunk_kt < 0 || p.chunk_kt >= kt) p.chunk_kt = 0;
+  if (splits > 1) {
+    // split-K executes the canonical chunking when there is one (one chunk per slab), else an even cut
+    p.kt_per_split = p.chunk_kt > 0 ? p.chunk_kt : cdiv(kt, splits);
+    p.splits = cdiv(kt, p.kt_per_split);
+    ARG_CHECK(p.chunk_kt == 0 || p.splits == splits, "gemm: split count does not match the canonical chunking");
+  } else {
+    p.splits = 1;
+    p.kt_per_split = kt;
+  }
   splits = p.splits;
   if (p.raw_f32) {
-    ARG_CHECK(!p.geglu, "gemm: raw fp32 output excludes the GEGLU epilogue");
+    ARG_CHECK(!p.geglu && p.chunk_kt == 0, "gemm: raw fp32 output excludes the GEGLU epilogue and K-chunking");
     p.splits = splits = 1;
     p.kt_per_split = kt;
     p.partial = p.raw_f32;      // the split-K slab path with one split IS the fp32 product
@@ -753,10 +836,14 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
   } else {
     p.partial = nullptr;
   }
-  const int bn = pick_bn(p);
+  int bn = pick_bn(p);
+  // the in-register chunk fold doubles the accumulators: with the upsampling gather's extra lane state the
+  // 160-column tile would spill inside the K loop, so that one combination takes the 128-column tile
+  // (the tile shape never changes a result)
+  if (splits == 1 && p.chunk_kt > 0 && p.mode == 3) bn = 128;
   if (p.geglu) {
     ARG_CHECK(p.N % 32 == 0 && p.mode == 0 && p.residual == nullptr && p.ldc % 8 == 0, "gemm: geglu epilogue needs N % 32 == 0, linear mode, no residual");
-    splits = 1;
+    ARG_CHECK(splits == 1 && p.chunk_kt == 0, "gemm: the geglu epilogue takes no K-chunking");
   }
   {
     // unique operand bytes: activations M x (K or Cin), weights N x K

@@ -156,13 +156,14 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restr
   }
 }
 
+// slabs per image: a function of (HW, C) only, like gn_nslab -- the gradient of an image does not depend on the batch
 int gb_nslab(int B, int HW, int C) {
+  (void)B;
   const int R = 256 / (C / 8);
-  int n = HW / (R * 4);
-  int want = 1024 / (B > 0 ? B : 1);
-  if (want < 1) want = 1;
-  if (n > want) n = want;
-  if (n > 128) n = 128;
+  int n = HW / (R * 8);
+  int cap = HW / 1024;
+  cap = cap < 32 ? 32 : (cap > 128 ? 128 : cap);
+  if (n > cap) n = cap;
   if (n < 1) n = 1;
   return n;
 }

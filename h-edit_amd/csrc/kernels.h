@@ -24,10 +24,14 @@ struct GemmParams {
   int asym;              // mode 2 only: 1 = pad (0,1,0,1) instead of 1 all round (the VAE encoder's
                          // Downsample2D(padding=0): taps at rows 2oy .. 2oy+2)
   float* raw_f32;        // if set: write the plain fp32 products [M][N] here (no bias / residual / bf16 C)
+  int chunk_kt;          // canonical K-chunking (gemm_canonical_chunk), in K-tiles of 64; 0 = one plain chain
 };
+#define GEMM_NOMINAL_BATCH 4   // the canonical chunking is sized for this many rows of the batch dimension
 int gemm_prepare();   // allocates the zero page (call once outside any timed / captured region)
 int gemm_pick_bn(int N);
-int gemm_pick_splits(int M, int N, int K, int force);
+int gemm_pick_splits(int M, int N, int K, int force);      // explicit split count clamped to the K-tiles (C entry points)
+int gemm_canonical_chunk(int M_nom, int N_nom, int K);     // batch-independent definition of the fp32 summation order
+int gemm_plan_splits(int M, int N, int K, int chunk_kt);   // slabs this launch uses to execute it (1 = in registers)
 size_t gemm_partial_bytes(int M, int N, int splits);
 int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st);
 
@@ -137,6 +141,9 @@ struct StepCoef {
 // base pass: eps [rows][n_img][elems], rows = [x_o|null, x_e|null, x_o|src, x_e|src] -> x_prev [2][n_img][elems]
 int step_base_launch(const float* eps, const float* xt, const float* z, float* x_prev, int n_img,
                      int elems, int eps_rows_per_img, StepCoef c, hipStream_t st);
+// inversion step: z = (x_prev - mu) / sigma, x_prev <- mu + sigma z, with step_base's mu (sigma = c.noise_coef)
+int step_invert_launch(const float* e_u, const float* e_c, const float* xt, float* x_prev, float* z_out, int n_img,
+                       int elems, StepCoef c, hipStream_t st);
 int step_update_launch(const float* e_u_src, const float* e_c_src, const float* e_u_tar,
                        const float* e_c_tar, long stride_img, const float* x_k, const float* x_base,
                        float* x_out, int n_img, int elems, int k_gt0, StepCoef c, hipStream_t st);

@@ -450,14 +450,17 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* __restrict_
   }
 }
 
+// Pixel slabs per image for the statistics pass.  A function of (HW, C) only -- never of the batch -- so that the
+// fp32 summation order of an image's statistics, and with it every bit of the normalised output, is the same
+// whether the image is evaluated alone or in a batch of 120 (the sampler's reconstruction invariant rests on it).
 int gn_nslab(int B, int HW, int C) {
+  (void)B;
   const int CV = C / 8;
   const int R = CV <= 256 ? 256 / CV : 1;
-  int n = HW / (R * 4);         // >= 4 rows per thread
-  int want = 1024 / (B > 0 ? B : 1);
-  if (want < 1) want = 1;
-  if (n > want) n = want;
-  if (n > 128) n = 128;
+  int n = HW / (R * 8);         // >= 8 rows per thread
+  int cap = HW / 1024;          // 32 slabs up to 128 x 128 pixels, 128 for the VAE's 512 x 512
+  cap = cap < 32 ? 32 : (cap > 128 ? 128 : cap);
+  if (n > cap) n = cap;
   if (n < 1) n = 1;
   return n;
 }

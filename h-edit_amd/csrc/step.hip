@@ -20,8 +20,17 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
-// x_prev[j] = sqrt(ab_prev) * (x[j] - sqrt(1-ab_t) e) / sqrt(ab_t) + dir * e + noise * z
-// with e = e_u + w_src (e_c - e_u).  Batched tensors are [row][image][elems] ("row-major over
+// mu(x, e) = sqrt(ab_prev) * (x - sqrt(1-ab_t) e) / sqrt(ab_t) + dir * e   with e = e_u + w_src (e_c - e_u).
+// ONE definition for the sampler's base step and for the inversion that produced its noise maps: the
+// reconstruction branch of the loop then retraces the inverted trajectory bit for bit (same operations in the
+// same order on the same eps; this unit is built with -ffp-contract=off, so nothing is re-associated).
+__device__ __forceinline__ float ddpm_mu(float x, float eu, float ec, const StepCoef& c) {
+  const float en = eu + c.w_src * (ec - eu);
+  const float x0 = (x - c.sqrt_1m_ab_t * en) / c.sqrt_ab_t;
+  return c.sqrt_ab_prev * x0 + c.dir_coef * en;
+}
+
+// x_prev[j] = mu(x[j], e) + noise * z.  Batched tensors are [row][image][elems] ("row-major over
 // images", identical to the reference layout for one image):
 //   rows == 4: P2P layout [x_o|0, x_e|0, x_o|src, x_e|src];
 //   rows == 2: no-P2P layout [x_e|0, x_e|src], the same eps drives both branches;
@@ -37,13 +46,29 @@ __global__ __launch_bounds__(256) void step_base_kernel(const float* __restrict_
       const int ru = rows == 4 ? j : 0, rc = rows == 4 ? 2 + j : 1;
       const float eu = eps[((long)ru * n_img + img) * elems + i];
       const float ec = eps[((long)rc * n_img + img) * elems + i];
-      const float en = eu + c.w_src * (ec - eu);
       const long xi = ((long)j * n_img + img) * elems + i;
-      const float x0 = (xt[xi] - c.sqrt_1m_ab_t * en) / c.sqrt_ab_t;
-      float pv = c.sqrt_ab_prev * x0 + c.dir_coef * en;
+      float pv = ddpm_mu(xt[xi], eu, ec, c);
       pv = pv + c.noise_coef * zz;
       x_prev[xi] = pv;
     }
+  }
+}
+
+// One step of the edit-friendly DDPM inversion (text-guided/inversion/ddpm_inversion.py:146-162):
+//   z = (x_prev - mu(x_t, e)) / sigma ;  x_prev <- mu + sigma z   (the reference's in-place rewrite of xts[idx]).
+// e_u / e_c: [n_img][elems] each (e_c == e_u for an unconditional inversion); sigma = c.noise_coef.
+__global__ __launch_bounds__(256) void step_invert_kernel(const float* __restrict__ e_u, const float* __restrict__ e_c,
+                                                          const float* __restrict__ xt, float* __restrict__ x_prev,
+                                                          float* __restrict__ z_out, int elems, StepCoef c) {
+  const int img = blockIdx.y;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < elems; i += gridDim.x * 256) {
+    const long xi = (long)img * elems + i;
+    const float mu = ddpm_mu(xt[xi], e_u[xi], e_c[xi], c);
+    const float zz = (x_prev[xi] - mu) / c.noise_coef;
+    z_out[xi] = zz;
+    float pv = mu;
+    pv = pv + c.noise_coef * zz;
+    x_prev[xi] = pv;
   }
 }
 
@@ -220,6 +245,15 @@ int step_base_launch(const float* eps, const float* xt, const float* z, float* x
   ARG_CHECK(rows == 4 || rows == 2, "step_base: eps rows per image must be 4 (P2P) or 2");
   dim3 grid(cdiv(elems, 256) > 64 ? 64 : cdiv(elems, 256), n_img);
   hipLaunchKernelGGL(step_base_kernel, grid, dim3(256), 0, st, eps, xt, z, x_prev, n_img, elems, rows, c);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int step_invert_launch(const float* e_u, const float* e_c, const float* xt, float* x_prev, float* z_out, int n_img,
+                       int elems, StepCoef c, hipStream_t st) {
+  ARG_CHECK(c.noise_coef > 0.f, "step_invert: sigma must be positive (eta > 0)");
+  dim3 grid(cdiv(elems, 256) > 64 ? 64 : cdiv(elems, 256), n_img);
+  hipLaunchKernelGGL(step_invert_kernel, grid, dim3(256), 0, st, e_u, e_c, xt, x_prev, z_out, elems, c);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }

@@ -231,8 +231,16 @@ int aalloc(Fwd& f, T** out, size_t n) {
   return HEDIT_OK;
 }
 
-int run_gemm(Fwd& f, GemmParams p) {
-  const int splits = gemm_pick_splits(p.M, p.N, p.K, 0);
+// batch_in: which extent of the GEMM carries the batch (1 = M, 2 = N, 0 = neither).  The K-chunking is taken from
+// the per-image extent times a fixed nominal batch, so the summation order of a layer is a property of the
+// layer, not of the launch (see gemm_canonical_chunk).
+int run_gemm(Fwd& f, GemmParams p, int batch_in = 1) {
+  if (!p.raw_f32 && !p.geglu) {
+    const int mn = batch_in == 1 ? p.M / f.B * GEMM_NOMINAL_BATCH : p.M;
+    const int nn = batch_in == 2 ? p.N / f.B * GEMM_NOMINAL_BATCH : p.N;
+    p.chunk_kt = gemm_canonical_chunk(mn, nn, p.K);
+  }
+  const int splits = gemm_plan_splits(p.M, p.N, p.K, p.chunk_kt);
   float* part = nullptr;
   if (splits > 1) TRY(aalloc(f, &part, (size_t)splits * p.M * p.N));
   {
@@ -244,11 +252,11 @@ int run_gemm(Fwd& f, GemmParams p) {
 }
 
 int linear(Fwd& f, const bf16_t* A, int M, int K, const bf16_t* W, int N, const float* bias,
-           const bf16_t* residual, bf16_t* C, int ldc) {
+           const bf16_t* residual, bf16_t* C, int ldc, int batch_in = 1) {
   GemmParams p{};
   p.A = A; p.W = W; p.M = M; p.N = N; p.K = K; p.lda = K; p.mode = 0;
   p.bias = bias; p.residual = residual; p.ldr = N; p.C = C; p.ldc = ldc;
-  return run_gemm(f, p);
+  return run_gemm(f, p, batch_in);
 }
 
 int conv3x3(Fwd& f, const bf16_t* X, int Hin, int Win, int Cin, const bf16_t* W, int Cout, const float* bias,
@@ -331,7 +339,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   TRY(aalloc(f, &qk, M * 2 * C));
   TRY(linear(f, tn, (int)M, C, a.w_qk, 2 * C, nullptr, nullptr, qk, 2 * C));
   TRY(aalloc(f, &vt, M * C));
-  TRY(linear(f, a.w_v1, C, C, tn, (int)M, nullptr, nullptr, vt, (int)M));   // V^T = W_v . X^T
+  TRY(linear(f, a.w_v1, C, C, tn, (int)M, nullptr, nullptr, vt, (int)M, 2));   // V^T = W_v . X^T
   f.ar.free(tn);
   TRY(aalloc(f, &ao, M * C));
   {
@@ -362,7 +370,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   TRY(aalloc(f, &k2, (size_t)MC * C));
   TRY(linear(f, f.ctxb, MC, ctx_dim, a.w_k2, C, nullptr, nullptr, k2, C));
   TRY(aalloc(f, &vt2, (size_t)MC * C));
-  TRY(linear(f, a.w_v2, C, ctx_dim, f.ctxb, MC, nullptr, nullptr, vt2, MC));
+  TRY(linear(f, a.w_v2, C, ctx_dim, f.ctxb, MC, nullptr, nullptr, vt2, MC, 2));
   TRY(aalloc(f, &ao, M * C));
   {
     CrossAttnParams cp{};
@@ -429,15 +437,8 @@ int forward_impl(hedit_unet* h, const float* x, float t, const float* ctx, int B
   const int ch0 = c.block_out_channels[0];
 
   if (!dry && h->iota_cap < B) {
-    // identity row list for "all rows are singles" (controller off); grown on demand, off the hot path
-    std::vector<int32_t> v(B > 64 ? B : 64);
-    for (size_t i = 0; i < v.size(); ++i) v[i] = (int32_t)i;
-    int32_t* p = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), v.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    h->owned.push_back(p);
-    h->iota = p;
-    h->iota_cap = (int)v.size();
+    hedit_set_error("batch larger than " + std::to_string(h->iota_cap) + " rows");
+    return HEDIT_ERR_ARG;
   }
 
   // ---- text context -> bf16, padded to 80 rows per item
@@ -599,7 +600,7 @@ int forward_impl(hedit_unet* h, const float* x, float t, const float* ctx, int B
 // =============================================================================== C ABI
 extern "C" {
 
-int hedit_unet_create(const hedit_unet_cfg* cfg, hedit_unet** out) {
+int hedit_unet_create(const hedit_unet_cfg* cfg, hedit_unet** out) try {
   ARG_CHECK(cfg && out, "null");
   ARG_CHECK(cfg->n_levels >= 2 && cfg->n_levels <= HEDIT_MAX_LEVELS, "n_levels");
   ARG_CHECK(cfg->in_channels <= 8 && cfg->out_channels <= 4, "in/out channels");
@@ -691,6 +692,16 @@ int hedit_unet_create(const hedit_unet_cfg* cfg, hedit_unet** out) {
   h->conv_out_w = conv3p(h, "conv_out.weight", cfg->out_channels, ch[0]);
   h->conv_out_b = f32p(h, "conv_out.bias", cfg->out_channels);
 
+  {
+    // identity row list for "all rows are singles" (controller off), sized once: nothing is allocated or copied
+    // synchronously inside hedit_unet_forward
+    constexpr int IOTA = 16384;
+    std::vector<int32_t> v(IOTA);
+    for (int i = 0; i < IOTA; ++i) v[i] = i;
+    h->iota = dalloc<int32_t>(h, IOTA);
+    if (h->iota && hipMemcpy(h->iota, v.data(), IOTA * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) h->iota = nullptr;
+    h->iota_cap = h->iota ? IOTA : 0;
+  }
   if (toff != total) {
     hedit_set_error("internal: time-embedding plan mismatch");
     delete h;
@@ -702,29 +713,29 @@ int hedit_unet_create(const hedit_unet_cfg* cfg, hedit_unet** out) {
     if (!s.dst) { hedit_set_error("hipMalloc failed for " + s.name); return HEDIT_ERR_HIP; }
   *out = h;
   return HEDIT_OK;
-}
+} catch (...) { return hedit_abi_catch(); }
 
-void hedit_unet_destroy(hedit_unet* h) {
+void hedit_unet_destroy(hedit_unet* h) try {
   if (!h) return;
   for (void* p : h->owned) (void)hipFree(p);
   for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
   delete h;
-}
+} catch (...) { (void)hedit_abi_catch(); }
 
 int hedit_unet_num_params(const hedit_unet* h) { return h ? (int)h->slots.size() : 0; }
-const char* hedit_unet_param_name(const hedit_unet* h, int i) {
+const char* hedit_unet_param_name(const hedit_unet* h, int i) try {
   if (!h || i < 0 || i >= (int)h->slots.size()) return nullptr;
   return h->slots[i].name.c_str();
-}
+} catch (...) { (void)hedit_abi_catch(); return nullptr; }
 
-int hedit_unet_param_shape(const hedit_unet* h, int i, int* ndim, int* dims4) {
+int hedit_unet_param_shape(const hedit_unet* h, int i, int* ndim, int* dims4) try {
   ARG_CHECK(h && ndim && dims4 && i >= 0 && i < (int)h->slots.size(), "param index");
   *ndim = h->slots[i].ndim;
   for (int k = 0; k < 4; ++k) dims4[k] = h->slots[i].dims[k];
   return HEDIT_OK;
-}
+} catch (...) { return hedit_abi_catch(); }
 
-int hedit_unet_load(hedit_unet* h, const char* name, const float* w, size_t numel, void* stream) {
+int hedit_unet_load(hedit_unet* h, const char* name, const float* w, size_t numel, void* stream) try {
   ARG_CHECK(h && name && w, "null");
   auto it = h->index.find(name);
   if (it == h->index.end()) {
@@ -750,25 +761,25 @@ int hedit_unet_load(hedit_unet* h, const char* name, const float* w, size_t nume
   }
   s.loaded = true;
   return HEDIT_OK;
-}
+} catch (...) { return hedit_abi_catch(); }
 
-int hedit_unet_missing(const hedit_unet* h) {
+int hedit_unet_missing(const hedit_unet* h) try {
   if (!h) return -1;
   int m = 0;
   for (auto& s : h->slots) m += s.loaded ? 0 : 1;
   return m;
-}
+} catch (...) { return hedit_abi_catch(); }
 
-size_t hedit_unet_workspace_bytes(hedit_unet* h, int B, int height, int width) {
+size_t hedit_unet_workspace_bytes(hedit_unet* h, int B, int height, int width) try {
   if (!h) return 0;
   size_t peak = 0;
   if (forward_impl(h, nullptr, 0.f, nullptr, B, height, width, nullptr, nullptr, nullptr, 0, nullptr, true, &peak) != HEDIT_OK) return 0;
   return peak + 4096;
-}
+} catch (...) { (void)hedit_abi_catch(); return 0; }
 
 int hedit_unet_forward(hedit_unet* h, const float* x, float t, const float* ctx, int B, int height, int width,
                        const hedit_p2p_plan* plan, float* eps_out, void* workspace, size_t workspace_bytes,
-                       void* stream) {
+                       void* stream) try {
   ARG_CHECK(h && x && ctx && eps_out && workspace, "null");
   ARG_CHECK(B >= 1, "B");
   const int div = 1 << (h->cfg.n_levels - 1);
@@ -785,9 +796,9 @@ int hedit_unet_forward(hedit_unet* h, const float* x, float t, const float* ctx,
   }
   return forward_impl(h, x, t, ctx, B, height, width, plan, eps_out, workspace, workspace_bytes,
                       reinterpret_cast<hipStream_t>(stream), false, nullptr);
-}
+} catch (...) { return hedit_abi_catch(); }
 
-int hedit_prof_enable(hedit_unet* h, int on, int max_records) {
+int hedit_prof_enable(hedit_unet* h, int on, int max_records) try {
   ARG_CHECK(h, "null");
   if (on && (int)h->prof_pool.size() < 2 * max_records) {
     const size_t want = (size_t)2 * max_records;
@@ -799,17 +810,17 @@ int hedit_prof_enable(hedit_unet* h, int on, int max_records) {
   }
   h->prof_on = on != 0;
   return HEDIT_OK;
-}
+} catch (...) { return hedit_abi_catch(); }
 
-int hedit_prof_reset(hedit_unet* h) {
+int hedit_prof_reset(hedit_unet* h) try {
   ARG_CHECK(h, "null");
   h->prof_recs.clear();
   h->prof_next = 0;
   return HEDIT_OK;
-}
+} catch (...) { return hedit_abi_catch(); }
 
 /* call after the stream has been synchronised */
-int hedit_prof_collect(hedit_unet* h, int kind, double* total_ms, double* total_flops, int64_t* count) {
+int hedit_prof_collect(hedit_unet* h, int kind, double* total_ms, double* total_flops, int64_t* count) try {
   ARG_CHECK(h && total_ms && total_flops && count && kind >= 0 && kind < PK_COUNT, "prof args");
   double ms = 0, fl = 0;
   int64_t n = 0;
@@ -823,7 +834,7 @@ int hedit_prof_collect(hedit_unet* h, int kind, double* total_ms, double* total_
   }
   *total_ms = ms; *total_flops = fl; *count = n;
   return HEDIT_OK;
-}
+} catch (...) { return hedit_abi_catch(); }
 
 static void store_layers(const hedit_unet* h, int height, int width, std::vector<std::pair<int, int>>& v) {
   const hedit_unet_cfg& c = h->cfg;
@@ -843,14 +854,14 @@ static void store_layers(const hedit_unet* h, int height, int width, std::vector
   }
 }
 
-int hedit_unet_num_store_layers(const hedit_unet* h, int height, int width) {
+int hedit_unet_num_store_layers(const hedit_unet* h, int height, int width) try {
   if (!h) return 0;
   std::vector<std::pair<int, int>> v;
   store_layers(h, height, width, v);
   return (int)v.size();
-}
+} catch (...) { return hedit_abi_catch(); }
 
-int hedit_unet_store_layer_info(const hedit_unet* h, int height, int width, int i, int* tokens, int* place) {
+int hedit_unet_store_layer_info(const hedit_unet* h, int height, int width, int i, int* tokens, int* place) try {
   ARG_CHECK(h && tokens && place, "null");
   std::vector<std::pair<int, int>> v;
   store_layers(h, height, width, v);
@@ -858,6 +869,6 @@ int hedit_unet_store_layer_info(const hedit_unet* h, int height, int width, int 
   *tokens = v[i].first;
   *place = v[i].second;
   return HEDIT_OK;
-}
+} catch (...) { return hedit_abi_catch(); }
 
 }  // extern "C"

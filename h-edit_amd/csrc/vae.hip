@@ -284,7 +284,7 @@ int encode_impl(hedit_vae* h, const float* image, int B, int IH, int IW, float* 
 // ==================================================================================== C ABI
 extern "C" {
 
-int hedit_vae_create(const hedit_vae_cfg* cfg, hedit_vae** out) {
+int hedit_vae_create(const hedit_vae_cfg* cfg, hedit_vae** out) try {
   ARG_CHECK(cfg && out, "null");
   ARG_CHECK(cfg->n_levels >= 1 && cfg->n_levels <= 4, "n_levels in 1..4");
   ARG_CHECK(cfg->in_channels >= 1 && cfg->in_channels <= 4, "in_channels in 1..4");
@@ -367,36 +367,36 @@ int hedit_vae_create(const hedit_vae_cfg* cfg, hedit_vae** out) {
   }
   *out = h;
   return HEDIT_OK;
-}
+} catch (...) { return hedit_abi_catch(); }
 
 static void drop_tape(hedit_vae* h) {
   if (h->tape && h->tape_free) h->tape_free(h->tape);
   h->tape = nullptr;
 }
 
-void hedit_vae_destroy(hedit_vae* h) {
+void hedit_vae_destroy(hedit_vae* h) try {
   if (!h) return;
   drop_tape(h);
   store_free(h);
   delete h;
-}
+} catch (...) { (void)hedit_abi_catch(); }
 
 int hedit_vae_num_params(const hedit_vae* h) { return h ? (int)h->slots.size() : 0; }
-const char* hedit_vae_param_name(const hedit_vae* h, int i) {
+const char* hedit_vae_param_name(const hedit_vae* h, int i) try {
   if (!h || i < 0 || i >= (int)h->slots.size()) return nullptr;
   return h->slots[i].name.c_str();
-}
-int hedit_vae_param_shape(const hedit_vae* h, int i, int* ndim, int* dims4) {
+} catch (...) { (void)hedit_abi_catch(); return nullptr; }
+int hedit_vae_param_shape(const hedit_vae* h, int i, int* ndim, int* dims4) try {
   ARG_CHECK(h && ndim && dims4 && i >= 0 && i < (int)h->slots.size(), "param index");
   *ndim = h->slots[i].ndim;
   for (int k = 0; k < 4; ++k) dims4[k] = h->slots[i].dims[k];
   return HEDIT_OK;
-}
+} catch (...) { return hedit_abi_catch(); }
 
-int hedit_vae_load(hedit_vae* h, const char* name, const float* w, size_t numel, void* stream) {
+int hedit_vae_load(hedit_vae* h, const char* name, const float* w, size_t numel, void* stream) try {
   ARG_CHECK(h && name && w, "null");
   return store_load(h, "VAE", name, w, numel, reinterpret_cast<hipStream_t>(stream));
-}
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_vae_missing(const hedit_vae* h) { return h ? store_missing(h) : -1; }
 
@@ -406,7 +406,7 @@ static int check_latent(const hedit_vae* h, int lh, int lw) {
   return HEDIT_OK;
 }
 
-size_t hedit_vae_workspace_bytes(hedit_vae* h, int B, int latent_h, int latent_w, int encode) {
+size_t hedit_vae_workspace_bytes(hedit_vae* h, int B, int latent_h, int latent_w, int encode) try {
   if (!h || B < 1 || check_latent(h, latent_h, latent_w) != HEDIT_OK) return 0;
   size_t peak = 0;
   const int f = 1 << (h->cfg.n_levels - 1);
@@ -415,10 +415,10 @@ size_t hedit_vae_workspace_bytes(hedit_vae* h, int B, int latent_h, int latent_w
          : encode == 2 ? decode_impl(h, nullptr, B, latent_h, latent_w, nullptr, nullptr, 0, nullptr, true, &peak, &dummy, &dummy)
                        : decode_impl(h, nullptr, B, latent_h, latent_w, nullptr, nullptr, 0, nullptr, true, &peak);
   return rc == HEDIT_OK ? peak + 4096 : 0;
-}
+} catch (...) { (void)hedit_abi_catch(); return 0; }
 
 int hedit_vae_decode(hedit_vae* h, const float* z, int B, int latent_h, int latent_w, float* image, void* workspace,
-                     size_t workspace_bytes, void* stream) {
+                     size_t workspace_bytes, void* stream) try {
   ARG_CHECK(h && z && image && workspace, "null");
   ARG_CHECK(B >= 1, "B");
   TRY(check_latent(h, latent_h, latent_w));
@@ -428,10 +428,10 @@ int hedit_vae_decode(hedit_vae* h, const float* z, int B, int latent_h, int late
   }
   return decode_impl(h, z, B, latent_h, latent_w, image, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream),
                      false, nullptr);
-}
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_vae_decode_vjp(hedit_vae* h, const float* z, const float* d_image, int B, int latent_h, int latent_w, float* d_z,
-                         float* image, void* workspace, size_t workspace_bytes, void* stream) {
+                         float* image, void* workspace, size_t workspace_bytes, void* stream) try {
   ARG_CHECK(h && z && d_image && d_z && workspace, "null");
   ARG_CHECK(B >= 1, "B");
   TRY(check_latent(h, latent_h, latent_w));
@@ -441,10 +441,10 @@ int hedit_vae_decode_vjp(hedit_vae* h, const float* z, const float* d_image, int
   }
   return decode_impl(h, z, B, latent_h, latent_w, image, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream),
                      false, nullptr, d_image, d_z);
-}
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_vae_decode_keep(hedit_vae* h, const float* z, int B, int latent_h, int latent_w, float* image, void* workspace,
-                          size_t workspace_bytes, void* stream) {
+                          size_t workspace_bytes, void* stream) try {
   ARG_CHECK(h && z && image && workspace, "null");
   ARG_CHECK(B >= 1, "B");
   TRY(check_latent(h, latent_h, latent_w));
@@ -463,9 +463,9 @@ int hedit_vae_decode_keep(hedit_vae* h, const float* z, int B, int latent_h, int
   h->tape = T;
   h->tape_free = [](void* p) { delete reinterpret_cast<DecodeTape*>(p); };
   return HEDIT_OK;
-}
+} catch (...) { return hedit_abi_catch(); }
 
-int hedit_vae_decode_backward(hedit_vae* h, const float* d_image, float* d_z, void* workspace, void* stream) {
+int hedit_vae_decode_backward(hedit_vae* h, const float* d_image, float* d_z, void* workspace, void* stream) try {
   ARG_CHECK(h && d_image && d_z && workspace, "null");
   if (!h->tape) {
     hedit_set_error("hedit_vae_decode_backward: no forward is being kept (call hedit_vae_decode_keep first; one backward per forward)");
@@ -480,10 +480,10 @@ int hedit_vae_decode_backward(hedit_vae* h, const float* d_image, float* d_z, vo
   const int rc = decode_backward(h, *T, d_image, d_z);
   drop_tape(h);
   return rc;
-}
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_vae_encode(hedit_vae* h, const float* image, int B, int height, int width, float* mean, void* workspace,
-                     size_t workspace_bytes, void* stream) {
+                     size_t workspace_bytes, void* stream) try {
   ARG_CHECK(h && image && mean && workspace, "null");
   ARG_CHECK(B >= 1, "B");
   const int f = 1 << (h->cfg.n_levels - 1);
@@ -495,6 +495,6 @@ int hedit_vae_encode(hedit_vae* h, const float* image, int B, int height, int wi
   }
   return encode_impl(h, image, B, height, width, mean, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream),
                      false, nullptr);
-}
+} catch (...) { return hedit_abi_catch(); }
 
 }  // extern "C"

@@ -67,6 +67,8 @@ _SIGS = {
                                      C.POINTER(C.c_int64)]),
     "hedit_step_base": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                   C.c_int, C.POINTER(StepCoef), C.c_void_p]),
+    "hedit_step_invert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.POINTER(StepCoef), C.c_void_p]),
     "hedit_step_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(StepCoef),
                                     C.c_void_p]),
@@ -104,6 +106,8 @@ _SIGS = {
     "hedit_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p]),
     "hedit_k_gemm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "hedit_k_gemm_canonical_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "hedit_k_gemm_plan_splits": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "hedit_k_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 13 +
                      [C.c_void_p, C.c_void_p]),
     "hedit_k_pack_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

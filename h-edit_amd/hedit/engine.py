@@ -165,6 +165,7 @@ class HEditEngine:
         rec_pull=False drops the L1 reconstruction pull of inner steps k > 0 (the MasaCtrl loop,
         masactrl_h_edit.py:139-150); ``controller`` may be any object with _plan / _after_pass /
         step_callback (P2P controllers, hedit.masactrl.MutualSelfAttentionControl).
+        eta: one number, or the reference's per-step list etas[idx] (len == num_inference_steps, indexed like zs).
         Returns (edit (n,C,H,W), recon (n,C,H,W))."""
         if style is not None and not (p2p and implicit):
             raise ValueError("style guidance is defined for the implicit P2P loop only (n-style h_edit.py)")
@@ -211,13 +212,14 @@ class HEditEngine:
             idx = T - i - (T - after_skip_steps + 1)
             z = zs[idx] if zs is not None else None
             tt = op[i + 1] if i < len(op) - 1 else 0
-            coef = S.step_coef(t, tt, eta, ddim_inv, cfg_scales, w_rec)
+            eta_i = float(eta[idx]) if isinstance(eta, (list, tuple)) else float(eta)   # etas[idx], p2p_h_edit.py:619,665
+            coef = S.step_coef(t, tt, eta_i, ddim_inv, cfg_scales, w_rec)
 
             if (not p2p) and implicit and i == 0 and ahead != -1:
                 # one extra correction of the start sample when steps were skipped (p2p_h_edit.py:239-267)
                 xe = xt[n:]
                 e = self.unet.forward_raw(torch.cat([xe] * 4), t, ctx_edit, off)
-                c0 = S.step_coef(t, tt, eta, ddim_inv, cfg_scales, w_rec, coeff=S.edit_coeff(ahead, t, eta, ddim_inv))
+                c0 = S.step_coef(t, tt, eta_i, ddim_inv, cfg_scales, w_rec, coeff=S.edit_coeff(ahead, t, eta_i, ddim_inv))
                 new = torch.empty_like(xe)
                 self.step_update(e[0:n], e[2 * n:3 * n], e[n:2 * n], e[3 * n:], xe, xe, new, n, False, c0)
                 xt = torch.cat([xt[:n], new]).contiguous()
@@ -330,20 +332,25 @@ class HEditEngine:
 
     # ------------------------------------------------------------------ DDPM inversion
     @torch.no_grad()
-    def ddpm_inversion(self, x0, prompts, eta=1.0, cfg_src=1.0, noise=None, generator=None):
+    def ddpm_inversion(self, x0, prompts, eta=1.0, cfg_src=1.0, noise=None, generator=None, return_noise=False):
         """Edit-friendly DDPM inversion for n images (ddpm_inversion.py:54-167).
-        x0 (n,C,H,W); prompts: n source prompts ("" = unconditional).  noise: optional
-        (T+1,n,C,H,W) tensor of the forward-process noises (row idx as in the reference).
-        Returns zs (T,n,C,H,W), xts (T+1,n,C,H,W)."""
+        x0 (n,C,H,W); prompts: n source prompts ("" = unconditional: its embedding IS the null embedding, so the
+        CFG mix of such a row reduces to eps(null) exactly, per image, as the reference decides per image).
+        noise: optional (T+1,n,C,H,W) tensor of the forward-process noises (row idx as in the reference).
+        Each step runs in hedit_step_invert with the arithmetic of the sampler's base step, so the loop's
+        reconstruction branch retraces xts bit for bit (ddpm_inversion.py:146-162 <-> inversion_utils.py:84-119).
+        Returns zs (T,n,C,H,W), xts (T+1,n,C,H,W) [, noise_added (T+1,n,C,H,W) if return_noise]."""
         sch = self.model.scheduler
         S = Schedule(sch)
         T = sch.num_inference_steps
         dev = self.dev
         x0 = x0.to(device=dev, dtype=torch.float32)
         n = x0.shape[0]
+        elems = x0[0].numel()
         ts = [int(v) for v in sch.timesteps]
         ab = S.ab
         xts = torch.zeros(T + 1, *x0.shape, device=dev)
+        nzs = torch.zeros(T + 1, *x0.shape, device=dev) if return_noise else None
         xts[0] = x0
         for j, t in enumerate(reversed(ts)):
             idx = j + 1
@@ -351,9 +358,11 @@ class HEditEngine:
                 nz = noise[idx].to(dev)
             else:
                 nz = torch.randn(x0.shape, device=dev, generator=generator)
+            if nzs is not None:
+                nzs[idx] = nz
             xts[idx] = x0 * _f(ab[t] ** 0.5) + nz * _f((1 - ab[t]) ** 0.5)
         null = self.encode([""]).expand(n, -1, -1)
-        cond = all(p != "" for p in prompts)
+        cond = any(p != "" for p in prompts)
         ctx = torch.cat([null, self.encode(list(prompts))]).contiguous() if cond else null.contiguous()
         zs = torch.zeros(T, *x0.shape, device=dev)
         for i, t in enumerate(ts):
@@ -361,16 +370,15 @@ class HEditEngine:
             xt = xts[idx + 1]
             if cond:
                 e = self.unet.forward_raw(torch.cat([xt, xt]), t, ctx)
-                eps = e[:n] + cfg_src * (e[n:] - e[:n])
+                e_u, e_c = e[:n], e[n:]
             else:
-                eps = self.unet.forward_raw(xt.contiguous(), t, ctx)
-            a_t, a_p, var = ab[t], S.ab_prev(t), S.variance(t)
-            x0_hat = (xt - _f((1 - a_t) ** 0.5) * eps) / _f(a_t ** 0.5)
-            mu = _f(a_p ** 0.5) * x0_hat + _f((1 - a_p - (eta ** 2) * var) ** 0.5) * eps
-            sig = _f(eta * var ** 0.5)
-            z = (xts[idx] - mu) / sig
-            zs[idx] = z
-            xts[idx] = mu + sig * z
+                e_u = e_c = self.unet.forward_raw(xt.contiguous(), t, ctx)
+            eta_i = float(eta[idx]) if isinstance(eta, (list, tuple)) else float(eta)      # etas[idx], ddpm_inversion.py:152-161
+            coef = S.step_coef(t, 0, eta_i, False, (cfg_src, 0.0, 0.0), coeff=0.0)
+            _lib.check(self.lib.hedit_step_invert(_lib.ptr(e_u), _lib.ptr(e_c), _lib.ptr(xt), _lib.ptr(xts[idx]),
+                                                  _lib.ptr(zs[idx]), n, elems, C.byref(coef), _lib.cur_stream()))
+        if return_noise:
+            return zs, xts, nzs
         return zs, xts
 
     # ------------------------------------------------------------------ DDIM inversion (h-Edit-D)

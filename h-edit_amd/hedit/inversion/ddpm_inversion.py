@@ -30,10 +30,15 @@ def inversion_forward_process_ddpm(model, x0, etas=None, prog_bar=True, prompt="
     `noise` (T+1,C,H,W) lets the caller fix the forward-process noise (parity tests)."""
     if etas is None or (type(etas) in [int, float] and etas == 0):
         raise AssertionError("eta must be > 0 for DDPM inversion")   # reference: assert not eta_is_zero
-    eta = float(etas) if type(etas) in [int, float] else float(etas[0])
+    if type(etas) in [int, float]:
+        eta = float(etas)
+    else:
+        assert len(etas) == num_inference_steps
+        eta = [float(e) for e in etas]        # etas[idx], as the reference indexes them (ddpm_inversion.py:152-161)
     assert model.scheduler.num_inference_steps == num_inference_steps
     eng = HEditEngine(model)
     x = x0 if x0.dim() == 4 else x0[None]
     nz = None if noise is None else noise[:, None]
-    zs, xts = eng.ddpm_inversion(x, [prompt], eta=eta, cfg_src=cfg_scale_src, noise=nz, generator=generator)
-    return xts[1], zs[:, 0], xts[:, 0], nz
+    zs, xts, noise_added = eng.ddpm_inversion(x, [prompt], eta=eta, cfg_src=cfg_scale_src, noise=nz, generator=generator,
+                                              return_noise=True)
+    return xts[1], zs[:, 0], xts[:, 0], noise_added[:, 0]

@@ -17,7 +17,8 @@ def _common(model, xT, eta, prompts, cfg_scales, zs):
     assert len(cfg_scales) == 3, "cfg_scales = [w_src, w_src_edit, w_tar]"
     x = xT.unsqueeze(0) if xT.dim() < 4 else xT
     z = None if zs is None else zs[:, None]          # (T',1,C,H,W)
-    return float(etas[0]), x, z
+    etas = [float(e) for e in etas]
+    return (etas[0] if all(e == etas[0] for e in etas) else etas), x, z
 
 
 def h_Edit_R_explicit(model, xT, eta=1.0, prompts="", cfg_scales=None, prog_bar=False, zs=None, controller=None,

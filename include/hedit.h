@@ -13,6 +13,10 @@
  *                           text-guided/p2p/ptp_classes.py:91-108,135-150,202-227)
  *   hedit_step_base         replaces  CFG mix + reverse_step  (p2p_h_edit.py:614-622 /
  *                                     inversion/inversion_utils.py:84-119)
+ *   hedit_step_invert       replaces  one step of the edit-friendly DDPM inversion: z_t = (x_{t-1} - mu_t) / sigma_t and
+ *                                     the in-place rewrite x_{t-1} <- mu_t + sigma_t z_t
+ *                                     (text-guided/inversion/ddpm_inversion.py:146-162), with hedit_step_base's
+ *                                     mu so that the sampler's reconstruction branch retraces it bit for bit
  *   hedit_step_update       replaces  the three CFG mixes, correction, L1 reconstruction pull with
  *                                     its two .item() syncs, and the x_{t-1} update
  *                                     (p2p_h_edit.py:654-692; twins :317-353, :494-514, :125-147)
@@ -148,6 +152,10 @@ int hedit_prof_collect(hedit_unet* h, int kind, double* total_ms, double* total_
  *   [n_img][2][heads][256][77]; alpha_layers [n_img][2][77]; enabled [n_img] or NULL. */
 int hedit_step_base(const float* eps, const float* xt, const float* z, float* x_prev, int n_img,
                     int elems, int eps_rows_per_img, const hedit_step_coef* c, void* stream);
+/* inversion step: e_u, e_c, xt, x_prev (in/out), z_out: [n_img][elems]; sigma = c->noise_coef > 0; the CFG mix
+ * uses c->w_src (pass e_c = e_u for an unconditional inversion). */
+int hedit_step_invert(const float* e_u, const float* e_c, const float* xt, float* x_prev, float* z_out,
+                      int n_img, int elems, const hedit_step_coef* c, void* stream);
 int hedit_step_update(const float* e_u_src, const float* e_c_src, const float* e_u_tar,
                       const float* e_c_tar, int64_t stride_img, const float* x_k,
                       const float* x_base, float* x_out, int n_img, int elems, int k_gt0,
@@ -223,6 +231,14 @@ int hedit_vae_encode(hedit_vae* h, const float* image, int B, int height, int wi
  * 2x nearest-upsampled input.  bf16 in/out.  splits: 0 = auto.  partial_ws may be NULL if the
  * call resolves to one split (query with hedit_k_gemm_ws_bytes). */
 size_t hedit_k_gemm_ws_bytes(int M, int N, int K, int splits);
+/* Batch-independent summation order.  The fp32 result of a contraction is DEFINED by a K-chunking that depends
+ * on the layer's nominal shape only (per-image extent x 4 on the batch dimension): chunk sums are MFMA chains,
+ * added in order.  hedit_k_gemm_canonical_chunk returns the chunk length in 64-deep K-tiles (0 = one chain);
+ * hedit_k_gemm_plan_splits how many split-K slabs a launch of the ACTUAL shape uses to execute it (1 = chunks
+ * folded in registers).  Both forms give the same bits, which hedit_k_gemm exposes for the tests:
+ * splits > 0: that many slabs + reduce; splits < 0: the same chunking folded in one launch; 0: one plain chain. */
+int hedit_k_gemm_canonical_chunk(int M_nominal, int N_nominal, int K);
+int hedit_k_gemm_plan_splits(int M, int N, int K, int chunk_kt);
 int hedit_k_gemm(const void* A, const void* W, const float* bias, const void* residual, void* C,
                  int M, int N, int K, int lda, int ldc, int ldr, int mode, int Hin, int Win,
                  int Cin, int Hout, int Wout, int splits, void* partial_ws, void* stream);

@@ -1,0 +1,255 @@
+"""-m gpu: batch invariance and the reconstruction invariant.
+
+The reference evaluates one image at a time, so "the same row gives the same eps whoever else is in the
+batch" holds trivially there, and with it the invariant of SURVEY.md section 4.1: the x^orig branch of the
+sampler retraces the edit-friendly inversion (text-guided/inversion/ddpm_inversion.py:146-162 <->
+inversion_utils.py:84-119) and ends on the inverted latent.  The lock-step engine runs inversion with 2n-row
+UNet calls and the loop with 4n / 5n-row calls, so the property has to be built into the kernels: every fp32
+summation order (split-K chunking, GroupNorm slabs) is a function of the layer, never of the batch.  These
+tests assert BIT equality, at SD-1.5 shape too."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import gpu as G  # noqa: E402
+from helpers.models import make_pair  # noqa: E402
+from helpers.tiny import PROMPT_PAIRS  # noqa: E402
+from hedit import _lib  # noqa: E402
+from hedit.unet import SD15_CONFIG, TINY_CONFIG  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return _lib.lib()
+
+
+def _gemm(lib, A, W, bias, res, M, N, K, lda, mode, conv, splits):
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=G.dev())
+    ws = torch.empty(max(lib.hedit_k_gemm_ws_bytes(M, N, K, abs(splits)), 16), dtype=torch.uint8, device=G.dev())
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(out), M, N, K,
+                                lda, N, N, mode, *conv, splits, _lib.ptr(ws), None))
+    G.sync()
+    return out
+
+
+@pytest.mark.parametrize("M,N,K,S", [(256, 1280, 11520, 16), (320, 640, 5760, 4), (200, 132, 1280, 3),
+                                     (7680, 1280, 2560, 5), (64, 320, 1280, 2), (1024, 160, 2880, 7)])
+def test_chunks_folded_in_registers_equal_split_k_slabs(lib, M, N, K, S):
+    """the canonical K-chunking executed as S slabs + reduce (small launches) and folded in registers by one
+    launch (large ones): the same bits, with bias and residual, both tile shapes"""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = G.bf(torch.randn(M, K, generator=g))
+    W = G.bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = G.f32(torch.randn(N, generator=g))
+    res = G.bf(torch.randn(M, N, generator=g))
+    for b, r in ((bias, res), (None, None), (bias, None)):
+        split = _gemm(lib, A, W, b, r, M, N, K, K, 0, (0, 0, 0, 0, 0), S)
+        fold = _gemm(lib, A, W, b, r, M, N, K, K, 0, (0, 0, 0, 0, 0), -S)
+        assert torch.equal(split, fold)
+    want = A.float() @ W.float().t() + bias + res.float()
+    assert G.rel_err(fold.float(), want) < 6e-3
+
+
+@pytest.mark.parametrize("mode,B,H,Wd,Cin,Cout,S", [(1, 2, 8, 8, 1280, 1280, 16), (1, 3, 16, 16, 640, 1280, 6),
+                                                     (2, 2, 16, 16, 320, 320, 4), (3, 2, 8, 8, 1280, 1280, 9)])
+def test_conv_chunks_folded_equal_slabs(lib, mode, B, H, Wd, Cin, Cout, S):
+    g = torch.Generator().manual_seed(mode * 1000 + Cin + Cout)
+    x = torch.randn(B, H, Wd, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = G.f32(torch.randn(Cout, generator=g))
+    xb = G.bf(x)
+    wq = torch.empty(Cout * 9 * Cin, dtype=torch.bfloat16, device=G.dev())
+    _lib.check(lib.hedit_k_pack_conv3x3(_lib.ptr(G.f32(w)), _lib.ptr(wq), Cout, Cin, None))
+    Ho, Wo = (H // 2, Wd // 2) if mode == 2 else ((2 * H, 2 * Wd) if mode == 3 else (H, Wd))
+    M = B * Ho * Wo
+    res = G.bf(torch.randn(M, Cout, generator=g))
+    split = _gemm(lib, xb, wq, bias, res, M, Cout, 9 * Cin, Cin, mode, (H, Wd, Cin, Ho, Wo), S)
+    fold = _gemm(lib, xb, wq, bias, res, M, Cout, 9 * Cin, Cin, mode, (H, Wd, Cin, Ho, Wo), -S)
+    assert torch.equal(split, fold)
+
+
+def test_canonical_chunking_ignores_the_batch(lib):
+    """the chunk length comes from the nominal shape; the slab count of a launch only decides HOW it runs"""
+    for (hw, n, k) in [(64, 1280, 11520), (256, 1280, 23040), (1024, 640, 5760), (4096, 320, 2880), (64, 1280, 1280)]:
+        chunk = lib.hedit_k_gemm_canonical_chunk(hw * 4, n, k)
+        kt = k // 64
+        for B in (1, 2, 5, 24, 120):
+            s = lib.hedit_k_gemm_plan_splits(hw * B, n, k, chunk)
+            assert s == 1 or (chunk > 0 and s == -(-kt // chunk))
+    assert lib.hedit_k_gemm_canonical_chunk(64 * 4, 1280, 11520) > 0          # the 8x8 level is chunked
+    assert lib.hedit_k_gemm_plan_splits(64 * 120, 1280, 11520, 12) == 1        # folded in registers at 120 rows
+    assert lib.hedit_k_gemm_plan_splits(64 * 5, 1280, 11520, 12) == 15         # slabs at 5 rows
+
+
+@pytest.mark.parametrize("HW,C", [(4096, 320), (1024, 640), (64, 1280), (256, 1920), (1024, 960)])
+def test_groupnorm_is_batch_invariant(lib, HW, C):
+    g = torch.Generator().manual_seed(HW + C)
+    B = 7
+    x = G.bf(torch.randn(B, HW, C, generator=g) * 1.7 + 0.3)
+    gamma, beta = G.f32(torch.randn(C, generator=g)), G.f32(torch.randn(C, generator=g))
+
+    def run(xx):
+        b = xx.shape[0]
+        y = torch.empty_like(xx)
+        ws = torch.empty(lib.hedit_k_groupnorm_ws_bytes(b, HW, C), dtype=torch.uint8, device=G.dev())
+        _lib.check(lib.hedit_k_groupnorm(_lib.ptr(xx), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), b, HW, C, 32, 1e-5, 1,
+                                         _lib.ptr(ws), None))
+        G.sync()
+        return y
+    full = run(x)
+    for i in (0, 3, 6):
+        assert torch.equal(full[i:i + 1], run(x[i:i + 1].contiguous()))
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return make_pair(TINY_CONFIG, 10)
+
+
+def _inputs(B, cfg, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 4, cfg["sample_size"], cfg["sample_size"], generator=g)
+    ctx = torch.randn(B, 77, cfg["cross_attention_dim"], generator=g)
+    return G.f32(x), G.f32(ctx)
+
+
+def test_tiny_unet_rows_are_bitwise_batch_invariant(tiny):
+    hip, _, _ = tiny
+    x, ctx = _inputs(23, TINY_CONFIG, 33)
+    kw = {"use_controller": False}
+    full = hip.unet(x, 401, encoder_hidden_states=ctx, cross_attention_kwargs=kw).sample
+    for rows in ([3], [0, 22], [5, 6, 7, 8, 9]):
+        part = hip.unet(x[rows].contiguous(), 401, encoder_hidden_states=ctx[rows].contiguous(), cross_attention_kwargs=kw).sample
+        G.sync()
+        assert torch.equal(full[rows], part)
+
+
+@pytest.fixture(scope="module")
+def sd15():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return make_pair(SD15_CONFIG, 2, seed=3)
+
+
+def test_sd15_row_alone_equals_row_inside_120_row_batch(sd15):
+    """BASELINE.json's network, the bench's 120-row launch: row 77 evaluated alone, in a 2-row call (the
+    inversion's shape for one image) and in a 5-row call gives the SAME BITS as inside the 120-row batch"""
+    hip, _, _ = sd15
+    x, ctx = _inputs(120, SD15_CONFIG, 5)
+    kw = {"use_controller": False}
+    full = hip.unet(x, 481, encoder_hidden_states=ctx, cross_attention_kwargs=kw).sample
+    G.sync()
+    assert torch.isfinite(full).all()
+    for rows in ([77], [77, 3], [0, 119, 77, 5, 60]):
+        part = hip.unet(x[rows].contiguous(), 481, encoder_hidden_states=ctx[rows].contiguous(), cross_attention_kwargs=kw).sample
+        G.sync()
+        assert torch.equal(full[rows], part), rows
+
+
+def _batch_controller(hip, pairs, T, K=1):
+    from hedit.p2p import ptp_controller_utils as PCU
+    from hedit.p2p.ptp_classes import ControllerBatch
+    from hedit.p2p.ptp_utils import register_attention_control
+    ctrls = []
+    for (s_, t_, bw, is_replace) in pairs:
+        ctrls.append(PCU.make_controller(prompts=[s_, t_], is_replace_controller=is_replace, cross_replace_steps=0.4,
+                                         self_replace_steps=0.35, blend_word=((bw[0],), (bw[1],)) if bw else None,
+                                         equilizer_params={"words": (bw[1],), "values": (2.0 if K == 1 else 1.25,)} if bw else None,
+                                         num_steps=T, tokenizer=hip.tokenizer, device=hip.device))
+    cb = ControllerBatch(ctrls)
+    register_attention_control(hip, cb)
+    return cb
+
+
+def _recon_run(hip, cfg, n, T, K, seed, fuse):
+    from hedit.engine import HEditEngine
+    hip.scheduler.set_timesteps(T)
+    eng = HEditEngine(hip)
+    pairs = [PROMPT_PAIRS[i % len(PROMPT_PAIRS)] for i in range(n)]
+    prompt_pairs = [[p[0], p[1]] for p in pairs]
+    S = cfg["sample_size"]
+    w0 = torch.stack([torch.randn(4, S, S, generator=torch.Generator().manual_seed(seed + i)) * 0.8 for i in range(n)]).to(G.dev())
+    gen = torch.Generator(device=G.dev()).manual_seed(seed)
+    zs, xts = eng.ddpm_inversion(w0, [p[0] for p in prompt_pairs], eta=1.0, cfg_src=1.0, generator=gen)
+    cb = _batch_controller(hip, pairs, T, K)
+    edit, recon = eng.run(xts[T].contiguous(), zs, prompt_pairs, [1.0, 5.0, 7.5], cb, eta=1.0, p2p=True, implicit=True, K=K,
+                          w_rec=0.1, after_skip_steps=T, ddim_inv=False, fuse_src_pass=fuse)
+    G.sync()
+    return w0, xts, edit, recon
+
+
+@pytest.mark.parametrize("n,K,fuse", [(1, 1, False), (3, 2, True), (5, 1, True)])
+def test_reconstruction_branch_retraces_the_inversion_bit_for_bit(tiny, n, K, fuse):
+    """full-gain random network, 10 steps: inversion in 2n-row calls, loop in 4n / 5n / n-row calls"""
+    hip, _, _ = tiny
+    w0, xts, edit, recon = _recon_run(hip, TINY_CONFIG, n, 10, K, 40 + n, fuse)
+    assert torch.isfinite(edit).all()
+    assert torch.equal(recon, xts[0])
+    assert G.rel_err(recon, w0) < 2e-6            # the reference's figure for this invariant: 2.6e-6
+
+
+def test_sd15_reconstruction_invariant_50_steps(sd15):
+    """SD-1.5 shape, the bench's schedule (50 steps, K = 1, P2P + LocalBlend), 2 images in lock-step"""
+    hip, _, _ = sd15
+    try:
+        w0, xts, edit, recon = _recon_run(hip, SD15_CONFIG, 2, 50, 1, 7, True)
+    finally:
+        hip.scheduler.set_timesteps(2)
+    assert torch.isfinite(edit).all()
+    assert torch.equal(recon, xts[0])
+    assert G.rel_err(recon, w0) < 2e-6
+
+
+def test_sd15_two_step_loop_matches_oracle(sd15):
+    """loop-level parity at SD-1.5 shape: h_Edit_p2p_implicit, 2 steps (timesteps 501, 1), K = 1, Replace + Reweight +
+    LocalBlend, against oracle/loops.py (fp32 CPU) on the same weights and the same inversion noise: 22 oracle
+    sample-forwards.  Tolerance: one bf16 eps evaluation is < 3e-2 off the fp32 oracle (test_gpu_unet.py); two
+    chained steps at full output gain stay within 6e-2 on the edited latent and 2e-2 on the reconstruction."""
+    from oracle import loops as OL
+    from oracle import p2p as OP
+    from hedit.inversion import p2p_h_edit as HE
+    from hedit.inversion.ddpm_inversion import inversion_forward_process_ddpm
+    from hedit.p2p import ptp_controller_utils as PCU
+    from hedit.p2p.ptp_utils import register_attention_control
+    hip, om, _ = sd15
+    T = 2
+    src, tar, blend, is_replace = PROMPT_PAIRS[0]
+    torch.manual_seed(11)
+    w0 = torch.randn(1, 4, 64, 64) * 0.8
+    torch.manual_seed(100)
+    with torch.no_grad():
+        zs_o, wts_o, noise = OL.ddpm_inversion(om, w0, eta=1.0, prompt=src, cfg_src=1.0, T=T)
+    _, zs, wts, _ = inversion_forward_process_ddpm(hip, G.f32(w0), etas=1.0, prog_bar=False, prompt=src, cfg_scale_src=1.0,
+                                                   num_inference_steps=T, noise=G.f32(noise))
+    G.sync()
+    assert G.rel_err(wts, wts_o) < 1e-2
+    bw = ((blend[0],), (blend[1],))
+    eq = {"words": (blend[1],), "values": (2.0,)}
+    hc = PCU.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=bw, equilizer_params=eq, num_steps=T,
+                             tokenizer=hip.tokenizer, device=hip.device)
+    oc = OP.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=bw, eq_params=eq, num_steps=T, tok=om.tokenizer)
+    register_attention_control(hip, hc)
+    OP.register(om, oc)
+    kw = dict(eta=1.0, prompts=[src, tar], cfg_scales=[1.0, 5.0, 7.5], after_skip_steps=T, is_ddim_inversion=False,
+              weight_reconstruction=0.1, optimization_steps=1)
+    try:
+        with torch.no_grad():
+            e_o, r_o = OL.h_edit_p2p_implicit(om, xT=wts_o[T], zs=zs_o[:T], controller=oc, **kw)
+        # the HIP loop on the ORACLE's inversion outputs: isolates the loop from the inversion's own rounding
+        e_h, r_h = HE.h_Edit_p2p_implicit(hip, xT=G.f32(wts_o[T]), zs=G.f32(zs_o[:T]), controller=hc, prog_bar=False, **kw)
+        G.sync()
+    finally:
+        from hedit.unet import AttnProcessor
+        hip.unet.set_attn_processor({k: AttnProcessor() for k in hip.unet.attn_processors})
+        from oracle.sd_unet import PlainProcessor
+        om.unet.set_attn_processor({k: PlainProcessor() for k in om.unet.attn_processors})
+    assert hc.cur_step == oc.cur_step
+    assert G.rel_err(r_h, r_o) < 2e-2, G.rel_err(r_h, r_o)
+    assert G.rel_err(e_h, e_o) < 6e-2, G.rel_err(e_h, e_o)
