@@ -47,7 +47,7 @@ def test_chunks_folded_in_registers_equal_split_k_slabs(lib, M, N, K, S):
     W = G.bf(torch.randn(N, K, generator=g) / math.sqrt(K))
     bias = G.f32(torch.randn(N, generator=g))
     res = G.bf(torch.randn(M, N, generator=g))
-    for b, r in ((bias, res), (None, None), (bias, None)):
+    for b, r in ((None, None), (bias, None), (bias, res)):
         split = _gemm(lib, A, W, b, r, M, N, K, K, 0, (0, 0, 0, 0, 0), S)
         fold = _gemm(lib, A, W, b, r, M, N, K, K, 0, (0, 0, 0, 0, 0), -S)
         assert torch.equal(split, fold)
