@@ -62,6 +62,8 @@ def parse():
                          "as n extra rows of the P2P pass (same arithmetic either way)")
     ap.add_argument("--force-dist", action="store_true", help="init the RCCL process group even for one rank")
     ap.add_argument("--no-single", action="store_true", help="skip the auxiliary one-image latency measurement")
+    ap.add_argument("--no-config2", action="store_true",
+                    help="skip the auxiliary BASELINE configs[2] block (32 images in lock-step, K = 3; one pass after the timed region)")
     ap.add_argument("--reuse-orig-eps", action="store_true",
                     help="opt-in: reuse eps(x_orig, t-1, {null,src}) of the P2P pass in the next base pass "
                          "(7 instead of 9 sample-forwards per step; NOT the reference's evaluation count)")
@@ -215,35 +217,61 @@ def main():
     model.scheduler.set_timesteps(T)
     eng = HEditEngine(model)
 
-    n = args.images
     S = cfg["sample_size"]
-    pairs = [DEMO_PAIRS[(rank * n + i) % len(DEMO_PAIRS)] for i in range(n)]
-    prompt_pairs = [[p[0], p[1]] for p in pairs]
-    w0 = torch.stack([torch.randn(4, S, S, generator=torch.Generator().manual_seed(1 + rank * n + i)) * 0.8
-                      for i in range(n)]).to(dev)
+    cfg_scales = [1.0, 5.0, 7.5]
     with torch.no_grad():
         null = eng.encode([""])
-        src = eng.encode([p[0] for p in prompt_pairs])
-        tar = eng.encode([p[1] for p in prompt_pairs])
-    # step before the path (not timed): edit-friendly DDPM inversion on the same kernels
-    g = torch.Generator(device=dev).manual_seed(3 + rank)
-    t_i0 = time.time()
-    zs, xts = eng.ddpm_inversion(w0, [p[0] for p in prompt_pairs], eta=1.0, cfg_src=1.0, generator=g)
-    torch.cuda.synchronize()
-    t_inversion = time.time() - t_i0
-    xT = xts[T].contiguous()
-    cfg_scales = [1.0, 5.0, 7.5]
-    K = args.opt_steps
 
-    def make_batch_controller():
-        ctrls = []
-        for (s_, t_, bw, is_replace) in pairs:
-            ctrls.append(PCU.make_controller(
-                prompts=[s_, t_], is_replace_controller=is_replace, cross_replace_steps=0.4,
-                self_replace_steps=0.35, blend_word=((bw[0],), (bw[1],)),
-                equilizer_params={"words": (bw[1],), "values": (2.0 if K == 1 else 1.25,)},
-                num_steps=T, tokenizer=tok, device=dev))
-        return ControllerBatch(ctrls)
+    def build_workload(n, K, seed_off=0):
+        """n images in lock-step with K implicit steps: inverted latents / noise maps / embeddings resident in HBM,
+        returns (one_step, w0, t_inversion).  DDPM inversion = the step BEFORE the path, not timed."""
+        pairs = [DEMO_PAIRS[(rank * n + i) % len(DEMO_PAIRS)] for i in range(n)]
+        prompt_pairs = [[p[0], p[1]] for p in pairs]
+        w0 = torch.stack([torch.randn(4, S, S, generator=torch.Generator().manual_seed(1 + seed_off + rank * n + i)) * 0.8
+                          for i in range(n)]).to(dev)
+        with torch.no_grad():
+            src = eng.encode([p[0] for p in prompt_pairs])
+            tar = eng.encode([p[1] for p in prompt_pairs])
+        g = torch.Generator(device=dev).manual_seed(3 + seed_off + rank)
+        t_i0 = time.time()
+        zs, xts = eng.ddpm_inversion(w0, [p[0] for p in prompt_pairs], eta=1.0, cfg_src=1.0, generator=g)
+        torch.cuda.synchronize()
+        t_inv = time.time() - t_i0
+        xT = xts[T].contiguous()
+
+        def make_batch_controller():
+            ctrls = []
+            for (s_, t_, bw, is_replace) in pairs:
+                ctrls.append(PCU.make_controller(
+                    prompts=[s_, t_], is_replace_controller=is_replace, cross_replace_steps=0.4,
+                    self_replace_steps=0.35, blend_word=((bw[0],), (bw[1],)),
+                    equilizer_params={"words": (bw[1],), "values": (2.0 if K == 1 else 1.25,)},
+                    num_steps=T, tokenizer=tok, device=dev))
+            return ControllerBatch(ctrls)
+
+        def one_step():
+            cb = make_batch_controller()
+            register_attention_control(model, cb)
+            return eng.run(xT, zs, prompt_pairs, cfg_scales, cb, eta=1.0, p2p=True, implicit=True, K=K, w_rec=0.1,
+                           after_skip_steps=T, ddim_inv=False, ctx=(null, src, tar), fuse_src_pass=not args.no_fuse_src,
+                           reuse_orig_eps=args.reuse_orig_eps, style=style)
+
+        def one_image():
+            c1 = PCU.make_controller(prompts=list(prompt_pairs[0]), is_replace_controller=pairs[0][3],
+                                     cross_replace_steps=0.4, self_replace_steps=0.35,
+                                     blend_word=((pairs[0][2][0],), (pairs[0][2][1],)),
+                                     equilizer_params={"words": (pairs[0][2][1],), "values": (2.0 if K == 1 else 1.25,)},
+                                     num_steps=T, tokenizer=tok, device=dev)
+            register_attention_control(model, c1)
+            return eng.run(xT[:1], zs[:, :1].contiguous(), prompt_pairs[:1], cfg_scales, c1, eta=1.0, p2p=True,
+                           implicit=True, K=K, w_rec=0.1, after_skip_steps=T, ddim_inv=False,
+                           ctx=(null, src[:1], tar[:1]), fuse_src_pass=not args.no_fuse_src,
+                           reuse_orig_eps=args.reuse_orig_eps)
+        return one_step, one_image, w0, t_inv
+
+    n = args.images
+    K = args.opt_steps
+    one_step_raw, one_image, w0, t_inversion = build_workload(n, K)
 
     # sampled launch timing: bracket every prof_every-th UNet call with HIP event pairs
     calls = {"n": 0}
@@ -264,12 +292,7 @@ def main():
     unet.prof_enable(True, 16384)        # allocate the event pool outside the timed region
     unet.prof_enable(False, 16384)
 
-    def one_step():
-        cb = make_batch_controller()
-        register_attention_control(model, cb)
-        return eng.run(xT, zs, prompt_pairs, cfg_scales, cb, eta=1.0, p2p=True, implicit=True, K=K, w_rec=0.1,
-                       after_skip_steps=T, ddim_inv=False, ctx=(null, src, tar), fuse_src_pass=not args.no_fuse_src,
-                       reuse_orig_eps=args.reuse_orig_eps, style=style)
+    one_step = one_step_raw
 
     for _ in range(args.warmup):
         one_step()
@@ -297,23 +320,34 @@ def main():
     # auxiliary (outside the timed region): BASELINE configs[1] read literally = ONE image; latency
     single_s = None
     if not args.no_single and style is None:
-        def one_image():
-            c1 = PCU.make_controller(prompts=list(prompt_pairs[0]), is_replace_controller=pairs[0][3],
-                                     cross_replace_steps=0.4, self_replace_steps=0.35,
-                                     blend_word=((pairs[0][2][0],), (pairs[0][2][1],)),
-                                     equilizer_params={"words": (pairs[0][2][1],), "values": (2.0 if K == 1 else 1.25,)},
-                                     num_steps=T, tokenizer=tok, device=dev)
-            register_attention_control(model, c1)
-            return eng.run(xT[:1], zs[:, :1].contiguous(), prompt_pairs[:1], cfg_scales, c1, eta=1.0, p2p=True,
-                           implicit=True, K=K, w_rec=0.1, after_skip_steps=T, ddim_inv=False,
-                           ctx=(null, src[:1], tar[:1]), fuse_src_pass=not args.no_fuse_src,
-                           reuse_orig_eps=args.reuse_orig_eps)
         one_image()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         one_image()
         torch.cuda.synchronize()
         single_s = time.perf_counter() - t1
+
+    # auxiliary (outside the timed region): BASELINE configs[2] = 32 images in lock-step, 50 steps x K = 3
+    # (text-guided/main_p2p.py:65 optimization_steps 3: (4 + 5*3) * 50 = 950 sample-forwards per image), ONE pass
+    config2 = None
+    if not args.no_config2 and style is None and not args.tiny and K == 1 and world == 1:
+        n2, K2 = 32, 3
+        step2, _, w02, t_inv2 = build_workload(n2, K2, seed_off=1000)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        e2, r2 = step2()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        fwd2 = (4 + 5 * K2) * T
+        config2 = {"workload": f"BASELINE configs[2]: the same loop, {n2} images in lock-step, {T} steps x K={K2} implicit steps "
+                               f"({fwd2} sample-forwards per image), equalizer 1.25; one pass, kernels warm",
+                   "value": round(n2 / dt2, 4), "unit": "images/s", "ms_per_step": round(1e3 * dt2, 1),
+                   "achieved_tflops_per_s": round(n2 * fwd2 * FLOP_PER_SAMPLE_FWD / dt2 / 1e12, 1),
+                   "mfma_frac_whole_loop": round(n2 * fwd2 * FLOP_PER_SAMPLE_FWD / dt2 / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                   "finite": bool(torch.isfinite(e2).all()),
+                   "recon_rel_err": round(float(((r2 - w02).norm() / w02.norm()).item()), 7),
+                   "ddpm_inversion_untimed_s": round(t_inv2, 2)}
+        del step2, e2, r2, w02
 
     finite = bool(torch.isfinite(edit).all())
     recon_err = float(((recon - w0).norm() / w0.norm()).item())
@@ -348,16 +382,30 @@ def main():
             "alg_flops_per_launch": round(dfl / max(dcnt, 1), 0),
             "share_of_sampled_time": round(dms / sampled_ms, 4) if sampled_ms > 0 else None,
             "traffic": None}
+    # roofline.traffic = HBM bytes per launch of that class from the PMC counters (tools/pmc_traffic.sh: two separate
+    # rocprofv3 --pmc passes of THIS bench configuration, FETCH_SIZE doubled as the micro-arch guide prescribes).
+    # A summary taken at another configuration is refused (traffic stays null).
+    alg_bytes = unet.prof_collect_bytes()
+    roof["alg_bytes_per_launch"] = round(alg_bytes.get(dk, 0.0) / max(dcnt, 1), 0)
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    want_cfg = {"workload": args.workload, "images_per_gpu": n, "opt_steps": K, "fuse_src_pass": not args.no_fuse_src,
+                "reuse_orig_eps": bool(args.reuse_orig_eps), "tiny": bool(args.tiny)}
     if os.path.exists(pmc):
         try:
-            roof["traffic"] = json.load(open(pmc)).get(dk, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+            summ = json.load(open(pmc))
+            if summ.get("config") == want_cfg:
+                roof["traffic"] = summ["classes"].get(dk, {}).get("hbm_bytes_per_launch")
+                roof["traffic_source"] = "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this configuration)"
+                if roof["traffic"] and roof["alg_bytes_per_launch"]:
+                    roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["alg_bytes_per_launch"], 3)
+            else:
+                roof["traffic_source"] = "profiles/pmc_summary.json was measured at another configuration: refused"
+        except Exception as e:      # a malformed summary must not kill the bench line
+            roof["traffic_source"] = f"profiles/pmc_summary.json unreadable: {e}"
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline and not args.tiny and style is None:
-        cpu = cpu_baseline(cfg, sd_cpu, T, K)
+        cpu = cpu_baseline(cfg, sd_cpu, T, K, tok)
 
     out = {
         "metric": "edited images/sec (512^2, 50 steps, K Langevin)" + (" + style guidance" if style else ""), "value": round(imgs / elapsed, 4),
@@ -375,7 +423,8 @@ def main():
                    "images_per_gpu": n, "unet_sample_forwards_per_image": sample_fwd_per_img,
                    "unet_sample_forwards_evaluated_per_image": evaluated_per_img,
                    "reuse_orig_eps": bool(args.reuse_orig_eps),
-                   "unet_calls_in_timed_region": unet_calls, "parallelism": f"replica-dp{world}"},
+                   "unet_calls_in_timed_region": unet_calls, "parallelism": f"replica-dp{world}",
+                   "pmc_config": want_cfg},
         "achieved_tflops_per_s_per_gpu": round(total_flops / elapsed / 1e12 / world, 1),
         "mfma_frac_whole_loop": round(total_flops / elapsed / 1e12 / world / MFMA_PEAK_TFLOPS, 4),
         "ms_per_unet_sample_forward": round(1e3 * elapsed * world / (imgs * evaluated_per_img), 4),
@@ -383,7 +432,8 @@ def main():
         "single_image": None if single_s is None else {"latency_s": round(single_s, 4), "images_per_s": round(1.0 / single_s, 4),
                                                         "note": "configs[1] read literally (1 image, 450 sample-forwards), "
                                                                 "measured after the timed region"},
-        "finite": finite, "recon_rel_err": round(recon_err, 5),
+        "configs2": config2,
+        "finite": finite, "recon_rel_err": round(recon_err, 7),
         "setup_s": {"weights_create_broadcast_load": round(t_weights, 1), "ddpm_inversion_untimed": round(t_inversion, 2)},
     }
     print(json.dumps(out))
@@ -391,33 +441,51 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(cfg, sd_cpu, T, K):
-    """The oracle (CPU fp32 eager restatement = "port" of the reference's CPU path) timed on this
-    box's host cores on a bounded sample of the same workload: ONE base pass of one image
-    (4 UNet sample-forwards of the 450 an image needs)."""
+def cpu_baseline(cfg, sd_cpu, T, K, tok):
+    """The oracle (CPU fp32 eager restatement = "port" of the reference's CPU path, oracle/loops.py + oracle/p2p.py +
+    oracle/sd_unet.py) timed on this box's host cores on a bounded sample of the same workload: ONE complete
+    sampler step of one image in the REFERENCE'S loop shape (text-guided/inversion/p2p_h_edit.py:599-699) -- the
+    4-row base pass, the 1-row source pass and the 4-row P2P pass with the Python controller mutating materialised
+    attention probabilities, plus the step algebra and LocalBlend = 9 of the (4 + 5K) * T sample-forwards."""
+    import types
     sys.path.insert(0, ROOT)
+    from oracle import loops as OL
+    from oracle import p2p as OP
     from oracle import sd_unet as OU
+    from hedit.scheduler import DDIMScheduler
+    from hedit.text import ClipTextEncoder
     net = OU.UNet2DConditionModel(**cfg)
     net.load_state_dict(sd_cpu)
     net.eval()
     for p in net.parameters():
         p.requires_grad_(False)
+    om = types.SimpleNamespace(device=torch.device("cpu"), unet=net, scheduler=DDIMScheduler(), tokenizer=tok, vae=None,
+                               text_encoder=ClipTextEncoder(dim=cfg["cross_attention_dim"], layers=12, heads=12, seed=7))
+    om.scheduler.set_timesteps(T)
+    src, tar, bw, is_replace = DEMO_PAIRS[0]
+    oc = OP.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=((bw[0],), (bw[1],)),
+                            eq_params={"words": (bw[1],), "values": (2.0 if K == 1 else 1.25,)}, num_steps=T, tok=tok)
+    OP.register(om, oc)
+    oc.cur_step = T - 1              # the last step of the schedule (cross window closed, LocalBlend active)
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(4, 4, cfg["sample_size"], cfg["sample_size"], generator=g)
-    ctx = torch.randn(4, 77, cfg["cross_attention_dim"], generator=g)
+    S = cfg["sample_size"]
+    x = torch.randn(1, 4, S, S, generator=g)
+    z = torch.randn(1, 1, 4, S, S, generator=g)
     threads = torch.get_num_threads()
     with torch.no_grad():
-        net(x[:1], torch.tensor(481), encoder_hidden_states=ctx[:1])      # warm-up (1 sample-forward)
+        net(x, torch.tensor(481), encoder_hidden_states=torch.randn(1, 77, cfg["cross_attention_dim"], generator=g))   # warm-up
         t0 = time.perf_counter()
-        net(x, torch.tensor(481), encoder_hidden_states=ctx)
+        OL.h_edit_p2p_implicit(om, xT=x, eta=1.0, prompts=[src, tar], cfg_scales=[1.0, 5.0, 7.5], zs=z[:, 0], controller=oc,
+                               weight_reconstruction=0.1, optimization_steps=1, after_skip_steps=1, is_ddim_inversion=False)
         dt = time.perf_counter() - t0
-    per_fwd = dt / 4
+    per_fwd = dt / 9
     per_img = per_fwd * (4 + 5 * K) * T
     return {"value": round(1.0 / per_img, 6), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"1 UNet call of 4 rows (4 of the {(4 + 5 * K) * T} sample-forwards of one image) by the "
-                      f"fp32 eager oracle on {threads} host threads = {dt:.2f} s; images/s extrapolated by "
-                      "sample-forward count",
-            "s_per_unet_sample_forward": round(per_fwd, 3)}
+            "sample": f"one full sampler step of one image in the reference's loop shape (4-row base pass + 1-row source pass + "
+                      f"4-row P2P pass with the Python controller = 9 of the {(4 + 5 * K) * T} sample-forwards of an image, step "
+                      f"algebra and LocalBlend included) by the fp32 eager oracle on {threads} host threads = {dt:.2f} s; "
+                      "images/s extrapolated by sample-forward count",
+            "s_per_sampler_step": round(dt, 2), "s_per_unet_sample_forward": round(per_fwd, 3)}
 
 
 if __name__ == "__main__":

@@ -76,7 +76,7 @@ struct hedit_unet {
   // sampled launch timing (bench.py roofline): HIP event pairs on the launch stream
   bool prof_on = false;
   std::vector<hipEvent_t> prof_pool;
-  struct ProfRec { int kind; double flops; int e0, e1; };
+  struct ProfRec { int kind; double flops, bytes; int e0, e1; };
   std::vector<ProfRec> prof_recs;
   size_t prof_next = 0;
 };
@@ -206,15 +206,16 @@ struct ProfScope {
   hedit_unet* h;
   hipStream_t st;
   int rec = -1;
-  ProfScope(Fwd& f, int kind, double flops);
+  ProfScope(Fwd& f, int kind, double flops, double bytes = 0.0);
   ~ProfScope() {
     if (rec >= 0) (void)hipEventRecord(h->prof_pool[h->prof_recs[rec].e1], st);
   }
 };
 
-ProfScope::ProfScope(Fwd& f, int kind, double flops) : h(f.h), st(f.st) {
+// bytes = ALGORITHMIC HBM bytes of the launch(es) in the scope: every operand read once, every result written once
+ProfScope::ProfScope(Fwd& f, int kind, double flops, double bytes) : h(f.h), st(f.st) {
   if (f.dry() || !h->prof_on || h->prof_next + 2 > h->prof_pool.size()) return;
-  hedit_unet::ProfRec r{kind, flops, (int)h->prof_next, (int)h->prof_next + 1};
+  hedit_unet::ProfRec r{kind, flops, bytes, (int)h->prof_next, (int)h->prof_next + 1};
   h->prof_next += 2;
   h->prof_recs.push_back(r);
   rec = (int)h->prof_recs.size() - 1;
@@ -234,6 +235,13 @@ int aalloc(Fwd& f, T** out, size_t n) {
 // batch_in: which extent of the GEMM carries the batch (1 = M, 2 = N, 0 = neither).  The K-chunking is taken from
 // the per-image extent times a fixed nominal batch, so the summation order of a layer is a property of the
 // layer, not of the launch (see gemm_canonical_chunk).
+// unique operand bytes + result bytes of one GEMM launch (bf16 operands; conv: the input image once, not nine times)
+double gemm_alg_bytes(const Fwd& f, const GemmParams& p) {
+  const double a = p.mode == 0 ? (double)p.M * p.K : (double)f.B * p.Hin * p.Win * p.Cin;
+  const double c = p.raw_f32 ? 4.0 * p.M * p.N : 2.0 * p.M * (p.geglu ? p.N / 2 : p.N);
+  return 2.0 * a + 2.0 * (double)p.N * p.K + c + (p.residual ? 2.0 * p.M * p.N : 0.0);
+}
+
 int run_gemm(Fwd& f, GemmParams p, int batch_in = 1) {
   if (!p.raw_f32 && !p.geglu) {
     const int mn = batch_in == 1 ? p.M / f.B * GEMM_NOMINAL_BATCH : p.M;
@@ -244,7 +252,7 @@ int run_gemm(Fwd& f, GemmParams p, int batch_in = 1) {
   float* part = nullptr;
   if (splits > 1) TRY(aalloc(f, &part, (size_t)splits * p.M * p.N));
   {
-    ProfScope ps(f, p.mode == 0 ? PK_LINEAR : PK_CONV, 2.0 * p.M * p.N * p.K);
+    ProfScope ps(f, p.mode == 0 ? PK_LINEAR : PK_CONV, 2.0 * p.M * p.N * p.K, gemm_alg_bytes(f, p));
     RUN(f, gemm_launch(p, splits, part, f.st));
   }
   if (part) f.ar.free(part);
@@ -275,7 +283,7 @@ int groupnorm(Fwd& f, const bf16_t* x, bf16_t* y, const float* g, const float* b
   float* ws;
   TRY(aalloc(f, &ws, groupnorm_ws_bytes(f.B, HW, C) / sizeof(float)));
   {
-    ProfScope ps(f, PK_NORM, 0.0);
+    ProfScope ps(f, PK_NORM, 0.0, 6.0 * f.B * (double)HW * C);
     RUN(f, groupnorm_launch(x, y, g, b, f.B, HW, C, f.h->cfg.norm_num_groups, eps, silu, ws, f.st));
   }
   f.ar.free(ws);
@@ -335,7 +343,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
 
   // ---- self-attention
   TRY(aalloc(f, &tn, M * C));
-  { ProfScope ps(f, PK_NORM, 0.0); RUN(f, layernorm_launch(t0, tn, a.ln1g, a.ln1b, (long)M, C, 1e-5f, f.st)); }
+  { ProfScope ps(f, PK_NORM, 0.0, 4.0 * M * C); RUN(f, layernorm_launch(t0, tn, a.ln1g, a.ln1b, (long)M, C, 1e-5f, f.st)); }
   TRY(aalloc(f, &qk, M * 2 * C));
   TRY(linear(f, tn, (int)M, C, a.w_qk, 2 * C, nullptr, nullptr, qk, 2 * C));
   TRY(aalloc(f, &vt, M * C));
@@ -350,7 +358,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
                     ? pl->qk_src : nullptr;
     sp.kv_src = (pl && pl->kv_src && f.tblock >= pl->kv_first_block) ? pl->kv_src : nullptr;
     ++f.tblock;
-    ProfScope ps(f, PK_SELF_ATTN, 4.0 * B * (double)N * N * C);
+    ProfScope ps(f, PK_SELF_ATTN, 4.0 * B * (double)N * N * C, 8.0 * M * C);      // q, k, v^T read, out written
     RUN(f, self_attn_launch(sp, f.st));
   }
   f.ar.free(qk);
@@ -362,7 +370,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
 
   // ---- cross-attention (P2P edits + store happen inside the kernel)
   TRY(aalloc(f, &tn, M * C));
-  { ProfScope ps(f, PK_NORM, 0.0); RUN(f, layernorm_launch(t1, tn, a.ln2g, a.ln2b, (long)M, C, 1e-5f, f.st)); }
+  { ProfScope ps(f, PK_NORM, 0.0, 4.0 * M * C); RUN(f, layernorm_launch(t1, tn, a.ln2g, a.ln2b, (long)M, C, 1e-5f, f.st)); }
   TRY(aalloc(f, &q2, M * C));
   TRY(linear(f, tn, (int)M, C, a.w_q2, C, nullptr, nullptr, q2, C));
   f.ar.free(tn);
@@ -386,7 +394,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
       cp.n_pairs = 0; cp.singles = f.h->iota; cp.n_single = B;
     }
     if (stored_layer) f.store_idx++;
-    ProfScope ps(f, PK_CROSS_ATTN, 4.0 * B * (double)N * HEDIT_MAXW * C);
+    ProfScope ps(f, PK_CROSS_ATTN, 4.0 * B * (double)N * HEDIT_MAXW * C, 4.0 * M * C + 4.0 * MC * C);
     RUN(f, cross_attn_launch(cp, f.st));
   }
   f.ar.free(q2);
@@ -399,13 +407,13 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
 
   // ---- GEGLU feed-forward
   TRY(aalloc(f, &tn, M * C));
-  { ProfScope ps(f, PK_NORM, 0.0); RUN(f, layernorm_launch(t2, tn, a.ln3g, a.ln3b, (long)M, C, 1e-5f, f.st)); }
+  { ProfScope ps(f, PK_NORM, 0.0, 4.0 * M * C); RUN(f, layernorm_launch(t2, tn, a.ln3g, a.ln3b, (long)M, C, 1e-5f, f.st)); }
   TRY(aalloc(f, &gf, M * 4 * C));
   {
     GemmParams gp{};
     gp.A = tn; gp.W = a.ff1; gp.M = (int)M; gp.N = 8 * C; gp.K = C; gp.lda = C; gp.mode = 0;
     gp.bias = a.ff1_b; gp.residual = nullptr; gp.ldr = 0; gp.C = gf; gp.ldc = 4 * C; gp.geglu = 1;
-    ProfScope ps(f, PK_LINEAR, 2.0 * gp.M * gp.N * gp.K);
+    ProfScope ps(f, PK_LINEAR, 2.0 * gp.M * gp.N * gp.K, gemm_alg_bytes(f, gp));
     RUN(f, gemm_launch(gp, 1, nullptr, f.st));
   }
   f.ar.free(tn);
@@ -833,6 +841,16 @@ int hedit_prof_collect(hedit_unet* h, int kind, double* total_ms, double* total_
     ++n;
   }
   *total_ms = ms; *total_flops = fl; *count = n;
+  return HEDIT_OK;
+} catch (...) { return hedit_abi_catch(); }
+
+/* algorithmic HBM bytes (operands read once, results written once) of the sampled launches of a class */
+int hedit_prof_collect_bytes(hedit_unet* h, int kind, double* total_bytes) try {
+  ARG_CHECK(h && total_bytes && kind >= 0 && kind < PK_COUNT, "prof args");
+  double b = 0;
+  for (auto& r : h->prof_recs)
+    if (r.kind == kind) b += r.bytes;
+  *total_bytes = b;
   return HEDIT_OK;
 } catch (...) { return hedit_abi_catch(); }
 

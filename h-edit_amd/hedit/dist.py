@@ -26,19 +26,31 @@ def shard(n_items, rank, world):
 
 
 def broadcast_state_dict(shapes, sd, src=0, device="cpu", group=None):
-    """Every rank returns the full {name: tensor} dict that rank `src` holds in `sd` (other ranks
-    pass None).  One broadcast per tensor, fp32, in the deterministic order of `shapes`."""
+    """Every rank returns the full {name: tensor} dict that rank `src` holds in `sd` (other ranks pass None).
+    ONE collective: the tensors are packed, in the deterministic order of `shapes`, into a single flat fp32
+    blob (3.4 GB for the SD-1.5 UNet: ~30 ms on an xGMI ring), broadcast once, and returned as views of it --
+    bit-identical weights on every rank, no per-tensor launches ("one broadcast per weight blob")."""
     rank = dist.get_rank(group)
-    out = {}
+    sizes = []
     for name, shape in shapes.items():
-        if rank == src:
-            t = sd[name].to(device=device, dtype=torch.float32).contiguous()
+        n = 1
+        for d in shape:
+            n *= int(d)
+        sizes.append(n)
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    if rank == src:
+        off = 0
+        for (name, shape), n in zip(shapes.items(), sizes):
+            t = sd[name]
             if tuple(t.shape) != tuple(shape):
                 raise ValueError(f"{name}: shape {tuple(t.shape)} != {tuple(shape)}")
-        else:
-            t = torch.empty(tuple(shape), dtype=torch.float32, device=device)
-        dist.broadcast(t, src=src, group=group)
-        out[name] = t
+            flat[off:off + n].copy_(t.reshape(-1).to(dtype=torch.float32))
+            off += n
+    dist.broadcast(flat, src=src, group=group)
+    out, off = {}, 0
+    for (name, shape), n in zip(shapes.items(), sizes):
+        out[name] = flat[off:off + n].view(tuple(shape))
+        off += n
     return out
 
 

@@ -229,6 +229,15 @@ class UNet2DConditionModel:
             out[k] = (ms.value, fl.value, n.value)
         return out
 
+    def prof_collect_bytes(self):
+        """{kind: algorithmic HBM bytes of the sampled launches} (operands read once, results written once)."""
+        out = {}
+        b = C.c_double()
+        for i, k in enumerate(self.PROF_KINDS):
+            _lib.check(self._lib.hedit_prof_collect_bytes(self._h, i, C.byref(b)))
+            out[k] = b.value
+        return out
+
     # ---------------------------------------------------------------- forward
     def forward_raw(self, sample, t, ctx, plan=None, out=None):
         """sample fp32 (B,C,H,W) cuda, t python float, ctx fp32 (B,77,D) cuda, plan: _lib.P2PPlan."""

@@ -140,6 +140,9 @@ int hedit_unet_store_layer_info(const hedit_unet* h, int height, int width, int 
 int hedit_prof_enable(hedit_unet* h, int on, int max_records);
 int hedit_prof_reset(hedit_unet* h);
 int hedit_prof_collect(hedit_unet* h, int kind, double* total_ms, double* total_flops, int64_t* count);
+/* algorithmic HBM bytes of the sampled launches of a class: every operand read once, every result written once
+ * (what roofline.traffic, a PMC measurement, is compared with) */
+int hedit_prof_collect_bytes(hedit_unet* h, int kind, double* total_bytes);
 
 /* ---- sampler steps ------------------------------------------------------------------------
  * Batched tensors are [row][image][elems]: for one image this is exactly the reference layout.

@@ -45,9 +45,18 @@ def read(dbpath, counter):
     return agg
 
 
+def bench_config(log):
+    """config.pmc_config of the bench JSON line in the profiled run's stdout"""
+    for line in reversed(open(log).read().splitlines()):
+        if line.startswith("{") and '"pmc_config"' in line:
+            return json.loads(line)["config"]["pmc_config"]
+    return None
+
+
 def main():
     fetch = read(sys.argv[1], "FETCH_SIZE")
     write = read(sys.argv[2], "WRITE_SIZE")
+    cfg = bench_config(sys.argv[3]) if len(sys.argv) > 3 else None
     out = {}
     for k in sorted(set(fetch) | set(write)):
         f, nf = fetch.get(k, [0.0, 0])
@@ -55,7 +64,8 @@ def main():
         n = max(nf, nw, 1)
         out[k] = {"launches": n, "fetch_kib_raw_per_launch": f / max(nf, 1), "write_kib_per_launch": w / max(nw, 1),
                   "hbm_bytes_per_launch": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0}
-    json.dump(out, sys.stdout, indent=1)
+    json.dump({"config": cfg, "counters": "rocprofv3 --pmc FETCH_SIZE (x2: gfx950 counts 128-B requests as 64 B) + WRITE_SIZE, KiB",
+               "classes": out}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
