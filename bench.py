@@ -441,7 +441,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(cfg, sd_cpu, T, K, tok):
+def cpu_baseline(cfg, sd_cpu, T, K, tok, text_layers=12, text_heads=12):
     """The oracle (CPU fp32 eager restatement = "port" of the reference's CPU path, oracle/loops.py + oracle/p2p.py +
     oracle/sd_unet.py) timed on this box's host cores on a bounded sample of the same workload: ONE complete
     sampler step of one image in the REFERENCE'S loop shape (text-guided/inversion/p2p_h_edit.py:599-699) -- the
@@ -460,13 +460,11 @@ def cpu_baseline(cfg, sd_cpu, T, K, tok):
     for p in net.parameters():
         p.requires_grad_(False)
     om = types.SimpleNamespace(device=torch.device("cpu"), unet=net, scheduler=DDIMScheduler(), tokenizer=tok, vae=None,
-                               text_encoder=ClipTextEncoder(dim=cfg["cross_attention_dim"], layers=12, heads=12, seed=7))
+                               text_encoder=ClipTextEncoder(dim=cfg["cross_attention_dim"], layers=text_layers, heads=text_heads, seed=7))
     om.scheduler.set_timesteps(T)
     src, tar, bw, is_replace = DEMO_PAIRS[0]
     oc = OP.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=((bw[0],), (bw[1],)),
                             eq_params={"words": (bw[1],), "values": (2.0 if K == 1 else 1.25,)}, num_steps=T, tok=tok)
-    OP.register(om, oc)
-    oc.cur_step = T - 1              # the last step of the schedule (cross window closed, LocalBlend active)
     g = torch.Generator().manual_seed(5)
     S = cfg["sample_size"]
     x = torch.randn(1, 4, S, S, generator=g)
@@ -474,6 +472,9 @@ def cpu_baseline(cfg, sd_cpu, T, K, tok):
     threads = torch.get_num_threads()
     with torch.no_grad():
         net(x, torch.tensor(481), encoder_hidden_states=torch.randn(1, 77, cfg["cross_attention_dim"], generator=g))   # warm-up
+    OP.register(om, oc)
+    oc.cur_step = T - 1              # the last step of the schedule (cross window closed, LocalBlend active)
+    with torch.no_grad():
         t0 = time.perf_counter()
         OL.h_edit_p2p_implicit(om, xT=x, eta=1.0, prompts=[src, tar], cfg_scales=[1.0, 5.0, 7.5], zs=z[:, 0], controller=oc,
                                weight_reconstruction=0.1, optimization_steps=1, after_skip_steps=1, is_ddim_inversion=False)
