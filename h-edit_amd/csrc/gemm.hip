@@ -666,6 +666,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < p.splits; ++s)
     v += *reinterpret_cast<const f32x4*>(p.partial + ((long)s * p.M + m) * p.N + n);
+  if (p.raw_f32) {      // plain fp32 products (precise-GEMM path of pnet.hip): no bias / residual / rounding
+    *reinterpret_cast<f32x4*>(p.raw_f32 + (long)m * p.N + n) = v;
+    return;
+  }
   f32x4 b = {0.f, 0.f, 0.f, 0.f};
   if (p.bias) b = *reinterpret_cast<const f32x4*>(p.bias + n);
   v = v + b;
@@ -825,12 +829,11 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
     p.kt_per_split = kt;
   }
   splits = p.splits;
-  if (p.raw_f32) {
-    ARG_CHECK(!p.geglu && p.chunk_kt == 0, "gemm: raw fp32 output excludes the GEGLU epilogue and K-chunking");
-    p.splits = splits = 1;
-    p.kt_per_split = kt;
+  if (p.raw_f32 && splits == 1) {
+    ARG_CHECK(!p.geglu, "gemm: raw fp32 output excludes the GEGLU epilogue");
     p.partial = p.raw_f32;      // the split-K slab path with one split IS the fp32 product
   } else if (splits > 1) {
+    ARG_CHECK(!p.geglu, "gemm: split-K excludes the GEGLU epilogue");
     ARG_CHECK(partial_ws != nullptr, "gemm: split-K needs a partial workspace");
     p.partial = partial_ws;
   } else {

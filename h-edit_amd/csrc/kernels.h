@@ -156,3 +156,41 @@ int step_style_launch(const float* e_u_src, const float* e_c_src, const float* e
                       float w_tar, float chain, float weight, hipStream_t st);
 int local_blend_launch(const float* const* maps, int n_maps, int heads, const float* alpha_layers,
                        const int* enabled, float* xt, int n_img, int C, int H, int W, float th, hipStream_t st);
+
+// ---------------------------------------------------------------- pnet.hip ("precise" fp32-quality building blocks)
+// ops of the fused element-wise stage that produces a split-bf16 GEMM operand (and of act_launch)
+enum { P_COPY = 0, P_AFFINE = 1, P_PRELU = 2, P_PRELU_GRAD = 3, P_RELU = 4, P_RELU_GRAD = 5 };
+struct Split3Params {
+  const float* x; int ldx;     // fp32 input rows [rows_in][ldx] (NHWC pixels x channels)
+  const float* z;              // P_*_GRAD: the pre-activation the mask is taken from (same geometry as x)
+  const float* p; const float* q;   // per-channel parameters (q may be null for the activations), or per (image, channel)
+  int pq_img;                  // 1: p / q are [B][C]
+  int op;
+  bf16_t* out; int Kp, Cs, C;  // bf16 [rows_out][Kp]: columns [0,C) hi, [Cs,Cs+C) hi, [2Cs,2Cs+C) lo, rest 0
+  int geo;                     // 0: rows_out = rows_in; 1: every second pixel of every second row; 2: zero-stuffed to 2H x 2W
+  int B, H, W;                 // INPUT geometry (needed for geo != 0 or pq_img)
+};
+int split3_launch(const Split3Params& s, long rows_out, hipStream_t st);
+int pack_split3_w_launch(const float* w, const float* scale, bf16_t* out, int O, int I, int k, int dgrad, int Cs, int Kp,
+                         int rows_out, int perm_hw, int perm_c, hipStream_t st);
+int bn_affine_launch(const float* g, const float* b, const float* m, const float* v, float eps, float* p, float* q, int C, int rep,
+                     hipStream_t st);
+int bn_fold_bias_launch(const float* bias, const float* g, const float* b, const float* m, const float* v, float eps, float* p, float* q,
+                        int C, hipStream_t st);
+int act_launch(const float* x, const float* p, const float* q, float* y, long total, int C, int op, hipStream_t st);
+int se_nslab(int HW);          // pixel slabs of the SE reductions: partial buffers are [B][se_nslab(HW)][C]
+int se_pool_launch(const float* u, float* part, int B, int HW, int C, hipStream_t st);
+int se_fc_launch(const float* part, const float* bias, const float* w1, const float* w2, float* hbuf, float* sbuf, int B, int HW, int C,
+                 int R, hipStream_t st);
+int se_combine_launch(const float* u, const float* bias, const float* s, const float* sc, const float* sc_bias, const float* X, int stride,
+                      float* Y, int B, int Ho, int Wo, int C, hipStream_t st);
+int se_bwd_reduce_launch(const float* dY, const float* u, const float* bias, float* part, int B, int HW, int C, hipStream_t st);
+int se_fc_bwd_launch(const float* part, const float* sbuf, const float* hbuf, const float* w1, const float* w2, float* rbuf, int B, int C,
+                     int R, int HW, hipStream_t st);
+int unit_bwd_combine_launch(const float* dxa, const float* p, const float* dsc, int stride, float* dX, int B, int H, int W, int C,
+                            hipStream_t st);
+int scale_cols_launch(const float* x, const float* p, float* y, long total, int n, hipStream_t st);
+int face_pool_launch(const float* img, float* out, int B, hipStream_t st);
+int face_pool_bwd_launch(const float* g, int ldg, float* dimg, int B, hipStream_t st);
+int cos_head_launch(const float* raw, const float* bias, const float* ref, int ref_stride, float* feat, float* loss, float* df, int B, int D,
+                    float scale, hipStream_t st);

@@ -89,6 +89,18 @@ _SIGS = {
     "hedit_ddpm_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "hedit_ddpm_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                      C.c_void_p]),
+    "hedit_irse50_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "hedit_irse50_destroy": (None, [C.c_void_p]),
+    "hedit_irse50_num_params": (C.c_int, [C.c_void_p]),
+    "hedit_irse50_param_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "hedit_irse50_param_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "hedit_irse50_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hedit_irse50_missing": (C.c_int, [C.c_void_p]),
+    "hedit_irse50_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hedit_irse50_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "hedit_irse50_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hedit_irse50_cos_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hedit_vae_create": (C.c_int, [C.POINTER(VaeCfg), C.POINTER(C.c_void_p)]),
     "hedit_vae_destroy": (None, [C.c_void_p]),
     "hedit_vae_num_params": (C.c_int, [C.c_void_p]),

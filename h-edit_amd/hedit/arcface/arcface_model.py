@@ -5,9 +5,11 @@ face-swapping/arcface/arcface_model.py:11-67 and its IR-SE50 backbone
 squeeze-excitation) -> l2-normalised 512-d feature; ``get_cosine_loss`` = 1 - cos(feature(image),
 feature(reference face)).
 
-Like the CLIP encoders this reward network stays a torch module on PyTorch-ROCm: the face loop only
-needs its value and its gradient w.r.t. the image (h_edit_R.py:103-106), which torch autograd provides
-exactly as in the reference; the eps-network it guides is the HIP executor (hedit.diffusion.Model).
+On the GPU the network runs natively (backend "hip": ``hedit_irse50_cos_fwd_bwd`` of libhedit_hip.so, csrc/irse.hip):
+the face loop only needs the loss and its gradient w.r.t. the image (h_edit_R.py:103-106), which one native
+call produces together (fp32-quality split-bf16 contractions on the MFMA GEMM kernel); ``get_cosine_loss`` wraps
+it in an autograd node so the caller's ``torch.autograd.grad(loss, x_{t-1})`` works unchanged.  The torch module
+below (backend "torch") is the parameter container and the CPU mirror the golden-vector tests run.
 state_dict keys are the reference's (``input_layer.0.weight``, ``body.3.res_layer.5.fc1.weight`` ...), so
 its ``model_ir_se50.pth`` loads directly from a local path; nothing is downloaded.
 ``LPIPS_Loss`` (arcface_model.py:69-94) wraps the third-party ``lpips`` package, absent offline: pass any
@@ -97,12 +99,31 @@ def load_face_image(path, size=256):
     return (x * 2 - 1).unsqueeze(0)
 
 
+class _NativeCosLoss(torch.autograd.Function):
+    """mean_b (1 - cos) with the image gradient computed by the same native call (forward + backward fused)."""
+
+    @staticmethod
+    def forward(ctx, image, owner):
+        loss, grad = owner._native_loss_and_grad(image.detach())
+        ctx.save_for_backward(grad)
+        return loss.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
 class IDLoss(nn.Module):
     """``IDLoss(ref_path)`` as the reference, plus where the backbone weights come from: ``weights`` = local
-    path of model_ir_se50.pth or a state_dict; None = seeded random weights (synthetic runs)."""
+    path of model_ir_se50.pth or a state_dict; None = seeded random weights (synthetic runs).
+    backend: "hip" (default on a GPU device: the native executor, no fallback) or "torch" (the CPU mirror)."""
 
-    def __init__(self, ref_path=None, weights=None, ref=None, device=None, seed=0):
+    def __init__(self, ref_path=None, weights=None, ref=None, device=None, seed=0, backend=None):
         super().__init__()
+        self._backend = backend
+        self._h = None
+        self._ws = None
         self.facenet = Backbone(input_size=112, num_layers=50, drop_ratio=0.6, mode="ir_se")
         if weights is None:
             self.facenet.init_random(seed)
@@ -120,18 +141,98 @@ class IDLoss(nn.Module):
         if device is not None:
             self.to(device)
 
+    # ------------------------------------------------------------------ native executor (csrc/irse.hip)
+    def _use_hip(self, x):
+        b = self._backend or ("hip" if x.is_cuda else "torch")
+        if b == "hip" and not x.is_cuda:
+            raise RuntimeError("IDLoss backend 'hip' needs CUDA tensors (there is no CPU fallback)")
+        return b == "hip"
+
+    def _native(self, device):
+        """create / load / finalize the native backbone on first use (parameters by the reference's names)"""
+        import ctypes as C
+        from .. import _lib
+        if self._h is not None:
+            return self._h
+        lib = _lib.lib()
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.hedit_irse50_create(C.byref(h)))
+            sd = self.facenet.state_dict()
+            for i in range(lib.hedit_irse50_num_params(h)):
+                name = lib.hedit_irse50_param_name(h, i).decode()
+                w = sd[name].detach().to(device=device, dtype=torch.float32).contiguous()
+                _lib.check(lib.hedit_irse50_load(h, name.encode(), _lib.ptr(w), w.numel(), _lib.cur_stream()))
+                torch.cuda.current_stream().synchronize()
+            _lib.check(lib.hedit_irse50_finalize(h, _lib.cur_stream()))
+        self._h, self._lib = h, lib
+        return h
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None:
+            try:
+                self._lib.hedit_irse50_destroy(self._h)
+            except Exception:
+                pass
+
+    def _workspace(self, B, device):
+        need = self._lib.hedit_irse50_workspace_bytes(self._h, B)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _to256(self, x):
+        return x if x.shape[2] == 256 else F.adaptive_avg_pool2d(x, (256, 256))
+
+    def _native_features(self, x):
+        from .. import _lib
+        x = self._to256(x).detach().float().contiguous()
+        h = self._native(x.device)
+        ws = self._workspace(x.shape[0], x.device)
+        feat = torch.empty(x.shape[0], 512, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.hedit_irse50_features(h, _lib.ptr(x), x.shape[0], _lib.ptr(feat), _lib.ptr(ws), ws.numel(),
+                                                       _lib.cur_stream()))
+        return feat
+
+    def _ref_feature(self, device):
+        if self._ref_feat is None or self._ref_feat.device != device:
+            with torch.no_grad():      # constant w.r.t. the image; the reference re-encodes it on every call (:51)
+                self._ref_feat = (self._native_features(self.ref.to(device)) if self._use_hip(self.ref.to(device))
+                                  else F.normalize(self.extract_feats(self.ref), p=2, dim=-1))
+        return self._ref_feat
+
+    def _native_loss_and_grad(self, x):
+        """(loss [B] = 1 - cos per image, d mean(loss) / d x) for x (B,3,256,256)"""
+        from .. import _lib
+        x = x.float().contiguous()
+        B = x.shape[0]
+        h = self._native(x.device)
+        ref = self._ref_feature(x.device)
+        ws = self._workspace(B, x.device)
+        loss = torch.empty(B, device=x.device)
+        grad = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.hedit_irse50_cos_fwd_bwd(h, _lib.ptr(x), _lib.ptr(ref), 0, B, 1.0 / B, _lib.ptr(loss), _lib.ptr(grad),
+                                                          _lib.ptr(ws), ws.numel(), _lib.cur_stream()))
+        return loss, grad
+
+    # ------------------------------------------------------------------ the reference's surface
     def extract_feats(self, x):
-        if x.shape[2] != 256:
-            x = F.adaptive_avg_pool2d(x, (256, 256))
+        if self._use_hip(x):
+            return self._native_features(x)
+        x = self._to256(x)
         x = x[:, :, 35:223, 32:220]                       # crop the face region
         return self.facenet(F.adaptive_avg_pool2d(x, (112, 112)))
 
     def get_cosine_sim(self, image):
+        if self._use_hip(image):
+            return (self._native_features(image) * self._ref_feature(image.device)).sum(-1)
         img_feat = F.normalize(self.extract_feats(image), p=2, dim=-1)
-        if self._ref_feat is None or self._ref_feat.device != img_feat.device:
-            with torch.no_grad():      # constant w.r.t. the image; the reference re-encodes it on every call (:51)
-                self._ref_feat = F.normalize(self.extract_feats(self.ref), p=2, dim=-1)
-        return F.cosine_similarity(self._ref_feat, img_feat, dim=-1)
+        return F.cosine_similarity(self._ref_feature(img_feat.device), img_feat, dim=-1)
 
     def get_cosine_loss(self, image):
+        if self._use_hip(image):
+            # the 256 x 256 pooling (if any) stays a torch op in front of the native node
+            return _NativeCosLoss.apply(self._to256(image), self)
         return (1 - self.get_cosine_sim(image)).mean()

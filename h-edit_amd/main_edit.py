@@ -60,6 +60,7 @@ def build_parser():
     p.add_argument("--random_init", action="store_true", help="synthetic SD-1.x / ViT-B/16-shaped weights")
     p.add_argument("--tiny", action="store_true", help="with --random_init: the small test configuration")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--batch", type=int, default=1, help="dataset entries edited in lock-step per pass (one style encoder each)")
     return p
 
 
@@ -73,6 +74,51 @@ def load_style_encoder(args, ref_path, device):
         m = ClipVisualPrefix(width=64, layers=3, heads=1, patch_size=32, input_resolution=224).init_random(args.seed)
         return CLIPEncoder(need_ref=True, ref_path=ref_path, clip_model=m.half(), device=device)
     return CLIPEncoder(need_ref=True, ref_path=ref_path, device=device, seed=args.seed)
+
+
+def edit_group(args, model, entries, scale, size, device):
+    """--batch N: n entries in lock-step on the batched engine; every image keeps its own style encoder / reference
+    (CLIPEncoder.get_gram_matrix_residual reads batch item 0 only, clip_guidance/base_clip.py:60-65).
+    entries: [(item, image_path, save_path)]."""
+    from hedit.engine import HEditEngine
+    from hedit.p2p.ptp_classes import ControllerBatch
+    eng = HEditEngine(model)
+    model.scheduler.config.timestep_spacing = "leading"
+    model.scheduler.set_timesteps(args.num_diffusion_steps)
+    after_skip_steps = args.num_diffusion_steps - args.skip
+    xs, pairs, ctrls, encs = [], [], [], []
+    for item, image_path, _ in entries:
+        original_prompt = item["original_prompt"].replace("[", "").replace("]", "")
+        editing_prompt = item["editing_prompt"].replace("[", "").replace("]", "")
+        blended_word = item["blended_word"].split(" ") if item["blended_word"] != "" else []
+        encs.append(load_style_encoder(args, args.dataset + item['style'], device))
+        x0 = load_512(image_path, 0, 0, 0, 0, device)
+        if x0.shape[-1] != size:
+            x0 = torch.nn.functional.interpolate(x0, size=(size, size), mode="bilinear", align_corners=False)
+        xs.append(x0)
+        pairs.append([original_prompt, editing_prompt])
+        same_len = len(original_prompt.split(" ")) == len(editing_prompt.split(" "))
+        eq_params = {"words": (blended_word[1],), "values": (2.0,)} if len(blended_word) else None
+        ctrls.append(make_controller(prompts=pairs[-1], is_replace_controller=same_len, cross_replace_steps=args.xa,
+                                     self_replace_steps=args.sa, blend_word=None, equilizer_params=eq_params,
+                                     num_steps=after_skip_steps, tokenizer=model.tokenizer, device=model.device))
+    w0 = (model.vae.encode(torch.cat(xs)).latent_dist.mode() * scale).float()
+    zs, wts = eng.ddpm_inversion(w0, [p[0] for p in pairs], eta=args.eta, cfg_src=args.cfg_src)
+    controller = ControllerBatch(ctrls)
+    register_attention_control(model, controller)
+    edited, _ = eng.run(wts[after_skip_steps].contiguous(), zs[:after_skip_steps].contiguous(), pairs,
+                        [args.cfg_src, args.cfg_src_edit, args.cfg_tar], controller, eta=args.eta, p2p=True, implicit=True,
+                        K=args.optimization_steps, after_skip_steps=after_skip_steps, ddim_inv=False, fuse_src_pass=True,
+                        style=(encs, args.weight_edit_clip))
+    out = []
+    with torch.no_grad():
+        x0_dec = model.vae.decode(1 / scale * edited).sample
+        for i, (_, _, save_path) in enumerate(entries):
+            print(f'loss from CLIP: {torch.linalg.norm(encs[i].get_gram_matrix_residual(x0_dec[i:i + 1])).item()}')
+            os.makedirs(os.path.dirname(save_path), exist_ok=True)
+            image_grid(x0_dec[i:i + 1]).save(save_path)
+            out.append(save_path)
+    return out
 
 
 def main(argv=None):
@@ -101,7 +147,20 @@ def main(argv=None):
 
     keys = list(full_data.keys())
     written = []
-    for idx in D.shard(len(keys), rank, world):
+    mine = D.shard(len(keys), rank, world)
+    if args.batch > 1:
+        sub = (args.mode + '_total_steps_' + str(args.num_diffusion_steps) + '_skip_' + str(args.skip) + '_' +
+               weight_string + xa_sa_string)
+        for lo in range(0, len(mine), args.batch):
+            entries = []
+            for idx in mine[lo:lo + args.batch]:
+                item = full_data[keys[idx]]
+                image_path = args.dataset + item['image_path']
+                entries.append((item, image_path, image_path.replace(args.dataset, os.path.join(args.output_path, sub))))
+            written += edit_group(args, model, entries, scale, size, device)
+        print(f"rank {rank}/{world}: wrote {len(written)} image(s)")
+        return written
+    for idx in mine:
         item = full_data[keys[idx]]
         eta = args.eta
         image_path = args.dataset + item['image_path']

@@ -9,6 +9,9 @@ Differences, all additive:
     configuration at 256x256).
   * launched under ``torch.distributed.run`` the dataset entries are sharded across the ranks
     (one process per GPU, no data-path collective).
+  * ``--batch N``: N dataset entries are edited in lock-step by the batched engine (the reference edits one image
+    at a time, main_p2p.py:110; images are independent, and the kernels are batch-invariant bit for bit, so every
+    image comes out exactly as it does alone -- at several times the throughput).
 The comparison baselines of the reference driver (ef, ef_p2p, nmg_p2p, pnp_inv_p2p) are not part of
 this build and are refused.
 """
@@ -67,6 +70,7 @@ def build_parser():
     p.add_argument("--random_init", action="store_true", help="synthetic SD-1.x-shaped weights (no checkpoint)")
     p.add_argument("--tiny", action="store_true", help="with --random_init: the small test configuration")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--batch", type=int, default=1, help="dataset entries edited in lock-step per pass")
     return p
 
 
@@ -82,6 +86,69 @@ def load_model(args, device):
     if not args.model_path:
         raise SystemExit("give --model_path DIR (local diffusers-layout checkpoint) or --random_init")
     return HEditPipeline.from_pretrained(args.model_path, device=device)
+
+
+def edit_group(args, model, entries, scale, size, device):
+    """--batch N: the n entries of one group in lock-step on hedit.engine.HEditEngine -- VAE encode, inversion
+    (2n-row UNet calls), the loop (4n / 5n-row calls, one controller per image in a ControllerBatch) and VAE decode.
+    entries: [(key, item, image_path, save_path)].  Same per-image arithmetic as the single-image path."""
+    from hedit.engine import HEditEngine
+    from hedit.p2p.ptp_classes import ControllerBatch
+    eng = HEditEngine(model)
+    n = len(entries)
+    eta = args.eta
+    is_ddim_inversion = eta == 0
+    if is_ddim_inversion:
+        model.scheduler = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                        clip_sample=False, set_alpha_to_one=False)
+    model.scheduler.config.timestep_spacing = "leading"
+    model.scheduler.set_timesteps(args.num_diffusion_steps)
+    T = args.num_diffusion_steps
+    xs, src_p, tar_p, ctrls = [], [], [], []
+    after_skip_steps = T - args.skip
+    for key, item, image_path, _ in entries:
+        x0 = load_512(image_path, 0, 0, 0, 0, device)
+        if x0.shape[-1] != size:
+            x0 = torch.nn.functional.interpolate(x0, size=(size, size), mode="bilinear", align_corners=False)
+        xs.append(x0)
+        original_prompt = item["original_prompt"].replace("[", "").replace("]", "")
+        editing_prompt = item["editing_prompt"].replace("[", "").replace("]", "")
+        src_p.append(original_prompt)
+        tar_p.append(editing_prompt)
+        blended_word = item["blended_word"].split(" ") if item["blended_word"] != "" else []
+        same_len = len(original_prompt.split(" ")) == len(editing_prompt.split(" "))
+        replace = same_len and key in (_REPLACE_KEYS_DDIM if is_ddim_inversion else _REPLACE_KEYS_DDPM)
+        if args.mode.endswith('p2p'):
+            blend_word = ((blended_word[0],), (blended_word[1],)) if len(blended_word) else None
+            eq_val = 1.25 if args.optimization_steps > 1 else 2.0
+            eq_params = {"words": (blended_word[1],), "values": (eq_val,)} if len(blended_word) else None
+            ctrls.append(make_controller(prompts=[original_prompt, editing_prompt], is_replace_controller=replace,
+                                         cross_replace_steps=args.xa, self_replace_steps=args.sa, blend_word=blend_word,
+                                         equilizer_params=eq_params, num_steps=after_skip_steps, tokenizer=model.tokenizer,
+                                         device=model.device))
+    w0 = (model.vae.encode(torch.cat(xs)).latent_dist.mode() * scale).float()
+    if is_ddim_inversion:
+        _, zs, wts = eng.ddim_inversion(w0, src_p, args.cfg_src)
+        eta = 1.0
+    elif 0 < eta <= 1:
+        zs, wts = eng.ddpm_inversion(w0, src_p, eta=eta, cfg_src=args.cfg_src)
+    else:
+        raise SystemExit("Warning: out of range for eta")
+    p2p = args.mode.endswith('p2p')
+    controller = ControllerBatch(ctrls) if p2p else AttentionStore()
+    register_attention_control(model, controller)
+    edited, _ = eng.run(wts[after_skip_steps].contiguous(), zs[:after_skip_steps].contiguous(), [[a, b] for a, b in zip(src_p, tar_p)],
+                        [args.cfg_src, args.cfg_src_edit, args.cfg_tar], controller, eta=eta, p2p=p2p, implicit=args.implicit,
+                        K=args.optimization_steps, w_rec=args.weight_reconstruction, after_skip_steps=after_skip_steps,
+                        ddim_inv=is_ddim_inversion, fuse_src_pass=p2p and args.implicit)
+    x0_dec = model.vae.decode(1 / scale * edited).sample
+    out = []
+    for i, (_, _, _, save_path) in enumerate(entries):
+        os.makedirs(os.path.dirname(save_path), exist_ok=True)
+        image_grid(x0_dec[i:i + 1]).save(save_path)
+        out.append(save_path)
+    model.unet.zero_grad()
+    return out
 
 
 def main(argv=None):
@@ -114,7 +181,20 @@ def main(argv=None):
 
     keys = [k for k, item in full_data.items() if item["editing_type_id"] in args.edit_category_list]
     written = []
-    for idx in D.shard(len(keys), rank, world):
+    mine = D.shard(len(keys), rank, world)
+    if args.batch > 1:
+        sub = (args.mode + '_total_steps_' + str(args.num_diffusion_steps) + '_skip_' + str(args.skip) + '_' +
+               weight_string + xa_sa_string)
+        for lo in range(0, len(mine), args.batch):
+            entries = []
+            for idx in mine[lo:lo + args.batch]:
+                item = full_data[keys[idx]]
+                image_path = os.path.join(f"{data_path}/annotation_images", item["image_path"])
+                entries.append((keys[idx], item, image_path, image_path.replace(data_path, os.path.join(output_path, sub))))
+            written += edit_group(args, model, entries, scale, size, device)
+        print(f"rank {rank}/{world}: wrote {len(written)} image(s)")
+        return written
+    for idx in mine:
         key = keys[idx]
         item = full_data[key]
         eta = args.eta

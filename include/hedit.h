@@ -296,6 +296,34 @@ size_t hedit_ddpm_workspace_bytes(hedit_ddpm* h, int B);
 int hedit_ddpm_forward(hedit_ddpm* h, const float* x, float t, int B, float* eps, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Identity reward of the face-swapping task: `IDLoss.get_cosine_loss(image)` of face-swapping/arcface/
+ * arcface_model.py:40-67 (crop [35:223, 32:220] -> adaptive average pool 112 -> IR-SE50, model_irse.py:9-48 /
+ * helpers.py:28-119 -> l2-normalised feature -> 1 - cos against the reference face's feature) fused with the gradient
+ * w.r.t. the image that inversion/h_edit_R.py:103-106 takes from it with torch.autograd.grad.  fp32-quality
+ * arithmetic (three-term split-bf16 products with fp32 accumulation, fp32 activations).  Parameters by the
+ * reference's state_dict names (`input_layer.0.weight`, `body.3.res_layer.4.running_var`, `output_layer.3.weight`,
+ * ...; the integer `num_batches_tracked` buffers are not parameters), fp32 device tensors in torch layouts;
+ * hedit_irse50_finalize folds the BatchNorms and packs the GEMM operands once after loading. */
+typedef struct hedit_irse hedit_irse;
+int hedit_irse50_create(hedit_irse** out);
+void hedit_irse50_destroy(hedit_irse* h);
+int hedit_irse50_num_params(const hedit_irse* h);
+const char* hedit_irse50_param_name(const hedit_irse* h, int i);
+int hedit_irse50_param_shape(const hedit_irse* h, int i, int* ndim, int* dims4);
+int hedit_irse50_load(hedit_irse* h, const char* name, const float* dev_w, size_t numel, void* stream);
+int hedit_irse50_missing(const hedit_irse* h);
+int hedit_irse50_finalize(hedit_irse* h, void* stream);
+size_t hedit_irse50_workspace_bytes(hedit_irse* h, int B);
+/* image fp32 [B][3][256][256] in [-1, 1] -> feat fp32 [B][512] = F.normalize(IDLoss.extract_feats(image)) */
+int hedit_irse50_features(hedit_irse* h, const float* image, int B, float* feat, void* workspace,
+                          size_t workspace_bytes, void* stream);
+/* loss[b] = 1 - cos(feature(image_b), ref_feat); d_image [B][3][256][256] = d(scale * sum_b loss[b]) / d image
+ * (scale = 1 / B: the reference's batch mean).  ref_feat: l2-normalised [512] (ref_per_image = 0) or [B][512]. */
+int hedit_irse50_cos_fwd_bwd(hedit_irse* h, const float* image, const float* ref_feat, int ref_per_image, int B,
+                             float scale, float* loss, float* d_image, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

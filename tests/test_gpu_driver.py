@@ -59,6 +59,22 @@ def test_driver_writes_edited_images(tmp_path, extra):
         assert im.shape == (256, 256, 3) and im.std() > 0
 
 
+def test_driver_batch_flag_edits_in_lock_step_with_identical_results(tmp_path):
+    """--batch 2: the two entries go through the batched engine (VAE encode, DDIM inversion, loop, decode in 2-image
+    launches).  The kernels are batch-invariant, so the PNGs are byte-identical to the one-image-at-a-time run
+    (h-Edit-D: the DDIM inversion draws no random numbers)."""
+    from PIL import Image
+    d = _dataset(tmp_path)
+    common = ["--data_path", str(d), "--random_init", "--tiny", "--num_diffusion_steps", "4", "--edit_category_list", "0", "1",
+              "--mode", "h_edit_D_p2p", "--eta", "0.0", "--implicit", "--optimization_steps", "2"]
+    one = _driver().main(common + ["--output_path", str(tmp_path / "r1")])
+    two = _driver().main(common + ["--output_path", str(tmp_path / "r2"), "--batch", "2"])
+    assert len(one) == len(two) == 2
+    for a, b in zip(sorted(one), sorted(two)):
+        assert os.path.basename(a) == os.path.basename(b)
+        assert np.array_equal(np.array(Image.open(a)), np.array(Image.open(b)))
+
+
 def test_driver_refuses_baselines(tmp_path):
     with pytest.raises(NotImplementedError):
         _driver().main(["--data_path", str(_dataset(tmp_path)), "--random_init", "--tiny", "--mode", "ef_p2p"])
