@@ -194,3 +194,11 @@ int face_pool_launch(const float* img, float* out, int B, hipStream_t st);
 int face_pool_bwd_launch(const float* g, int ldg, float* dimg, int B, hipStream_t st);
 int cos_head_launch(const float* raw, const float* bias, const float* ref, int ref_stride, float* feat, float* loss, float* df, int B, int D,
                     float scale, hipStream_t st);
+// LPIPS-VGG pieces
+int lpips_prep_launch(const float* img, float* out, const float* shift3, const float* scale3, int B, int H, int W, hipStream_t st);
+int lpips_prep_bwd_launch(const float* g, int ldg, float* dimg, const float* scale3, int B, int H, int W, hipStream_t st);
+int maxpool2_launch(const float* z, float* zp, uint8_t* idx, int B, int H, int W, int C, hipStream_t st);
+int maxpool2_bwd_launch(const float* gp, const uint8_t* idx, const float* add, float* G, int B, int H, int W, int C, hipStream_t st);
+int lpips_head_launch(const float* z, const float* bias, const float* src, long src_img_stride, const float* w, float* fn_out, float* dpix,
+                      float* dF, int B, int HW, int C, float gscale, hipStream_t st);
+int lpips_reduce_launch(const float* dpix, float* acc, int B, int HW, int first, hipStream_t st);

@@ -414,9 +414,186 @@ __global__ __launch_bounds__(256) void cos_head_kernel(const float* __restrict__
   }
 }
 
+// ---- LPIPS-VGG pieces (lpips 0.1.4: ScalingLayer, vgg16 slices, normalize_tensor, lin layers, spatial_average)
+// (x - shift_c) / scale_c, NCHW fp32 -> NHWC fp32 [B*H*W][3]
+__global__ __launch_bounds__(256) void lpips_prep_kernel(const float* __restrict__ img, float* __restrict__ out, float3 shift, float3 scale,
+                                                         int B, int H, int W) {
+  const long total = (long)B * H * W * 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % 3);
+    const long pix = i / 3;
+    const int b = (int)(pix / ((long)H * W));
+    const long r = pix - (long)b * H * W;
+    const float sh = c == 0 ? shift.x : (c == 1 ? shift.y : shift.z), sc = c == 0 ? scale.x : (c == 1 ? scale.y : scale.z);
+    out[i] = (img[((long)b * 3 + c) * H * W + r] - sh) / sc;
+  }
+}
+// d img[b][c][pix] = g[pix][c] / scale_c ; g: [B*H*W][ldg]
+__global__ __launch_bounds__(256) void lpips_prep_bwd_kernel(const float* __restrict__ g, int ldg, float* __restrict__ dimg, float3 scale, int B,
+                                                             int H, int W) {
+  const long total = (long)B * 3 * H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i % ((long)H * W);
+    const int c = (int)((i / ((long)H * W)) % 3), b = (int)(i / ((long)3 * H * W));
+    const float sc = c == 0 ? scale.x : (c == 1 ? scale.y : scale.z);
+    dimg[i] = g[((long)b * H * W + r) * ldg + c] / sc;
+  }
+}
+// 2 x 2 / stride 2 max pooling of a pre-activation tensor (ReLU and the per-channel bias commute with it); idx = winner 0..3
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ z, float* __restrict__ zp, uint8_t* __restrict__ idx, int B,
+                                                       int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long total = (long)B * Ho * Wo * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long pix = i / C;
+    const int b = (int)(pix / ((long)Ho * Wo));
+    const int r = (int)(pix - (long)b * Ho * Wo);
+    const int oy = r / Wo, ox = r - oy * Wo;
+    const float* src = z + (((long)b * H + oy * 2) * W + ox * 2) * C + c;
+    float best = src[0];
+    int bi = 0;
+    const float v1 = src[C], v2 = src[(long)W * C], v3 = src[(long)W * C + C];
+    if (v1 > best) { best = v1; bi = 1; }
+    if (v2 > best) { best = v2; bi = 2; }
+    if (v3 > best) { best = v3; bi = 3; }
+    zp[i] = best;
+    idx[i] = (uint8_t)bi;
+  }
+}
+// G[full] = add[full] (or 0) + (the pixel won its window ? g_pooled : 0)
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ gp, const uint8_t* __restrict__ idx,
+                                                           const float* __restrict__ add, float* __restrict__ G, int B, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long total = (long)B * H * W * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long pix = i / C;
+    const int b = (int)(pix / ((long)H * W));
+    const int r = (int)(pix - (long)b * H * W);
+    const int y = r / W, x = r - y * W;
+    const long pi = (((long)b * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c;
+    float v = add ? add[i] : 0.f;
+    if (idx[pi] == (uint8_t)((y & 1) * 2 + (x & 1))) v += gp[pi];
+    G[i] = v;
+  }
+}
+// One wave per pixel.  F = relu(z + bias); n = |F| + 1e-10; Fn = F / n.
+//   src == nullptr: write Fn to fn_out (the source image's normalised features)
+//   else: d = sum_c w_c (Fn - src)^2 -> dpix[pixel]; dF (gradient of  gscale * mean_hw d  w.r.t. F) -> dF
+__global__ __launch_bounds__(256) void lpips_head_kernel(const float* __restrict__ z, const float* __restrict__ bias, const float* __restrict__ src,
+                                                         long src_img_stride, const float* __restrict__ w, float* __restrict__ fn_out,
+                                                         float* __restrict__ dpix, float* __restrict__ dF, long npix, int HW, int C,
+                                                         float gscale) {
+  const int lane = threadIdx.x & 63;
+  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= npix) return;
+  const float* zr = z + pix * C;
+  float f[8];                       // C <= 512
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = lane + k * 64;
+    f[k] = 0.f;
+    if (c < C) {
+      const float t = zr[c] + bias[c];
+      f[k] = t > 0.f ? t : 0.f;
+      ss += f[k] * f[k];
+    }
+  }
+  const float nrm = sqrtf(wave_sum(ss));
+  const float n = nrm + 1e-10f;
+  if (!src) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = lane + k * 64;
+      if (c < C) fn_out[pix * C + c] = f[k] / n;
+    }
+    return;
+  }
+  const long b = pix / HW;
+  const float* sr = src + b * src_img_stride + (pix - b * HW) * C;
+  float g[8], d = 0.f, gf = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = lane + k * 64;
+    g[k] = 0.f;
+    if (c < C) {
+      const float df = f[k] / n - sr[c];
+      d += w[c] * df * df;
+      g[k] = 2.0f * w[c] * df * gscale;      // d / d Fn
+      gf += g[k] * f[k];
+    }
+  }
+  d = wave_sum(d);
+  gf = wave_sum(gf);
+  if (lane == 0) dpix[pix] = d;
+  if (dF) {
+    // Fn = F / (|F| + eps):  dF = g / n - F (g . F) / (|F| n^2)
+    const float k2 = nrm > 0.f ? gf / (nrm * n * n) : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = lane + k * 64;
+      if (c < C) dF[pix * C + c] = g[k] / n - f[k] * k2;
+    }
+  }
+}
+// acc[b] (+)= mean over the image's pixels of dpix, summed in a fixed order: one block per image
+__global__ __launch_bounds__(256) void lpips_reduce_kernel(const float* __restrict__ dpix, float* __restrict__ acc, int HW, int first) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < HW; p += 256) s += dpix[(long)b * HW + p];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (red[0] + red[1] + red[2] + red[3]) / (float)HW;
+    acc[b] = first ? v : acc[b] + v;
+  }
+}
+
 }  // namespace
 
 static inline dim3 pgrid(long total) { return dim3(ew_grid(total)); }
+
+int lpips_prep_launch(const float* img, float* out, const float* shift3, const float* scale3, int B, int H, int W, hipStream_t st) {
+  hipLaunchKernelGGL(lpips_prep_kernel, pgrid((long)B * H * W * 3), dim3(256), 0, st, img, out, make_float3(shift3[0], shift3[1], shift3[2]),
+                     make_float3(scale3[0], scale3[1], scale3[2]), B, H, W);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+int lpips_prep_bwd_launch(const float* g, int ldg, float* dimg, const float* scale3, int B, int H, int W, hipStream_t st) {
+  hipLaunchKernelGGL(lpips_prep_bwd_kernel, pgrid((long)B * 3 * H * W), dim3(256), 0, st, g, ldg, dimg,
+                     make_float3(scale3[0], scale3[1], scale3[2]), B, H, W);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+int maxpool2_launch(const float* z, float* zp, uint8_t* idx, int B, int H, int W, int C, hipStream_t st) {
+  ARG_CHECK(H % 2 == 0 && W % 2 == 0, "maxpool2: even size");
+  hipLaunchKernelGGL(maxpool2_kernel, pgrid((long)B * (H / 2) * (W / 2) * C), dim3(256), 0, st, z, zp, idx, B, H, W, C);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+int maxpool2_bwd_launch(const float* gp, const uint8_t* idx, const float* add, float* G, int B, int H, int W, int C, hipStream_t st) {
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, pgrid((long)B * H * W * C), dim3(256), 0, st, gp, idx, add, G, B, H, W, C);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+int lpips_head_launch(const float* z, const float* bias, const float* src, long src_img_stride, const float* w, float* fn_out, float* dpix,
+                      float* dF, int B, int HW, int C, float gscale, hipStream_t st) {
+  ARG_CHECK(C <= 512, "lpips_head: C <= 512");
+  const long npix = (long)B * HW;
+  hipLaunchKernelGGL(lpips_head_kernel, dim3(cdiv(npix, 4)), dim3(256), 0, st, z, bias, src, src_img_stride, w, fn_out, dpix, dF, npix, HW, C,
+                     gscale);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+int lpips_reduce_launch(const float* dpix, float* acc, int B, int HW, int first, hipStream_t st) {
+  hipLaunchKernelGGL(lpips_reduce_kernel, dim3(B), dim3(256), 0, st, dpix, acc, HW, first);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
 
 int split3_launch(const Split3Params& s, long rows_out, hipStream_t st) {
   ARG_CHECK(s.Kp % 64 == 0 && 3 * s.Cs <= s.Kp + 0 && s.C <= s.Cs, "split3: operand geometry");

@@ -101,6 +101,20 @@ _SIGS = {
     "hedit_irse50_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hedit_irse50_cos_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hedit_lpips_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "hedit_lpips_destroy": (None, [C.c_void_p]),
+    "hedit_lpips_num_params": (C.c_int, [C.c_void_p]),
+    "hedit_lpips_param_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "hedit_lpips_param_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "hedit_lpips_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hedit_lpips_missing": (C.c_int, [C.c_void_p]),
+    "hedit_lpips_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hedit_lpips_feature_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "hedit_lpips_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "hedit_lpips_source": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]),
+    "hedit_lpips_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hedit_vae_create": (C.c_int, [C.POINTER(VaeCfg), C.POINTER(C.c_void_p)]),
     "hedit_vae_destroy": (None, [C.c_void_p]),
     "hedit_vae_num_params": (C.c_int, [C.c_void_p]),

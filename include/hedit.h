@@ -324,6 +324,33 @@ int hedit_irse50_cos_fwd_bwd(hedit_irse* h, const float* image, const float* ref
                              float scale, float* loss, float* d_image, void* workspace, size_t workspace_bytes,
                              void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Perceptual reward of the face-swapping task: `LPIPS_Loss.get_lpips_loss(x)` of face-swapping/arcface/
+ * arcface_model.py:69-94 = lpips.LPIPS(net='vgg')(x, src).mean() (lpips==0.1.4: ScalingLayer, VGG16 taps relu1_2 ...
+ * relu5_3, channel-unit normalisation, squared difference, 1x1 lin weights, spatial mean, sum over taps) fused with
+ * the gradient w.r.t. x that inversion/h_edit_R.py:124-132 takes with torch.autograd.grad.  Parameters by the lpips
+ * state_dict names (`net.slice1.0.weight` ... `net.slice5.28.bias`, `lin0.model.1.weight` ... `lin4.model.1.weight`),
+ * fp32 device tensors in torch layouts.  Image height / width: multiples of 16. */
+typedef struct hedit_lpips hedit_lpips;
+int hedit_lpips_create(hedit_lpips** out);
+void hedit_lpips_destroy(hedit_lpips* h);
+int hedit_lpips_num_params(const hedit_lpips* h);
+const char* hedit_lpips_param_name(const hedit_lpips* h, int i);
+int hedit_lpips_param_shape(const hedit_lpips* h, int i, int* ndim, int* dims4);
+int hedit_lpips_load(hedit_lpips* h, const char* name, const float* dev_w, size_t numel, void* stream);
+int hedit_lpips_missing(const hedit_lpips* h);
+int hedit_lpips_finalize(hedit_lpips* h, void* stream);
+size_t hedit_lpips_feature_floats(int height, int width);
+size_t hedit_lpips_workspace_bytes(hedit_lpips* h, int B, int height, int width);
+/* src fp32 [B][3][H][W] in [-1, 1] -> feats fp32 [B][hedit_lpips_feature_floats(H, W)] (normalised tap features) */
+int hedit_lpips_source(hedit_lpips* h, const float* src, int B, int height, int width, float* feats,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* loss[b] = LPIPS(x_b, source); d_x = d(scale * sum_b loss[b]) / d x (scale = 1 / B: the reference's batch mean).
+ * src_feats: one source shared by the batch (src_per_image = 0) or one per image. */
+int hedit_lpips_fwd_bwd(hedit_lpips* h, const float* x, const float* src_feats, int src_per_image, int B, int height,
+                        int width, float scale, float* loss, float* d_x, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif
