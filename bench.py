@@ -72,12 +72,13 @@ def parse():
 
 def run_face(args, world, rank, local, dev, dist):
     """BASELINE configs[3] per GPU: face-swapping h-Edit-R (face-swapping/inversion/h_edit_R.py) -- pixel DDPM UNet
-    (HIP, CelebA-HQ 256 shape, random init) guided by the ArcFace identity reward (IR-SE50, torch), 100 steps,
-    K = 3 implicit steps: 100 + 2*3*99 = 694 eps evaluations per image; --images faces in lock-step per GPU
-    (default 8).  The LPIPS term needs the third-party lpips package (absent offline): lpipsloss=None, which the
-    reference loop guards the same way."""
+    (HIP, CelebA-HQ 256 shape, random init) guided by the ArcFace identity reward (IR-SE50) and the LPIPS-VGG
+    perceptual reward, both native executors (loss + image gradient in one call each), 100 steps, K = 3 implicit
+    steps: 100 + 2*3*99 = 694 eps evaluations and 297 + 297 reward evaluations per image; --images faces in lock-step
+    per GPU (default 8), one reference face and one source image per face."""
     import numpy as np
     from hedit.arcface import IDLoss
+    from hedit.arcface.lpips_loss import LPIPS_Loss
     from hedit.diffusion import Model, TINY_DDPM_CONFIG
     from hedit.inversion.h_edit_R import h_Edit_R
     n = args.images if args.images != 24 else 8
@@ -87,14 +88,16 @@ def run_face(args, world, rank, local, dev, dist):
     model.init_random(0)
     S = model.resolution
     g = torch.Generator().manual_seed(5 + rank)
-    idloss = IDLoss(ref=torch.randn(1, 3, 256, 256, generator=g) * 0.4, device=dev, seed=1)
+    # one reference face (identity reward) and one source image (LPIPS) per face, both native (csrc/irse.hip, lpips.hip)
+    idloss = IDLoss(ref=torch.randn(n, 3, 256, 256, generator=g) * 0.4, device=dev, seed=1)
+    lpipsloss = LPIPS_Loss(src=torch.randn(n, 3, S, S, generator=g) * 0.4, device=dev, seed=2) if S % 16 == 0 else None
     betas = torch.from_numpy(np.linspace(0.0001, 0.02, 1000, dtype=np.float64)).float().to(dev)
     seq = (np.arange(0, 1000, 1000 // T) + 1)[::-1]
     xT = torch.randn(n, 3, S, S, generator=g).to(dev)
     zs = torch.randn(T, n, 3, S, S, generator=g).to(dev)
 
     def one_step():
-        return h_Edit_R(model, None, idloss, xT, betas, seq, eta=1.0, zs=zs, weight_edit_face=50.0, optimization_steps=K,
+        return h_Edit_R(model, lpipsloss, idloss, xT, betas, seq, eta=1.0, zs=zs, weight_edit_face=50.0, optimization_steps=K,
                         after_skip_steps=T, num_inference_steps=T, per_image=True)
 
     for _ in range(args.warmup):
@@ -133,7 +136,7 @@ def run_face(args, world, rank, local, dev, dist):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3] per GPU: face-swapping h_Edit_R, CelebA-HQ-256-shaped random-init pixel DDPM "
-                               f"UNet (113.7M), ArcFace IR-SE50 identity reward (torch, random init), no LPIPS term, {T} steps, "
+                               f"UNet (113.7M), ArcFace IR-SE50 identity reward + LPIPS-VGG16 reward (native, random init), {T} steps, "
                                f"K={K}; {n} faces per GPU in lock-step",
                    "images_per_gpu": n, "eps_evaluations_per_image": evals, "parallelism": f"replica-dp{world}"},
         "achieved_tflops_per_s_per_gpu": round(imgs * evals * flop_fwd / elapsed / 1e12 / world, 1),

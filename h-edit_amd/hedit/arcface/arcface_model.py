@@ -176,6 +176,7 @@ class IDLoss(nn.Module):
                 pass
 
     def _workspace(self, B, device):
+        B = max(B, self.ref.shape[0])
         need = self._lib.hedit_irse50_workspace_bytes(self._h, B)
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
@@ -209,12 +210,15 @@ class IDLoss(nn.Module):
         B = x.shape[0]
         h = self._native(x.device)
         ref = self._ref_feature(x.device)
+        per_image = ref.shape[0] > 1           # lock-step batches: one reference face per image
+        if per_image and ref.shape[0] != B:
+            raise ValueError("one reference face per batch item expected")
         ws = self._workspace(B, x.device)
         loss = torch.empty(B, device=x.device)
         grad = torch.empty_like(x)
         with torch.cuda.device(x.device):
-            _lib.check(self._lib.hedit_irse50_cos_fwd_bwd(h, _lib.ptr(x), _lib.ptr(ref), 0, B, 1.0 / B, _lib.ptr(loss), _lib.ptr(grad),
-                                                          _lib.ptr(ws), ws.numel(), _lib.cur_stream()))
+            _lib.check(self._lib.hedit_irse50_cos_fwd_bwd(h, _lib.ptr(x), _lib.ptr(ref), int(per_image), B, 1.0 / B, _lib.ptr(loss),
+                                                          _lib.ptr(grad), _lib.ptr(ws), ws.numel(), _lib.cur_stream()))
         return loss, grad
 
     # ------------------------------------------------------------------ the reference's surface

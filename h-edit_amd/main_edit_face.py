@@ -61,6 +61,9 @@ def build_parser():
     p.add_argument("--random_init", action="store_true")
     p.add_argument("--tiny", action="store_true", help="with --random_init: 32 x 32 toy UNet")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--lpips_ckpt", type=str, default=None, help="local file with a saved lpips.LPIPS(net='vgg').state_dict()")
+    p.add_argument("--no_lpips", action="store_true", help="drop the LPIPS term (lpipsloss=None, which the loop guards)")
+    p.add_argument("--batch", type=int, default=1, help="(source, reference) pairs swapped in lock-step per pass")
     return p
 
 
@@ -91,24 +94,58 @@ def main(argv=None):
     betas = linear_betas(device)
     skip_per_step = betas.shape[0] // args.num_diffusion_steps
     seq = (np.arange(0, betas.shape[0], skip_per_step) + 1)[::-1]
-    try:
-        import lpips  # noqa: F401
-        have_lpips = True
-    except ImportError:
-        have_lpips = False
-        print("lpips is not installed: running without the LPIPS term (lpipsloss=None)")
+    from hedit.arcface.lpips_loss import LPIPS_Loss
+    have_lpips = not args.no_lpips
+    if have_lpips and not args.random_init and not args.lpips_ckpt:
+        raise SystemExit("give --lpips_ckpt FILE (saved lpips.LPIPS(net='vgg').state_dict()), or --no_lpips")
     pairs = list(get_source_ref_paths(args.json_file))
     written = []
-    for i in D.shard(len(pairs), rank, world):
+    mine = D.shard(len(pairs), rank, world)
+    if args.batch > 1:
+        # --batch N: the inversions run pair by pair (each reseeds with 42 like the reference), the h-Edit loop runs the
+        # N pairs in lock-step with one reference face / one source image per batch item (per_image: every pair is
+        # swapped exactly as it would be alone)
+        after_skip_steps = args.num_diffusion_steps - args.skip
+        save_path = args.output_path + (f"{args.mode}/steps_{args.num_diffusion_steps}_skip_{args.skip}_weight_{args.weight_edit_face}"
+                                        f"_opts_{args.optimization_steps}")
+        os.makedirs(save_path, exist_ok=True)
+        for lo in range(0, len(mine), args.batch):
+            grp = [pairs[i] for i in mine[lo:lo + args.batch]]
+            srcs = [load_face_image(os.path.join(args.image_path, sp), S).to(device) for _, sp, _ in grp]
+            refs = [load_face_image(os.path.join(args.image_path, rp), S).to(device) for _, _, rp in grp]
+            to256 = lambda t: t if S == 256 else torch.nn.functional.interpolate(t, size=(256, 256), mode="bilinear", align_corners=False)
+            idloss = IDLoss(ref=torch.cat([to256(r) for r in refs]), weights=None if args.random_init else args.arcface_ckpt,
+                            device=device, seed=args.seed)
+            lpipsloss = LPIPS_Loss(src=torch.cat(srcs), weights=None if args.random_init else args.lpips_ckpt, device=device,
+                                   seed=args.seed) if have_lpips else None
+            zs_l, xs_l = [], []
+            for src in srcs:
+                _, zs, xts, _ = inversion_forward_process_sde(model, src, betas, seq, etas=args.eta,
+                                                              num_inference_steps=args.num_diffusion_steps, device=device)
+                zs_l.append(zs[:after_skip_steps])
+                xs_l.append(xts[after_skip_steps])
+            edited = h_Edit_R(model, lpipsloss, idloss, torch.stack(xs_l), betas, seq, eta=args.eta, zs=torch.stack(zs_l, 1),
+                              weight_edit_face=args.weight_edit_face, optimization_steps=args.optimization_steps,
+                              after_skip_steps=after_skip_steps, num_inference_steps=args.num_diffusion_steps, soft_face_mask=None,
+                              per_image=True).detach()
+            with torch.no_grad():
+                print(f'Cosine Similarity: {idloss.get_cosine_sim(to256(edited)).mean().item()}')
+            for k, (_, sp, rp) in enumerate(grp):
+                img = image_grid([refs[k].cpu(), srcs[k].cpu(), edited[k:k + 1].cpu()])
+                key = f"{rp.split('/')[-1].split('.')[0]}_{sp.split('/')[-1].split('.')[0]}"
+                full = os.path.join(save_path, f'item_{key}.png')
+                img.save(full)
+                written.append(full)
+        print(f"rank {rank}/{world}: wrote {len(written)} image(s)")
+        return written
+    for i in mine:
         idx, source_path, ref_path = pairs[i]
         source = load_face_image(os.path.join(args.image_path, source_path), S).to(device)
         ref = load_face_image(os.path.join(args.image_path, ref_path), S).to(device)
         ref256 = ref if S == 256 else torch.nn.functional.interpolate(ref, size=(256, 256), mode="bilinear", align_corners=False)
         idloss = IDLoss(ref=ref256, weights=None if args.random_init else args.arcface_ckpt, device=device, seed=args.seed)
-        lpipsloss = None
-        if have_lpips:
-            from hedit.arcface.lpips_loss import LPIPS_Loss
-            lpipsloss = LPIPS_Loss(src=source).to(device)
+        lpipsloss = LPIPS_Loss(src=source, weights=None if args.random_init else args.lpips_ckpt, device=device,
+                               seed=args.seed) if have_lpips else None
         save_path = args.output_path + (f"{args.mode}/steps_{args.num_diffusion_steps}_skip_{args.skip}_weight_{args.weight_edit_face}"
                                         f"_opts_{args.optimization_steps}")
         os.makedirs(save_path, exist_ok=True)

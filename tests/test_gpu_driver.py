@@ -241,3 +241,29 @@ def test_face_driver_writes_swapped_images(tmp_path, capsys):
     assert capsys.readouterr().out.count("Cosine Similarity:") == 2
     with pytest.raises(NotImplementedError):
         drv.main(common + ["--mode", "ef"])
+
+
+def test_face_driver_batch_flag_swaps_pairs_in_lock_step(tmp_path):
+    """--batch 2: two (source, reference) pairs through h_Edit_R in one lock-step batch, each with its own reference
+    face (identity reward) and source image (LPIPS); the result sheets equal the pair-by-pair run (the eps-network and
+    both reward networks are batch-invariant; with two images the 1/n and n factors of the batch mean are exact)."""
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("hedit_main_face", os.path.join(ROOT, "h-edit_amd", "main_edit_face.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    d = tmp_path / "faces"
+    d.mkdir(parents=True)
+    y, x = np.mgrid[0:80, 0:72]
+    for i, name in enumerate(("a.jpg", "b.jpg", "c.jpg")):
+        Image.fromarray(np.stack([(x * (i + 2)) % 256, (y * 3 + i * 40) % 256, (x + y * (i + 1)) % 256], -1).astype(np.uint8)).save(d / name)
+    with open(d / "demo.json", "w") as f:
+        json.dump([dict(idx=0, ref="a.jpg", source="b.jpg"), dict(idx=1, ref="c.jpg", source="a.jpg")], f)
+    common = ["--json_file", str(d / "demo.json"), "--image_path", str(d) + "/", "--random_init", "--tiny",
+              "--num_diffusion_steps", "8", "--optimization_steps", "2", "--weight_edit_face", "4.0"]
+    one = drv.main(common + ["--output_path", str(tmp_path / "o1") + "/"])
+    two = drv.main(common + ["--output_path", str(tmp_path / "o2") + "/", "--batch", "2"])
+    assert len(one) == len(two) == 2
+    for a, b in zip(sorted(one), sorted(two)):
+        assert os.path.basename(a) == os.path.basename(b)
+        ia, ib = np.array(Image.open(a)).astype(np.int32), np.array(Image.open(b)).astype(np.int32)
+        assert ia.shape == ib.shape and np.abs(ia - ib).max() <= 1
