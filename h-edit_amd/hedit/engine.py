@@ -138,10 +138,16 @@ class HEditEngine:
 
     # ------------------------------------------------------------------ text
     def encode(self, prompts):
-        tok = self.model.tokenizer(prompts, padding="max_length", max_length=self.model.tokenizer.model_max_length,
-                                   truncation=True, return_tensors="pt")
-        with torch.no_grad():
-            return self.model.text_encoder(tok.input_ids.to(self.dev))[0].float()
+        """Prompt by prompt, each as a batch of one: the text encoder is a torch module whose GEMMs pick batch-dependent
+        kernels, and an image's embedding must not depend on the prompts it happens to be batched with (the engine's
+        results are bit-identical across batch sizes, tests/test_gpu_invariance.py)."""
+        out = []
+        for p in prompts:
+            tok = self.model.tokenizer([p], padding="max_length", max_length=self.model.tokenizer.model_max_length,
+                                       truncation=True, return_tensors="pt")
+            with torch.no_grad():
+                out.append(self.model.text_encoder(tok.input_ids.to(self.dev))[0].float())
+        return torch.cat(out)
 
     # ------------------------------------------------------------------ the loop
     @torch.no_grad()
