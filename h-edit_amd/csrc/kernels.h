@@ -159,7 +159,7 @@ int local_blend_launch(const float* const* maps, int n_maps, int heads, const fl
 
 // ---------------------------------------------------------------- pnet.hip ("precise" fp32-quality building blocks)
 // ops of the fused element-wise stage that produces a split-bf16 GEMM operand (and of act_launch)
-enum { P_COPY = 0, P_AFFINE = 1, P_PRELU = 2, P_PRELU_GRAD = 3, P_RELU = 4, P_RELU_GRAD = 5 };
+enum { P_COPY = 0, P_AFFINE = 1, P_PRELU = 2, P_PRELU_GRAD = 3, P_RELU = 4, P_RELU_GRAD = 5, P_QGELU = 6, P_QGELU_GRAD = 7 };
 struct Split3Params {
   const float* x; int ldx;     // fp32 input rows [rows_in][ldx] (NHWC pixels x channels)
   const float* z;              // P_*_GRAD: the pre-activation the mask is taken from (same geometry as x)
@@ -169,6 +169,7 @@ struct Split3Params {
   bf16_t* out; int Kp, Cs, C;  // bf16 [rows_out][Kp]: columns [0,C) hi, [Cs,Cs+C) hi, [2Cs,2Cs+C) lo, rest 0
   int geo;                     // 0: rows_out = rows_in; 1: every second pixel of every second row; 2: zero-stuffed to 2H x 2W
   int B, H, W;                 // INPUT geometry (needed for geo != 0 or pq_img)
+  int worder;                  // 1: parts (hi, lo, hi) -- the "weight" side of a product of two activation tensors
 };
 int split3_launch(const Split3Params& s, long rows_out, hipStream_t st);
 int pack_split3_w_launch(const float* w, const float* scale, bf16_t* out, int O, int I, int k, int dgrad, int Cs, int Kp,

@@ -57,11 +57,18 @@ __global__ __launch_bounds__(256) void split3_kernel(Split3Params s, long total)
           case P_PRELU_GRAD: { const float t = s.z[in_row * s.ldx + c] + (s.q ? s.q[c] : 0.f); v = x * (t > 0.f ? 1.f : s.p[c]); break; }
           case P_RELU: { const float t = x + (s.q ? s.q[c] : 0.f); v = t > 0.f ? t : 0.f; break; }
           case P_RELU_GRAD: { const float t = s.z[in_row * s.ldx + c] + (s.q ? s.q[c] : 0.f); v = t > 0.f ? x : 0.f; break; }
+          case P_QGELU: { const float t = x + (s.q ? s.q[c] : 0.f); v = t / (1.0f + __expf(-1.702f * t)); break; }
+          case P_QGELU_GRAD: {
+            const float t = s.z[in_row * s.ldx + c] + (s.q ? s.q[c] : 0.f);
+            const float sg = 1.0f / (1.0f + __expf(-1.702f * t));
+            v = x * (sg * (1.0f + 1.702f * t * (1.0f - sg)));
+            break;
+          }
           default: v = x;
         }
       }
       const bf16_t hi = bf16_rn(v);
-      o = part == 2 ? bf16_rn(v - bf16_to_f32(hi)) : hi;
+      o = part == (s.worder ? 1 : 2) ? bf16_rn(v - bf16_to_f32(hi)) : hi;
     }
     s.out[idx] = o;
   }
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256) void split3_v8_kernel(Split3Params s, long tot
           qq[e] = s.q ? s.q[(s.op == P_AFFINE ? pi : c) + e] : 0.f;
           zz[e] = 0.f;
         }
-        if (s.op == P_PRELU_GRAD || s.op == P_RELU_GRAD) {
+        if (s.op == P_PRELU_GRAD || s.op == P_RELU_GRAD || s.op == P_QGELU_GRAD) {
           const f32x4* zp = reinterpret_cast<const f32x4*>(s.z + in_row * s.ldx + c);
           const f32x4 z0 = zp[0], z1 = zp[1];
 #pragma unroll
@@ -122,10 +129,17 @@ __global__ __launch_bounds__(256) void split3_v8_kernel(Split3Params s, long tot
             case P_PRELU_GRAD: { const float t = zz[e] + qq[e]; y = v[e] * (t > 0.f ? 1.f : pp[e]); break; }
             case P_RELU: { const float t = v[e] + qq[e]; y = t > 0.f ? t : 0.f; break; }
             case P_RELU_GRAD: { const float t = zz[e] + qq[e]; y = t > 0.f ? v[e] : 0.f; break; }
+            case P_QGELU: { const float t = v[e] + qq[e]; y = t / (1.0f + __expf(-1.702f * t)); break; }
+            case P_QGELU_GRAD: {
+              const float t = zz[e] + qq[e];
+              const float sg = 1.0f / (1.0f + __expf(-1.702f * t));
+              y = v[e] * (sg * (1.0f + 1.702f * t * (1.0f - sg)));
+              break;
+            }
             default: y = v[e];
           }
           const bf16_t hi = bf16_rn(y);
-          const bf16_t ov = part == 2 ? bf16_rn(y - bf16_to_f32(hi)) : hi;
+          const bf16_t ov = part == (s.worder ? 1 : 2) ? bf16_rn(y - bf16_to_f32(hi)) : hi;
           if (e & 1) w[e >> 1] |= (uint32_t)ov << 16; else w[e >> 1] = ov;
         }
         o = make_uint4(w[0], w[1], w[2], w[3]);

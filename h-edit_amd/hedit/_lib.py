@@ -29,6 +29,10 @@ class DdpmCfg(C.Structure):
                 ("image_size", C.c_int)]
 
 
+class VitCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("width", "layers", "heads", "patch_size", "input_resolution")]
+
+
 class P2PPlan(C.Structure):
     _fields_ = [("mode", C.c_int), ("n_pairs", C.c_int),
                 ("pair_src", C.c_void_p), ("pair_tar", C.c_void_p),
@@ -115,6 +119,18 @@ _SIGS = {
                                      C.c_void_p]),
     "hedit_lpips_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hedit_vit_create": (C.c_int, [C.POINTER(VitCfg), C.POINTER(C.c_void_p)]),
+    "hedit_vit_destroy": (None, [C.c_void_p]),
+    "hedit_vit_num_params": (C.c_int, [C.c_void_p]),
+    "hedit_vit_param_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "hedit_vit_param_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "hedit_vit_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hedit_vit_missing": (C.c_int, [C.c_void_p]),
+    "hedit_vit_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hedit_vit_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "hedit_vit_gram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hedit_vit_gram_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_size_t, C.c_void_p]),
     "hedit_vae_create": (C.c_int, [C.POINTER(VaeCfg), C.POINTER(C.c_void_p)]),
     "hedit_vae_destroy": (None, [C.c_void_p]),
     "hedit_vae_num_params": (C.c_int, [C.c_void_p]),

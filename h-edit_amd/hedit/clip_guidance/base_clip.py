@@ -9,10 +9,12 @@ projection and the text tower cannot influence the residual or its gradient and 
 Parameters carry the OpenAI CLIP state_dict names (``visual.conv1.weight`` ...), so a local
 checkpoint of the reference's model (ViT-B/16) loads directly; nothing is ever downloaded.
 
-Like the CLIP text encoder this small network stays on PyTorch-ROCm
-(fp16 weights, LayerNorm in fp32, QuickGELU, as model.py:153-164,414-435): it is ~0.1 % of the
-FLOPs of a guided step and torch autograd differentiates it exactly as in the reference; the
-decoder it back-propagates into is the HIP executor (hedit.vae, hedit_vae_decode_backward)."""
+On the GPU the encoder runs natively (backend "hip": ``hedit_vit_gram_fwd_bwd`` of libhedit_hip.so, csrc/vit.hip):
+the Frobenius norm of the Gram residual AND its gradient w.r.t. the resized, normalised image come from one call
+(fp32 token stream, split-bf16 contractions with fp32 accumulation -- finer than the reference's fp16 CLIP,
+model.py:414-435); the bicubic resize and the normalisation in front of it stay torch ops, so autograd carries the
+gradient on into the VAE decoder's HIP backward (hedit.vae).  The torch modules below (fp16 weights, LayerNorm in
+fp32, QuickGELU, as model.py:153-164) are the parameter container and the CPU mirror the golden vectors pin."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -130,14 +132,33 @@ def read_clip_checkpoint(path):
         return sd.get("state_dict", sd) if isinstance(sd, dict) else sd.state_dict()
 
 
+class _NativeGramNorm(torch.autograd.Function):
+    """sum_b |Gram(x_b) - Gram_ref|_F with the gradient w.r.t. x from the same native call"""
+
+    @staticmethod
+    def forward(ctx, x, owner):
+        loss, grad = owner._native_loss_and_grad(x.detach())
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g.view(-1, 1, 1, 1), None
+
+
 class CLIPEncoder(nn.Module):
     """Reference signature ``CLIPEncoder(need_ref=False, ref_path=None)`` plus where the weights come
     from (the reference downloads them; this build is offline): ``clip_path`` = local checkpoint,
     or ``clip_model`` = a ready ClipVisualPrefix, else seeded random weights (synthetic runs)."""
 
     def __init__(self, need_ref=False, ref_path=None, clip_path=None, clip_model=None, device=None,
-                 dtype=torch.float16, seed=0):
+                 dtype=torch.float16, seed=0, backend=None):
         super().__init__()
+        self._backend = backend          # "hip" (default on a GPU device, no fallback) or "torch"
+        self._h = None
+        self._ws = None
+        self._gram_ref_native = None
         if clip_model is None:
             if clip_path is not None:
                 sd = read_clip_checkpoint(clip_path)
@@ -164,9 +185,100 @@ class CLIPEncoder(nn.Module):
         return (im - self._mean.to(im.dtype)) / self._std.to(im.dtype)
 
     def set_reference(self, ref):
-        """ref: (1, 3, S, S), already CLIP-normalised (base_clip.py:43-53)."""
-        self.ref = ref
+        """ref: (1, 3, S, S), already CLIP-normalised (base_clip.py:43-53).  Held as a (non-persistent) buffer so that
+        ``CLIPEncoder(...).cuda()`` / ``.to()`` moves it with the module, as the reference's call pattern expects."""
+        if "ref" in self._buffers:
+            self.ref = ref
+        else:
+            self.register_buffer("ref", ref, persistent=False)
         self._gram_ref = None
+        self._gram_ref_native = None
+
+    # ------------------------------------------------------------------ native executor (csrc/vit.hip)
+    def _use_hip(self, x):
+        b = self._backend or ("hip" if x.is_cuda else "torch")
+        if b == "hip" and not x.is_cuda:
+            raise RuntimeError("CLIPEncoder backend 'hip' needs CUDA tensors (there is no CPU fallback)")
+        return b == "hip"
+
+    def _native(self, device):
+        import ctypes as C
+        from .. import _lib
+        if self._h is not None:
+            return self._h
+        lib = _lib.lib()
+        v = self.clip_model.visual
+        cfg = _lib.VitCfg()
+        cfg.width = v.conv1.weight.shape[0]
+        cfg.layers = len(v.transformer.resblocks)
+        cfg.heads = v.transformer.resblocks[0].heads
+        cfg.patch_size = v.conv1.kernel_size[0]
+        cfg.input_resolution = self.size
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.hedit_vit_create(C.byref(cfg), C.byref(h)))
+            sd = self.clip_model.state_dict()
+            for i in range(lib.hedit_vit_num_params(h)):
+                name = lib.hedit_vit_param_name(h, i).decode()
+                w = sd[name].detach().to(device=device, dtype=torch.float32).contiguous()
+                _lib.check(lib.hedit_vit_load(h, name.encode(), _lib.ptr(w), w.numel(), _lib.cur_stream()))
+                torch.cuda.current_stream().synchronize()
+            _lib.check(lib.hedit_vit_finalize(h, _lib.cur_stream()))
+        self._h, self._lib, self._width = h, lib, cfg.width
+        return h
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None:
+            try:
+                self._lib.hedit_vit_destroy(self._h)
+            except Exception:
+                pass
+
+    def _workspace(self, B, device):
+        need = self._lib.hedit_vit_workspace_bytes(self._h, B)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _native_gram(self, x):
+        """x (B,3,S,S) CLIP-normalised -> Gram matrices (B,D,D)"""
+        from .. import _lib
+        x = x.detach().float().contiguous()
+        h = self._native(x.device)
+        ws = self._workspace(x.shape[0], x.device)
+        g = torch.empty(x.shape[0], self._width, self._width, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.hedit_vit_gram(h, _lib.ptr(x), x.shape[0], _lib.ptr(g), _lib.ptr(ws), ws.numel(), _lib.cur_stream()))
+        return g
+
+    def _native_ref(self, device):
+        if self._gram_ref_native is None or self._gram_ref_native.device != device:
+            self._gram_ref_native = self._native_gram(self.ref.to(device))[0].contiguous()
+        return self._gram_ref_native
+
+    def _native_loss_and_grad(self, x):
+        """(loss [B] = |Gram(x_b) - Gram_ref|_F, d sum(loss) / d x) for x (B,3,S,S), CLIP-normalised"""
+        from .. import _lib
+        x = x.float().contiguous()
+        B = x.shape[0]
+        h = self._native(x.device)
+        ref = self._native_ref(x.device)
+        ws = self._workspace(B, x.device)
+        loss = torch.empty(B, device=x.device)
+        grad = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.hedit_vit_gram_fwd_bwd(h, _lib.ptr(x), _lib.ptr(ref), 0, B, 1.0, _lib.ptr(loss), _lib.ptr(grad),
+                                                        _lib.ptr(ws), ws.numel(), _lib.cur_stream()))
+        return loss, grad
+
+    def gram_residual_norms(self, ims):
+        """(N,3,H,W) in [-1, 1] -> (N,) = |get_gram_matrix_residual(ims[i:i+1])|_F, differentiable w.r.t. ``ims``: what the
+        style closure needs (torch.linalg.norm of the residual, inversion/h_edit.py:172-175).  On the GPU one native call
+        evaluates norm and gradient; resize + normalisation stay torch ops in front of it."""
+        x = self.preprocess(F.interpolate(ims, size=(self.size, self.size), mode="bicubic"))
+        if self._use_hip(x):
+            return _NativeGramNorm.apply(x, self)
+        return torch.linalg.norm(self.gram_residuals(ims), dim=(1, 2))
 
     def _tokens(self, im):
         # batch item 0, class token dropped.  The Gram matrices and their norm are accumulated in fp32: with
@@ -178,8 +290,10 @@ class CLIPEncoder(nn.Module):
         (base_clip.py:55-66).  The reference's Gram matrix does not depend on ``im1``; it is computed
         on first use and kept (the reference recomputes it every call with the same result)."""
         im1 = F.interpolate(im1, size=(self.size, self.size), mode="bicubic")
+        if self._use_hip(im1) and not im1.requires_grad:
+            return self._native_gram(self.preprocess(im1[:1]))[0] - self._native_ref(im1.device)
         feat1 = self._tokens(self.preprocess(im1))
-        if self._gram_ref is None:
+        if self._gram_ref is None or self._gram_ref.device != feat1.device:
             with torch.no_grad():
                 feat2 = self._tokens(self.ref)
                 self._gram_ref = torch.mm(feat2.t(), feat2)
@@ -191,7 +305,7 @@ class CLIPEncoder(nn.Module):
         get_gram_matrix_residual(ims[i:i+1]) (one encoder pass for the N images of a lock-step batch)."""
         ims = F.interpolate(ims, size=(self.size, self.size), mode="bicubic")
         f = self.clip_model.block_features(self.preprocess(ims))[:, 1:, :].float()
-        if self._gram_ref is None:
+        if self._gram_ref is None or self._gram_ref.device != f.device:
             with torch.no_grad():
                 feat2 = self._tokens(self.ref)
                 self._gram_ref = torch.mm(feat2.t(), feat2)

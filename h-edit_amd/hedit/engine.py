@@ -123,7 +123,11 @@ class HEditEngine:
                 hi = min(n, lo + self.style_chunk)
                 zc = z0[lo:hi].clone().requires_grad_(True)
                 img = vae.decode(zc).sample
-                if shared and hasattr(image_encoder, "gram_residuals"):
+                if shared and hasattr(image_encoder, "gram_residual_norms"):
+                    loss = image_encoder.gram_residual_norms(img).sum()          # native on the GPU (csrc/vit.hip)
+                elif (not shared) and all(hasattr(e, "gram_residual_norms") for e in encs[lo:hi]):
+                    loss = sum(encs[i].gram_residual_norms(img[i - lo:i - lo + 1]).sum() for i in range(lo, hi))
+                elif shared and hasattr(image_encoder, "gram_residuals"):
                     loss = torch.linalg.norm(image_encoder.gram_residuals(img), dim=(1, 2)).sum()
                 else:
                     loss = sum(torch.linalg.norm(encs[i].get_gram_matrix_residual(img[i - lo:i - lo + 1]))
@@ -286,11 +290,13 @@ class HEditEngine:
     # ------------------------------------------------------------------ Plug-and-Play loop
     @torch.no_grad()
     def run_pnp(self, xT, zs, prompts, cfg_scales, eta=1.0, K=1, after_skip_steps=None, ddim_inv=True):
-        """h-Edit with Plug-and-Play injection, text-guided/inversion/pnp_h_edit.py:24-167 (one image: the
-        reference's injection rule only fires for a batch of two).  Per step: the 4-row base pass (plain; with four
+        """h-Edit with Plug-and-Play injection, text-guided/inversion/pnp_h_edit.py:24-167, for n images in lock-step
+        (the reference edits one: its injection rule only fires for a batch of two).  xT (n,C,H,W); zs (T',n,C,H,W) or
+        (T',C,H,W) for one image; prompts [src, tar] or n x [src, tar].  Per step: the 4n-row base pass (plain; with four
         rows the hooks stay silent, pnp_utils.py:46-50), then per inner step eps(x^k, t-1, null) and eps(x^k, t-1, src)
-        -- two 1-row calls in the reference, one plain 2-row call here -- and the 2-row pass
-        [x^orig | src, x^k | tar] under the registered injection plan.  Returns (edit, recon)."""
+        -- two 1-row calls in the reference, one plain 2n-row call here -- and the 2n-row pass
+        [x^orig | src] * n, [x^k | tar] * n under the registered injection plan (row n + i takes row i's q, k /
+        features).  Returns (edit, recon)."""
         from .plug_n_play.pnp_utils import register_time
         sch = self.model.scheduler
         S = Schedule(sch)
@@ -299,11 +305,16 @@ class HEditEngine:
             after_skip_steps = T
         dev = self.dev
         xT = xT.to(device=dev, dtype=torch.float32)
-        if xT.shape[0] != 1:
-            raise ValueError("Plug-and-Play edits one image per call")
+        n = xT.shape[0]
+        pairs = [list(prompts[:2])] if isinstance(prompts[0], str) else [list(p[:2]) for p in prompts]
+        if len(pairs) != n:
+            raise ValueError("one [source, target] prompt pair per image expected")
         if zs is not None:
             zs = zs.to(device=dev, dtype=torch.float32).contiguous()
-        null, src, tar = self.encode([""]), self.encode([prompts[0]]), self.encode([prompts[1]])
+            if zs.dim() == 4:
+                zs = zs[:, None]
+        null = self.encode([""]).expand(n, -1, -1)
+        src, tar = self.encode([p[0] for p in pairs]), self.encode([p[1] for p in pairs])
         ctx_base4 = torch.cat([null, null, src, src]).contiguous()
         ctx_k2 = torch.cat([null, src]).contiguous()
         ctx_pair = torch.cat([src, tar]).contiguous()
@@ -317,24 +328,25 @@ class HEditEngine:
             idx = T - i - (T - after_skip_steps + 1)
             z = zs[idx] if zs is not None else None
             tt = op[i + 1] if i < len(op) - 1 else 0
-            coef = S.step_coef(t, tt, eta, ddim_inv, cfg_scales, 0.0)
+            eta_i = float(eta[idx]) if isinstance(eta, (list, tuple)) else float(eta)
+            coef = S.step_coef(t, tt, eta_i, ddim_inv, cfg_scales, 0.0)
             register_time(self.model, t)
             e = self.unet.forward_raw(torch.cat([xt, xt]), t, ctx_base4, None)
-            self.step_base(e, xt, z, x_prev, 1, 4, coef)
-            x_orig, x_base = x_prev[:1], x_prev[1:]
+            self.step_base(e, xt, z, x_prev, n, 4, coef)
+            x_orig, x_base = x_prev[:n], x_prev[n:]
             x_k = x_base.clone()
             for _ in range(K):
                 register_time(self.model, tt)
                 e2 = self.unet.forward_raw(torch.cat([x_k, x_k]), tt, ctx_k2, None)
-                plan = editor._plan(self.unet, 2, H, W, True) if editor is not None else None
+                plan = editor._plan(self.unet, 2 * n, H, W, True, n_images=n) if editor is not None else None
                 ep = self.unet.forward_raw(torch.cat([x_orig, x_k]), tt, ctx_pair, plan)
                 if editor is not None:
                     editor._after_pass(True)
                 new = torch.empty_like(x_k)
-                self.step_update(e2[0:1], e2[1:2], e2[0:1], ep[1:2], x_k, x_base, new, 1, False, coef)
+                self.step_update(e2[0:n], e2[n:2 * n], e2[0:n], ep[n:2 * n].contiguous(), x_k, x_base, new, n, False, coef)
                 x_k = new
             xt = torch.cat([x_orig, x_k]).contiguous()
-        return xt[1:].clone(), xt[:1].clone()
+        return xt[n:].clone(), xt[:n].clone()
 
     # ------------------------------------------------------------------ DDPM inversion
     @torch.no_grad()

@@ -61,8 +61,12 @@ class _PnPEditor:
         t = getattr(self.unet, "_pnp_t", None)
         return sched is not None and t is not None and (t in sched or t == 1000)
 
-    def _plan(self, unet, B, H, W, save_attn):
-        if B // 2 != 1:                    # the reference injects only when q.shape[0] // 2 == 1
+    def _plan(self, unet, B, H, W, save_attn, n_images=1):
+        """n_images > 1 (lock-step engine): rows [x_orig | src] * n, [x_k | tar] * n -- row n + i takes the q, k / features
+        of row i, the reference's two-row rule applied to every image of the batch."""
+        if n_images == 1 and B // 2 != 1:  # the reference injects only when q.shape[0] // 2 == 1
+            return None
+        if n_images > 1 and B != 2 * n_images:
             return None
         qk = self._active(getattr(unet, "_pnp_qk_schedule", None))
         conv = self._active(getattr(unet, "_pnp_conv_schedule", None))
@@ -70,7 +74,10 @@ class _PnPEditor:
             return None
         ar = torch.arange(B, dtype=torch.int32)
         src = ar.clone()
-        src[1] = 0
+        if n_images > 1:
+            src[n_images:] = ar[:n_images]
+        else:
+            src[1] = 0
         self._keep = (ar.to(unet.device), src.to(unet.device))
         first_tblock, resblock = _block_indices(unet.config)
         p = _lib.P2PPlan()

@@ -351,6 +351,33 @@ int hedit_lpips_fwd_bwd(hedit_lpips* h, const float* x, const float* src_feats, 
                         int width, float scale, float* loss, float* d_x, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Style encoder of the text + style task: `CLIPEncoder.get_gram_matrix_residual` of text-guided-n-style/clip_guidance/
+ * base_clip.py:55-66 on the prefix of the CLIP ViT it exercises (clip/model.py:195-237,339-365: patch embedding, class +
+ * positional embedding, ln_pre, the first `layers` ResidualAttentionBlocks): Gram matrix F^T F of the last block's patch
+ * tokens, its residual against the style reference's Gram matrix and the Frobenius norm, fused with the gradient w.r.t.
+ * the CLIP-normalised, resized image (what inversion/h_edit.py:170-179 pulls back into the decoder).  Parameters by the
+ * OpenAI CLIP state_dict names (`visual.conv1.weight`, `visual.transformer.resblocks.{i}.attn.in_proj_weight`, ...).
+ * width / heads = 64; at most 264 tokens. */
+typedef struct hedit_vit hedit_vit;
+typedef struct { int width, layers, heads, patch_size, input_resolution; } hedit_vit_cfg;
+int hedit_vit_create(const hedit_vit_cfg* cfg, hedit_vit** out);
+void hedit_vit_destroy(hedit_vit* h);
+int hedit_vit_num_params(const hedit_vit* h);
+const char* hedit_vit_param_name(const hedit_vit* h, int i);
+int hedit_vit_param_shape(const hedit_vit* h, int i, int* ndim, int* dims4);
+int hedit_vit_load(hedit_vit* h, const char* name, const float* dev_w, size_t numel, void* stream);
+int hedit_vit_missing(const hedit_vit* h);
+int hedit_vit_finalize(hedit_vit* h, void* stream);
+size_t hedit_vit_workspace_bytes(hedit_vit* h, int B);
+/* image fp32 [B][3][R][R] (CLIP-normalised, R = input_resolution) -> gram fp32 [B][width][width] */
+int hedit_vit_gram(hedit_vit* h, const float* image, int B, float* gram, void* workspace, size_t workspace_bytes,
+                   void* stream);
+/* loss[b] = |Gram(image_b) - gram_ref|_F; d_image = d(scale * sum_b loss[b]) / d image.  gram_ref [width][width]
+ * shared by the batch (ref_per_image = 0) or [B][width][width]. */
+int hedit_vit_gram_fwd_bwd(hedit_vit* h, const float* image, const float* gram_ref, int ref_per_image, int B, float scale,
+                           float* loss, float* d_image, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

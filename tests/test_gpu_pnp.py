@@ -64,3 +64,28 @@ def test_injection_changes_the_edit_and_only_for_two_rows():
     assert G.rel_err(inj[1:], plain[1:]) > 1e-2                  # the target row is not
     assert torch.equal(off, plain)
     assert G.rel_err(four[:2], plain) < 1e-2
+
+
+def test_lock_step_pnp_equals_the_single_image_runs():
+    """engine.run_pnp with two images in lock-step (2n-row injected pass: row n + i takes row i's q, k / features) gives
+    each image exactly what the one-image run gives it (batch-invariant kernels, same arithmetic)."""
+    from hedit.engine import HEditEngine
+    from hedit.plug_n_play import register_attention_control_efficient, register_conv_control_efficient
+    vec = np.load(os.path.join(GD, "g14_pnp.npz"))
+    case = META[-1]
+    hip = hip_model()
+    register_attention_control_efficient(hip, case["qk"])
+    register_conv_control_efficient(hip, case["conv"])
+    eng = HEditEngine(hip)
+    zs = G.f32(torch.from_numpy(vec[f"{case['name']}_zs"])[:T])
+    xT = G.f32(torch.from_numpy(vec[f"{case['name']}_wts"])[T])
+    g = torch.Generator().manual_seed(9)
+    xT2 = torch.cat([xT, G.f32(torch.randn(1, 4, 64, 64, generator=g))])
+    zs2 = torch.stack([zs, G.f32(torch.randn(T, 4, 64, 64, generator=g))], 1)
+    pairs = [[PROMPT_PAIRS[0][0], PROMPT_PAIRS[0][1]], [PROMPT_PAIRS[1][0], PROMPT_PAIRS[1][1]]]
+    kw = dict(cfg_scales=[1.0, 5.0, 7.5], eta=1.0, K=case["K"], after_skip_steps=T, ddim_inv=False)
+    e_all, r_all = eng.run_pnp(xT2, zs2, pairs, **kw)
+    for i in range(2):
+        e1, r1 = eng.run_pnp(xT2[i:i + 1], zs2[:, i:i + 1].contiguous(), [pairs[i]], **kw)
+        G.sync()
+        assert torch.equal(e_all[i:i + 1], e1) and torch.equal(r_all[i:i + 1], r1)
