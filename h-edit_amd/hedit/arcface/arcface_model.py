@@ -183,7 +183,15 @@ class IDLoss(nn.Module):
         return self._ws
 
     def _to256(self, x):
-        return x if x.shape[2] == 256 else F.adaptive_avg_pool2d(x, (256, 256))
+        """the reference's ``F.adaptive_avg_pool2d(x, (256, 256))`` for inputs of another size (arcface_model.py:41-42).  When
+        the size divides 256 every pooling window is one pixel, i.e. the map is pixel replication: written as
+        repeat_interleave its backward is a plain (deterministic, batch-independent) block sum, where torch's
+        adaptive-pool backward accumulates with atomics."""
+        if x.shape[2] == 256 and x.shape[3] == 256:
+            return x
+        if 256 % x.shape[2] == 0 and 256 % x.shape[3] == 0:
+            return x.repeat_interleave(256 // x.shape[2], 2).repeat_interleave(256 // x.shape[3], 3)
+        return F.adaptive_avg_pool2d(x, (256, 256))
 
     def _native_features(self, x):
         from .. import _lib

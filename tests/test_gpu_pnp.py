@@ -77,8 +77,8 @@ def test_lock_step_pnp_equals_the_single_image_runs():
     register_attention_control_efficient(hip, case["qk"])
     register_conv_control_efficient(hip, case["conv"])
     eng = HEditEngine(hip)
-    zs = G.f32(torch.from_numpy(vec[f"{case['name']}_zs"])[:T])
-    xT = G.f32(torch.from_numpy(vec[f"{case['name']}_wts"])[T])
+    zs = G.f32(torch.from_numpy(vec[f"{case['name']}_zs"])[:T]).reshape(T, 4, 64, 64)
+    xT = G.f32(torch.from_numpy(vec[f"{case['name']}_wts"])[T]).reshape(1, 4, 64, 64)
     g = torch.Generator().manual_seed(9)
     xT2 = torch.cat([xT, G.f32(torch.randn(1, 4, 64, 64, generator=g))])
     zs2 = torch.stack([zs, G.f32(torch.randn(T, 4, 64, 64, generator=g))], 1)
