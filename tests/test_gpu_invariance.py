@@ -253,3 +253,27 @@ def test_sd15_two_step_loop_matches_oracle(sd15):
     assert hc.cur_step == oc.cur_step
     assert G.rel_err(r_h, r_o) < 2e-2, G.rel_err(r_h, r_o)
     assert G.rel_err(e_h, e_o) < 6e-2, G.rel_err(e_h, e_o)
+
+
+def test_reusing_the_source_rows_of_the_p2p_pass_is_bit_identical(tiny):
+    """engine.run(reuse_orig_eps=True): the P2P pass at t-1 already evaluates eps(x^orig_{t-1}, t-1, null / src) on rows the
+    controller never edits, and the next base pass would recompute exactly these (p2p_h_edit.py:604-616,644-652).
+    With batch-invariant kernels eliminating the duplicate is a pure common-subexpression elimination: same bits,
+    7 instead of 9 sample-forwards per step."""
+    from hedit.engine import HEditEngine
+    hip, _, _ = tiny
+    T, n = 10, 3
+    hip.scheduler.set_timesteps(T)
+    eng = HEditEngine(hip)
+    pairs = [PROMPT_PAIRS[i % len(PROMPT_PAIRS)] for i in range(n)]
+    prompt_pairs = [[p[0], p[1]] for p in pairs]
+    w0 = torch.stack([torch.randn(4, 32, 32, generator=torch.Generator().manual_seed(70 + i)) * 0.8 for i in range(n)]).to(G.dev())
+    zs, xts = eng.ddpm_inversion(w0, [p[0] for p in prompt_pairs], eta=1.0, cfg_src=1.0,
+                                 generator=torch.Generator(device=G.dev()).manual_seed(5))
+    outs = []
+    for reuse in (False, True):
+        cb = _batch_controller(hip, pairs, T, 2)
+        outs.append(eng.run(xts[T].contiguous(), zs, prompt_pairs, [1.0, 5.0, 7.5], cb, eta=1.0, p2p=True, implicit=True, K=2, w_rec=0.1,
+                            after_skip_steps=T, ddim_inv=False, fuse_src_pass=True, reuse_orig_eps=reuse))
+    G.sync()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
