@@ -99,108 +99,173 @@ __global__ __launch_bounds__(256) void add_bias_res_kernel(const float* __restri
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) out[i] = res[i] + raw[i] + bias[i % W];
 }
 
-// ---- attention over the L tokens of one image, head dimension 64, fp32, everything in LDS.  qkv: [B*L][3W] raw (bias added on
-// load), head h uses columns [h*64, h*64+64) of the q / k / v thirds.  One workgroup (4 waves) per (head, image); rows padded
-// to 65 floats so that both "lane = row" and "lane = column" accesses are conflict-free.
-constexpr int HD = 64, HP = 65, LMAX = 264;
-__device__ __forceinline__ void load_head(const float* __restrict__ src, int ld, const float* __restrict__ bias, int col0, int L, float* dst) {
-  for (int i = threadIdx.x; i < L * HD; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    dst[r * HP + c] = src[(long)r * ld + col0 + c] + (bias ? bias[col0 + c] : 0.f);
+// ---- attention over the L tokens of one image, head dimension 64, fp32, K / V (or Q / dA) of one (image, head) resident in
+// LDS.  qkv: [B*L][3W] raw (bias added on load), head h uses columns [h*64, h*64+64) of the q / k / v thirds.  Rows are
+// padded to 68 floats: 16-byte aligned, and the four 16-lane groups of a ds_read_b128 with lane = row hit all 64 banks.
+// Workgroups: (head, image, slice) -- the query rows (forward, dq) or the keys (dk / dv) are cut into ASPLIT slices so
+// that 12 heads x 8 images fill the chip; every output element is still produced by exactly one wave in a fixed order.
+constexpr int HD = 64, HP = 68, LMAX = 200;
+typedef __attribute__((ext_vector_type(4))) float fl4;
+__device__ __forceinline__ void load_head(const float* __restrict__ src, int ld, const float* __restrict__ bias, int col0, int L, float* dst,
+                                          float mul) {
+  for (int i = threadIdx.x; i < L * (HD / 4); i += 256) {
+    const int r = i >> 4, c = (i & 15) * 4;
+    fl4 v = *reinterpret_cast<const fl4*>(src + (long)r * ld + col0 + c);
+    if (bias) v += *reinterpret_cast<const fl4*>(bias + col0 + c);
+    *reinterpret_cast<fl4*>(dst + r * HP + c) = v * mul;
   }
 }
+// Two register-resident 64-float rows against one LDS row: the LDS row is read once for both (two independent FMA chains)
+__device__ __forceinline__ void dot64x2(const fl4 (&a0)[16], const fl4 (&a1)[16], const float* __restrict__ row, float& s0, float& s1) {
+  s0 = 0.f;
+  s1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const fl4 b = *reinterpret_cast<const fl4*>(row + 4 * c);
+    s0 += a0[c][0] * b[0] + a0[c][1] * b[1] + a0[c][2] * b[2] + a0[c][3] * b[3];
+    s1 += a1[c][0] * b[0] + a1[c][1] * b[1] + a1[c][2] * b[2] + a1[c][3] * b[3];
+  }
+}
+// o0[lane] = sum_j w0[j] M[j][lane], o1 likewise (w in LDS, four at a time as a broadcast; M read once for both)
+__device__ __forceinline__ void wsum2(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ M, int L, int lane,
+                                      float& o0, float& o1) {
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;      // two partial chains per output: even / odd quads, folded at the end in a fixed order
+  int j = 0;
+  for (; j + 8 <= L; j += 8) {
+    const fl4 p0 = *reinterpret_cast<const fl4*>(w0 + j), p1 = *reinterpret_cast<const fl4*>(w1 + j);
+    const fl4 r0 = *reinterpret_cast<const fl4*>(w0 + j + 4), r1 = *reinterpret_cast<const fl4*>(w1 + j + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float m = M[(j + e) * HP + lane], m2 = M[(j + 4 + e) * HP + lane];
+      a0 += p0[e] * m; a1 += p1[e] * m;
+      b0 += r0[e] * m2; b1 += r1[e] * m2;
+    }
+  }
+  for (; j < L; ++j) { const float m = M[j * HP + lane]; a0 += w0[j] * m; a1 += w1[j] * m; }
+  o0 = a0 + b0;
+  o1 = a1 + b1;
+}
+__device__ __forceinline__ void slice_of(int L, int z, int nz, int& lo, int& hi) {
+  const int per = (L + nz - 1) / nz;
+  lo = z * per;
+  hi = lo + per < L ? lo + per : L;
+}
+// a head's 64-float row of an [rows][ld] tensor (+bias) times mul, every lane gets the whole row (broadcast loads)
+__device__ __forceinline__ void load_row(const float* __restrict__ src, const float* __restrict__ bias, float mul, fl4 (&r)[16]) {
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    fl4 v = *reinterpret_cast<const fl4*>(src + 4 * c);
+    if (bias) v += *reinterpret_cast<const fl4*>(bias + 4 * c);
+    r[c] = v * mul;
+  }
+}
+
+// Every wave works on TWO rows at a time (i0 and i0 + 4; the second is a clamped duplicate when the slice runs out, its
+// results are then not stored): the LDS rows are read once for both and the FMA chains are independent.
 // A[b][i][h*64 + d] = sum_j softmax_j(scale q_i . k_j) v_j[d];  lse[b][h][i] = log-sum-exp of the scaled scores
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ bias, float* __restrict__ A,
                                                        float* __restrict__ lse, int L, int W, float scale) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Ks = sm;
   float* Vs = sm + LMAX * HP;
-  float* ps = Vs + LMAX * HP;          // [4][LMAX]
-  float* qs = ps + 4 * LMAX;           // [4][64]
+  float* ps = Vs + LMAX * HP;          // [8][LMAX]
   const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
   const float* base = qkv + (long)b * L * 3 * W;
-  load_head(base, 3 * W, bias, W + h * HD, L, Ks);
-  load_head(base, 3 * W, bias, 2 * W + h * HD, L, Vs);
+  load_head(base, 3 * W, bias, W + h * HD, L, Ks, 1.f);
+  load_head(base, 3 * W, bias, 2 * W + h * HD, L, Vs, 1.f);
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float* p = ps + wv * LMAX;
-  float* q = qs + wv * HD;
-  for (int i = wv; i < L; i += 4) {
-    q[lane] = (base[(long)i * 3 * W + h * HD + lane] + bias[h * HD + lane]) * scale;
-    float mx = -3.0e38f;
+  float* pa = ps + (2 * wv) * LMAX;
+  float* pb = pa + LMAX;
+  int lo, hi;
+  slice_of(L, blockIdx.z, gridDim.z, lo, hi);
+  for (int i0 = lo + wv; i0 < hi; i0 += 8) {
+    const bool two = i0 + 4 < hi;
+    const int i1 = two ? i0 + 4 : i0;
+    fl4 qa[16], qb[16];
+    load_row(base + (long)i0 * 3 * W + h * HD, bias + h * HD, scale, qa);
+    load_row(base + (long)i1 * 3 * W + h * HD, bias + h * HD, scale, qb);
+    float ma = -3.0e38f, mb = -3.0e38f;
     for (int j = lane; j < L; j += 64) {
-      float s = 0.f;
-#pragma unroll 16
-      for (int d = 0; d < HD; ++d) s += q[d] * Ks[j * HP + d];
-      p[j] = s;
-      mx = fmaxf(mx, s);
+      float sa, sb;
+      dot64x2(qa, qb, Ks + j * HP, sa, sb);
+      pa[j] = sa; pb[j] = sb;
+      ma = fmaxf(ma, sa); mb = fmaxf(mb, sb);
     }
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int j = lane; j < L; j += 64) { const float e = __expf(p[j] - mx); p[j] = e; sum += e; }
-    sum = wave_sum(sum);
-    const float inv = 1.0f / sum;
-    float o = 0.f;
-    for (int j = 0; j < L; ++j) o += p[j] * Vs[j * HP + lane];
-    A[((long)b * L + i) * W + h * HD + lane] = o * inv;
-    if (lane == 0) lse[((long)b * heads + h) * L + i] = mx + __logf(sum);
+    ma = wave_max(ma); mb = wave_max(mb);
+    float suma = 0.f, sumb = 0.f;
+    for (int j = lane; j < L; j += 64) {
+      const float ea = __expf(pa[j] - ma), eb = __expf(pb[j] - mb);
+      pa[j] = ea; pb[j] = eb;
+      suma += ea; sumb += eb;
+    }
+    suma = wave_sum(suma); sumb = wave_sum(sumb);
+    float oa, ob;
+    wsum2(pa, pb, Vs, L, lane, oa, ob);
+    A[((long)b * L + i0) * W + h * HD + lane] = oa / suma;
+    if (lane == 0) lse[((long)b * heads + h) * L + i0] = ma + __logf(suma);
+    if (two) {
+      A[((long)b * L + i1) * W + h * HD + lane] = ob / sumb;
+      if (lane == 0) lse[((long)b * heads + h) * L + i1] = mb + __logf(sumb);
+    }
   }
 }
 // dq_i = scale * sum_j ds_ij k_j,  ds_ij = p_ij (dA_i . v_j - D_i),  D_i = dA_i . A_i
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ A,
                                                           const float* __restrict__ dA, const float* __restrict__ lse, float* __restrict__ dqkv,
                                                           int L, int W, float scale) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Ks = sm;
   float* Vs = sm + LMAX * HP;
   float* ps = Vs + LMAX * HP;
-  float* qs = ps + 4 * LMAX;           // [4][64] q (scaled)
-  float* gs = qs + 4 * HD;             // [4][64] dA row
   const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
   const float* base = qkv + (long)b * L * 3 * W;
-  load_head(base, 3 * W, bias, W + h * HD, L, Ks);
-  load_head(base, 3 * W, bias, 2 * W + h * HD, L, Vs);
+  load_head(base, 3 * W, bias, W + h * HD, L, Ks, 1.f);
+  load_head(base, 3 * W, bias, 2 * W + h * HD, L, Vs, 1.f);
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float* p = ps + wv * LMAX;
-  float* q = qs + wv * HD;
-  float* g = gs + wv * HD;
-  for (int i = wv; i < L; i += 4) {
-    const long ro = ((long)b * L + i) * W + h * HD + lane;
-    q[lane] = (base[(long)i * 3 * W + h * HD + lane] + bias[h * HD + lane]) * scale;
-    g[lane] = dA[ro];
-    const float Di = wave_sum(dA[ro] * A[ro]);
-    const float ls = lse[((long)b * heads + h) * L + i];
+  float* pa = ps + (2 * wv) * LMAX;
+  float* pb = pa + LMAX;
+  int lo, hi;
+  slice_of(L, blockIdx.z, gridDim.z, lo, hi);
+  for (int i0 = lo + wv; i0 < hi; i0 += 8) {
+    const bool two = i0 + 4 < hi;
+    const int i1 = two ? i0 + 4 : i0;
+    const long ra = ((long)b * L + i0) * W + h * HD, rb = ((long)b * L + i1) * W + h * HD;
+    fl4 qa[16], qb[16], ga[16], gb[16];
+    load_row(base + (long)i0 * 3 * W + h * HD, bias + h * HD, scale, qa);
+    load_row(base + (long)i1 * 3 * W + h * HD, bias + h * HD, scale, qb);
+    load_row(dA + ra, nullptr, 1.f, ga);
+    load_row(dA + rb, nullptr, 1.f, gb);
+    const float Da = wave_sum(dA[ra + lane] * A[ra + lane]), Db = wave_sum(dA[rb + lane] * A[rb + lane]);
+    const float la = lse[((long)b * heads + h) * L + i0], lb = lse[((long)b * heads + h) * L + i1];
     for (int j = lane; j < L; j += 64) {
-      float s = 0.f, dp = 0.f;
-#pragma unroll 16
-      for (int d = 0; d < HD; ++d) { s += q[d] * Ks[j * HP + d]; dp += g[d] * Vs[j * HP + d]; }
-      p[j] = __expf(s - ls) * (dp - Di);
+      float sa, sb, da, db;
+      dot64x2(qa, qb, Ks + j * HP, sa, sb);
+      dot64x2(ga, gb, Vs + j * HP, da, db);
+      pa[j] = __expf(sa - la) * (da - Da);
+      pb[j] = __expf(sb - lb) * (db - Db);
     }
-    float o = 0.f;
-    for (int j = 0; j < L; ++j) o += p[j] * Ks[j * HP + lane];
-    dqkv[((long)b * L + i) * 3 * W + h * HD + lane] = o * scale;
+    float oa, ob;
+    wsum2(pa, pb, Ks, L, lane, oa, ob);
+    dqkv[((long)b * L + i0) * 3 * W + h * HD + lane] = oa * scale;
+    if (two) dqkv[((long)b * L + i1) * 3 * W + h * HD + lane] = ob * scale;
   }
 }
-// dv_j = sum_i p_ij dA_i ;  dk_j = scale * sum_i ds_ij q_i   (q unscaled here: ds already carries one factor, dk the other)
+// dv_j = sum_i p_ij dA_i ;  dk_j = sum_i ds_ij (scale q_i)
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ A,
                                                            const float* __restrict__ dA, const float* __restrict__ lse, float* __restrict__ dqkv,
                                                            int L, int W, float scale) {
-  extern __shared__ float sm[];
-  float* Qs = sm;                      // [L][65] q * scale
-  float* Gs = sm + LMAX * HP;          // [L][65] dA
-  float* ps = Gs + LMAX * HP;          // [4][LMAX] p_ij
-  float* ds = ps + 4 * LMAX;           // [4][LMAX] ds_ij
-  float* ks = ds + 4 * LMAX;           // [4][64]
-  float* vs = ks + 4 * HD;             // [4][64]
-  float* Dl = vs + 4 * HD;             // [LMAX][2]: D_i, lse_i
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Qs = sm;                      // [L][68] q * scale
+  float* Gs = sm + LMAX * HP;          // [L][68] dA
+  float* ps = Gs + LMAX * HP;          // [8][LMAX] p_ij   (two keys per wave)
+  float* ds = ps + 8 * LMAX;           // [8][LMAX] ds_ij
+  float* Dl = ds + 8 * LMAX;           // [LMAX][2]: D_i, lse_i
   const int h = blockIdx.x, b = blockIdx.y, heads = gridDim.x;
   const float* base = qkv + (long)b * L * 3 * W;
-  for (int i = threadIdx.x; i < L * HD; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    Qs[r * HP + c] = (base[(long)r * 3 * W + h * HD + c] + bias[h * HD + c]) * scale;
-    Gs[r * HP + c] = dA[((long)b * L + r) * W + h * HD + c];
-  }
+  load_head(base, 3 * W, bias, h * HD, L, Qs, scale);
+  load_head(dA + (long)b * L * W, W, nullptr, h * HD, L, Gs, 1.f);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int i = wv; i < L; i += 4) {
     const long ro = ((long)b * L + i) * W + h * HD + lane;
@@ -208,25 +273,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
     if (lane == 0) { Dl[i * 2] = Di; Dl[i * 2 + 1] = lse[((long)b * heads + h) * L + i]; }
   }
   __syncthreads();
-  float* p = ps + wv * LMAX;
-  float* dd = ds + wv * LMAX;
-  float* k = ks + wv * HD;
-  float* v = vs + wv * HD;
-  for (int j = wv; j < L; j += 4) {
-    k[lane] = base[(long)j * 3 * W + W + h * HD + lane] + bias[W + h * HD + lane];
-    v[lane] = base[(long)j * 3 * W + 2 * W + h * HD + lane] + bias[2 * W + h * HD + lane];
+  float* pa = ps + (2 * wv) * LMAX;
+  float* pb = pa + LMAX;
+  float* da = ds + (2 * wv) * LMAX;
+  float* db = da + LMAX;
+  int lo, hi;
+  slice_of(L, blockIdx.z, gridDim.z, lo, hi);
+  for (int j0 = lo + wv; j0 < hi; j0 += 8) {
+    const bool two = j0 + 4 < hi;
+    const int j1 = two ? j0 + 4 : j0;
+    fl4 ka[16], kb[16], va[16], vb[16];
+    load_row(base + (long)j0 * 3 * W + W + h * HD, bias + W + h * HD, 1.f, ka);
+    load_row(base + (long)j1 * 3 * W + W + h * HD, bias + W + h * HD, 1.f, kb);
+    load_row(base + (long)j0 * 3 * W + 2 * W + h * HD, bias + 2 * W + h * HD, 1.f, va);
+    load_row(base + (long)j1 * 3 * W + 2 * W + h * HD, bias + 2 * W + h * HD, 1.f, vb);
     for (int i = lane; i < L; i += 64) {
-      float s = 0.f, dp = 0.f;
-#pragma unroll 16
-      for (int d = 0; d < HD; ++d) { s += Qs[i * HP + d] * k[d]; dp += Gs[i * HP + d] * v[d]; }
-      const float pij = __expf(s - Dl[i * 2 + 1]);
-      p[i] = pij;
-      dd[i] = pij * (dp - Dl[i * 2]);
+      float sa, sb, ga, gb;
+      dot64x2(ka, kb, Qs + i * HP, sa, sb);
+      dot64x2(va, vb, Gs + i * HP, ga, gb);
+      const float ea = __expf(sa - Dl[i * 2 + 1]), eb = __expf(sb - Dl[i * 2 + 1]);
+      pa[i] = ea; pb[i] = eb;
+      da[i] = ea * (ga - Dl[i * 2]); db[i] = eb * (gb - Dl[i * 2]);
     }
-    float dv = 0.f, dk = 0.f;
-    for (int i = 0; i < L; ++i) { dv += p[i] * Gs[i * HP + lane]; dk += dd[i] * Qs[i * HP + lane]; }
-    dqkv[((long)b * L + j) * 3 * W + W + h * HD + lane] = dk;         // Qs already holds q * scale
-    dqkv[((long)b * L + j) * 3 * W + 2 * W + h * HD + lane] = dv;
+    float ka_o, kb_o, va_o, vb_o;
+    wsum2(da, db, Qs, L, lane, ka_o, kb_o);          // Qs already holds q * scale
+    wsum2(pa, pb, Gs, L, lane, va_o, vb_o);
+    dqkv[((long)b * L + j0) * 3 * W + W + h * HD + lane] = ka_o;
+    dqkv[((long)b * L + j0) * 3 * W + 2 * W + h * HD + lane] = va_o;
+    if (two) {
+      dqkv[((long)b * L + j1) * 3 * W + W + h * HD + lane] = kb_o;
+      dqkv[((long)b * L + j1) * 3 * W + 2 * W + h * HD + lane] = vb_o;
+    }
   }
 }
 
@@ -238,11 +315,14 @@ __global__ __launch_bounds__(256) void tokens_t_kernel(const float* __restrict__
     Ft[i] = l < L - 1 ? T[(long)(l + 1) * W + w] : 0.f;
   }
 }
-// R = G - Gref (in place over G), norm = |R|_F : one block, fixed summation order
-__global__ __launch_bounds__(1024) void gram_residual_kernel(float* __restrict__ G, const float* __restrict__ Gref, float* __restrict__ nrm, long n) {
-  __shared__ float red[16];
+// R = G - Gref (in place over G) and |R|_F in two deterministic stages: GR_BLOCKS blocks sum fixed contiguous chunks, one wave
+// folds their partial sums in order
+constexpr int GR_BLOCKS = 64;
+__global__ __launch_bounds__(256) void gram_residual_kernel(float* __restrict__ G, const float* __restrict__ Gref, float* __restrict__ part, long n) {
+  __shared__ float red[4];
+  const long per = (n + GR_BLOCKS - 1) / GR_BLOCKS, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
   float s = 0.f;
-  for (long i = threadIdx.x; i < n; i += 1024) {
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
     const float r = G[i] - Gref[i];
     G[i] = r;
     s += r * r;
@@ -250,11 +330,13 @@ __global__ __launch_bounds__(1024) void gram_residual_kernel(float* __restrict__
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int i = 0; i < 16; ++i) t += red[i];
-    *nrm = sqrtf(t);
-  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void gram_norm_kernel(const float* __restrict__ part, float* __restrict__ nrm, float* __restrict__ loss) {
+  float t = 0.f;
+  for (int i = 0; i < GR_BLOCKS; ++i) t += part[i];
+  *nrm = sqrtf(t);
+  *loss = *nrm;
 }
 // dT[0][:] = 0 ; dT[1+l][:] = (2 * scale / |R|) * FR[l][:]      (d |F^T F - Gref|_F / dF = 2 F R / |R| for symmetric R)
 __global__ __launch_bounds__(256) void gram_bwd_kernel(const float* __restrict__ FR, const float* __restrict__ nrm, float* __restrict__ dT, int L,
@@ -273,9 +355,15 @@ struct VBlock {
 };
 
 inline dim3 egrid(long total) { return dim3(ew_grid(total)); }
-constexpr size_t ATTN_LDS_FWD = (size_t)(2 * LMAX * HP + 4 * LMAX + 4 * HD) * 4;
-constexpr size_t ATTN_LDS_DQ = (size_t)(2 * LMAX * HP + 4 * LMAX + 8 * HD) * 4;
-constexpr size_t ATTN_LDS_DKV = (size_t)(2 * LMAX * HP + 8 * LMAX + 8 * HD + 2 * LMAX) * 4;
+constexpr size_t ATTN_LDS_FWD = (size_t)(2 * LMAX * HP + 8 * LMAX) * 4;
+constexpr size_t ATTN_LDS_DQ = ATTN_LDS_FWD;
+constexpr size_t ATTN_LDS_DKV = (size_t)(2 * LMAX * HP + 16 * LMAX + 2 * LMAX) * 4;
+// slices of the query rows / keys per (image, head): fill the 256 CUs in ONE round (a function of the launch only: every
+// output element is produced by the same per-row arithmetic whichever slice it falls in)
+inline int attn_slices(int heads, int B) {
+  int z = 256 / (heads * B);
+  return z < 1 ? 1 : (z > 4 ? 4 : z);
+}
 
 }  // namespace
 
@@ -345,7 +433,7 @@ int run(hedit_vit* h, const float* img, const float* gref, long gref_stride, int
     TRY(palloc(f, &t.A, (size_t)M * W));
     TRY(palloc(f, &t.lse, (size_t)B * heads * L));
     if (!dry) {
-      hipLaunchKernelGGL(attn_fwd_kernel, dim3(heads, B), dim3(256), ATTN_LDS_FWD, st, t.qkv, k.bin, t.A, t.lse, L, W, ascale);
+      hipLaunchKernelGGL(attn_fwd_kernel, dim3(heads, B, attn_slices(heads, B)), dim3(256), ATTN_LDS_FWD, st, t.qkv, k.bin, t.A, t.lse, L, W, ascale);
       LAUNCH_CHECK();
     }
     TRY(lin(f, t.A, W, P_COPY, nullptr, nullptr, k.out, false, M, &raw));
@@ -367,9 +455,9 @@ int run(hedit_vit* h, const float* img, const float* gref, long gref_stride, int
   }
   // ---- Gram matrix of the patch tokens, per image
   const int Lp = (L - 1 + 63) / 64 * 64;
-  float *Ft, *G, *nrm = nullptr, *dT = nullptr;
+  float *Ft, *G, *nrm = nullptr, *dT = nullptr, *gpart = nullptr;
   TRY(palloc(f, &Ft, (size_t)W * Lp));
-  if (grad) { TRY(palloc(f, &nrm, (size_t)B)); TRY(palloc(f, &dT, (size_t)M * W)); }
+  if (grad) { TRY(palloc(f, &nrm, (size_t)B)); TRY(palloc(f, &gpart, (size_t)GR_BLOCKS)); TRY(palloc(f, &dT, (size_t)M * W)); }
   PConv gc;                       // "weights" = the second activation operand of F^T F / F R
   for (int b = 0; b < B; ++b) {
     const float* Tb = T + (size_t)b * L * W;
@@ -396,9 +484,10 @@ int run(hedit_vit* h, const float* img, const float* gref, long gref_stride, int
       continue;
     }
     if (!dry) {
-      hipLaunchKernelGGL(gram_residual_kernel, dim3(1), dim3(1024), 0, st, G, gref + (size_t)b * gref_stride, nrm + b, (long)W * W);
+      hipLaunchKernelGGL(gram_residual_kernel, dim3(GR_BLOCKS), dim3(256), 0, st, G, gref + (size_t)b * gref_stride, gpart, (long)W * W);
       LAUNCH_CHECK();
-      HIP_TRY(hipMemcpyAsync(loss + b, nrm + b, sizeof(float), hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(gram_norm_kernel, dim3(1), dim3(1), 0, st, gpart, nrm + b, loss + b);
+      LAUNCH_CHECK();
     }
     // d loss / d F = 2 F R / |R| : [L-1][W] = F [L-1][W] . R [W][W]   (R symmetric: its rows serve as the "weights")
     bf16_t *AF, *AR;
@@ -432,6 +521,7 @@ int run(hedit_vit* h, const float* img, const float* gref, long gref_stride, int
     return HEDIT_OK;
   }
   f.ar.free(nrm);
+  f.ar.free(gpart);
   // ---- backward through the blocks
   for (int i = (int)h->blocks.size() - 1; i >= 0; --i) {
     const VBlock& k = h->blocks[i];
@@ -447,9 +537,9 @@ int run(hedit_vit* h, const float* img, const float* gref, long gref_stride, int
     TRY(lin(f, dTm, W, P_COPY, nullptr, nullptr, k.out, true, M, &dAo));                         // d attention output
     TRY(palloc(f, &dqkv, (size_t)M * 3 * W));
     if (!dry) {
-      hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(heads, B), dim3(256), ATTN_LDS_DQ, st, t.qkv, k.bin, t.A, dAo, t.lse, dqkv, L, W, ascale);
+      hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(heads, B, attn_slices(heads, B)), dim3(256), ATTN_LDS_DQ, st, t.qkv, k.bin, t.A, dAo, t.lse, dqkv, L, W, ascale);
       LAUNCH_CHECK();
-      hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(heads, B), dim3(256), ATTN_LDS_DKV, st, t.qkv, k.bin, t.A, dAo, t.lse, dqkv, L, W, ascale);
+      hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(heads, B, attn_slices(heads, B)), dim3(256), ATTN_LDS_DKV, st, t.qkv, k.bin, t.A, dAo, t.lse, dqkv, L, W, ascale);
       LAUNCH_CHECK();
     }
     f.ar.free(dAo); f.ar.free(t.qkv); f.ar.free(t.A); f.ar.free(t.lse);
@@ -486,7 +576,7 @@ int hedit_vit_create(const hedit_vit_cfg* cfg, hedit_vit** out) try {
   ARG_CHECK(cfg->layers >= 1 && cfg->input_resolution % cfg->patch_size == 0 && (3 * cfg->patch_size * cfg->patch_size) % 64 == 0,
             "vit: layers / patch geometry");
   const int P = cfg->input_resolution / cfg->patch_size, L = P * P + 1;
-  ARG_CHECK(L <= LMAX, "vit: at most 264 tokens");
+  ARG_CHECK(L <= LMAX, "vit: at most 200 tokens");
   TRY(gemm_prepare());
   hedit_vit* h = new hedit_vit();
   h->cfg = *cfg;

@@ -358,7 +358,7 @@ int hedit_lpips_fwd_bwd(hedit_lpips* h, const float* x, const float* src_feats, 
  * tokens, its residual against the style reference's Gram matrix and the Frobenius norm, fused with the gradient w.r.t.
  * the CLIP-normalised, resized image (what inversion/h_edit.py:170-179 pulls back into the decoder).  Parameters by the
  * OpenAI CLIP state_dict names (`visual.conv1.weight`, `visual.transformer.resblocks.{i}.attn.in_proj_weight`, ...).
- * width / heads = 64; at most 264 tokens. */
+ * width / heads = 64; at most 200 tokens. */
 typedef struct hedit_vit hedit_vit;
 typedef struct { int width, layers, heads, patch_size, input_resolution; } hedit_vit_cfg;
 int hedit_vit_create(const hedit_vit_cfg* cfg, hedit_vit** out);
