@@ -49,8 +49,9 @@ struct Smem {
   static constexpr int A_BYTES = BM * BK * 2;
   static constexpr int W_BYTES = BN * BK * 2;
   static constexpr int STAGE = A_BYTES + W_BYTES;
-  static constexpr int STAGES = BM == 256 ? 3 : 2;
-  static constexpr int TOTAL = STAGES * STAGE;
+  static constexpr int STAGES = (BM == 256 && BN <= 160) ? 3 : 2;
+  static constexpr int EPI = BM * (BN + 8) * 2;          // the epilogue stages the output tile in the same LDS
+  static constexpr int TOTAL = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
 };
 
 // CHUNK: the in-block form of the canonical K-chunking (see gemm_canonical_chunk): the fp32 sum is formed
@@ -730,7 +731,18 @@ int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
 }  // namespace
 
 int gemm_pick_bn(int N);
-static int pick_bn(const GemmParams& p) { return p.geglu ? 128 : gemm_pick_bn(p.N); }
+static int ff1_bn() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("HEDIT_FF1_BN");
+    v = e ? atoi(e) : 256;       // 256 x 256 tile (8 waves, 64 x 128 each, two LDS stages): +13...18 % on the three FF1 shapes
+  }                               // over 256 x 128 (23 % less operand traffic per MFMA); HEDIT_FF1_BN=128 for A/B runs
+  return v;
+}
+static int pick_bn(const GemmParams& p) {
+  if (p.geglu) return (ff1_bn() == 256 && p.N % 256 == 0 && (long)cdiv(p.M, 256) * (p.N / 256) >= 200) ? 256 : 128;
+  return gemm_pick_bn(p.N);
+}
 
 int gemm_pick_bn(int N) {
   // smallest padded width wins; ties go to the wider tile
@@ -862,7 +874,9 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
     case 2: rc = launch_igemm<BNV, 2>(p, splits, st); break;              \
     default: rc = launch_igemm<BNV, 3>(p, splits, st); break;             \
   }
-  if (bn == 160) { DISPATCH(160) } else { DISPATCH(128) }
+  if (bn == 256) {
+    rc = launch_igemm_impl<256, 256, 0, false>(p, 1, st);     // FF1 + GEGLU only (no K-chunking there: 242 VGPRs, the fold would not fit)
+  } else if (bn == 160) { DISPATCH(160) } else { DISPATCH(128) }
 #undef DISPATCH
   if (rc != HEDIT_OK) return rc;
   if (splits > 1) {
