@@ -76,7 +76,7 @@ struct hedit_unet {
   // sampled launch timing (bench.py roofline): HIP event pairs on the launch stream
   bool prof_on = false;
   std::vector<hipEvent_t> prof_pool;
-  struct ProfRec { int kind; double flops, bytes; int e0, e1; };
+  struct ProfRec { int kind; double flops, bytes; int e0, e1; int m = 0, n = 0, k = 0, tag = 0; };
   std::vector<ProfRec> prof_recs;
   size_t prof_next = 0;
 };
@@ -215,7 +215,8 @@ struct ProfScope {
 // bytes = ALGORITHMIC HBM bytes of the launch(es) in the scope: every operand read once, every result written once
 ProfScope::ProfScope(Fwd& f, int kind, double flops, double bytes) : h(f.h), st(f.st) {
   if (f.dry() || !h->prof_on || h->prof_next + 2 > h->prof_pool.size()) return;
-  hedit_unet::ProfRec r{kind, flops, bytes, (int)h->prof_next, (int)h->prof_next + 1};
+  hedit_unet::ProfRec r;
+  r.kind = kind; r.flops = flops; r.bytes = bytes; r.e0 = (int)h->prof_next; r.e1 = (int)h->prof_next + 1;
   h->prof_next += 2;
   h->prof_recs.push_back(r);
   rec = (int)h->prof_recs.size() - 1;
@@ -253,6 +254,11 @@ int run_gemm(Fwd& f, GemmParams p, int batch_in = 1) {
   if (splits > 1) TRY(aalloc(f, &part, (size_t)splits * p.M * p.N));
   {
     ProfScope ps(f, p.mode == 0 ? PK_LINEAR : PK_CONV, 2.0 * p.M * p.N * p.K, gemm_alg_bytes(f, p));
+    if (ps.rec >= 0) {
+      auto& r = f.h->prof_recs[ps.rec];
+      r.m = p.M; r.n = p.N; r.k = p.K;
+      r.tag = p.mode | (p.geglu ? 8 : 0) | (p.residual ? 16 : 0) | (splits > 1 ? 32 : 0) | (p.chunk_kt ? 64 : 0);
+    }
     RUN(f, gemm_launch(p, splits, part, f.st));
   }
   if (part) f.ar.free(part);
@@ -841,6 +847,23 @@ int hedit_prof_collect(hedit_unet* h, int kind, double* total_ms, double* total_
     ++n;
   }
   *total_ms = ms; *total_flops = fl; *count = n;
+  return HEDIT_OK;
+} catch (...) { return hedit_abi_catch(); }
+
+/* one row per sampled launch, in launch order: kind, ms, flops, bytes, M, N, K, tag (GEMM launches: mode | 8 geglu |
+   16 residual | 32 split-K | 64 chunked); call after the stream has been synchronised */
+int hedit_prof_records(hedit_unet* h, double* rows, int max_rows, int* n_rows) try {
+  ARG_CHECK(h && rows && n_rows && max_rows >= 0, "prof args");
+  int n = 0;
+  for (auto& r : h->prof_recs) {
+    if (n >= max_rows) break;
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, h->prof_pool[r.e0], h->prof_pool[r.e1]));
+    double* o = rows + (size_t)n * 8;
+    o[0] = r.kind; o[1] = t; o[2] = r.flops; o[3] = r.bytes; o[4] = r.m; o[5] = r.n; o[6] = r.k; o[7] = r.tag;
+    ++n;
+  }
+  *n_rows = n;
   return HEDIT_OK;
 } catch (...) { return hedit_abi_catch(); }
 

@@ -70,6 +70,7 @@ _SIGS = {
     "hedit_prof_collect": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_int64)]),
     "hedit_prof_collect_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "hedit_prof_records": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
     "hedit_step_base": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                   C.c_int, C.POINTER(StepCoef), C.c_void_p]),
     "hedit_step_invert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -211,9 +211,11 @@ class HEditEngine:
 
         def p2p_pass(x_in, t, save):
             rows = x_in.shape[0]
-            plan = controller._plan(self.unet, rows, x_in.shape[2], x_in.shape[3], save)
+            # controller=None: the reference's processors then leave every attention map alone (ptp_utils.py:98-101)
+            plan = controller._plan(self.unet, rows, x_in.shape[2], x_in.shape[3], save) if controller is not None else None
             e = self.unet.forward_raw(x_in, t, ctx_edit5 if rows == 5 * n else ctx_edit, plan)
-            controller._after_pass(save)
+            if controller is not None:
+                controller._after_pass(save)
             return e
 
         carry = None      # (eps(x_orig, t, null), eps(x_orig, t, src)) from the previous P2P pass

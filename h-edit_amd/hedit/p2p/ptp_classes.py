@@ -73,12 +73,15 @@ def _blend_launch(x_t, maps, blends, n_img):
     heads = maps[0].numel() // (n_img * 2 * 256 * MAX_NUM_WORDS)
     alpha = torch.zeros(n_img, 2, MAX_NUM_WORDS)
     enabled = torch.zeros(n_img, dtype=torch.int32)
-    th = 0.3
+    th = None
     for i, lb in enumerate(blends):
         if lb is not None:
             alpha[i] = lb.alpha_layers.reshape(2, MAX_NUM_WORDS).cpu()
             enabled[i] = 1
-            th = lb.th[0]
+            if th is not None and float(lb.th[0]) != th:
+                raise ValueError("LocalBlend thresholds differ inside one lock-step batch (the blend kernel takes one)")
+            th = float(lb.th[0])
+    th = 0.3 if th is None else th
     alpha = alpha.to(x_t.device)
     enabled = enabled.to(x_t.device)
     arr = (C.c_void_p * len(maps))(*[m.data_ptr() for m in maps])
@@ -227,7 +230,10 @@ class AttentionStore(AttentionControl):
     def _plan(self, unet, B, H, W, save_attn):
         members = self._members()
         if self._state is None or self._state.key != (id(unet), B, H, W):
+            # a pass of another shape (4n rows, then 5n rows; another resolution): new device buffers -- the store must
+            # follow them, maps accumulated in the old buffers would be read by LocalBlend otherwise
             self._state = _PlanState(members, unet, B, H, W)
+            self.attention_store = {}
         if save_attn and not self.attention_store:
             self.attention_store = self._state.attention_store
         self._live_plan = self._state.plan(self.cur_step, self._self_window(), save_attn)

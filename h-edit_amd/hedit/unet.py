@@ -238,6 +238,15 @@ class UNet2DConditionModel:
             out[k] = b.value
         return out
 
+    def prof_records(self, max_rows=16384):
+        """numpy (n, 8): kind, ms, flops, bytes, M, N, K, tag per sampled launch, in launch order."""
+        import numpy as np
+        torch.cuda.synchronize(self.device)
+        rows = np.zeros((max_rows, 8), dtype=np.float64)
+        n = C.c_int()
+        _lib.check(self._lib.hedit_prof_records(self._h, rows.ctypes.data_as(C.POINTER(C.c_double)), max_rows, C.byref(n)))
+        return rows[:n.value]
+
     # ---------------------------------------------------------------- forward
     def forward_raw(self, sample, t, ctx, plan=None, out=None):
         """sample fp32 (B,C,H,W) cuda, t python float, ctx fp32 (B,77,D) cuda, plan: _lib.P2PPlan."""

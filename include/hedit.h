@@ -143,6 +143,9 @@ int hedit_prof_collect(hedit_unet* h, int kind, double* total_ms, double* total_
 /* algorithmic HBM bytes of the sampled launches of a class: every operand read once, every result written once
  * (what roofline.traffic, a PMC measurement, is compared with) */
 int hedit_prof_collect_bytes(hedit_unet* h, int kind, double* total_bytes);
+/* one row of 8 doubles per sampled launch, in launch order: kind, ms, flops, bytes, M, N, K, tag (GEMM launches only:
+ * mode | 8 GEGLU | 16 residual | 32 split-K | 64 chunked K); after synchronising the stream */
+int hedit_prof_records(hedit_unet* h, double* rows, int max_rows, int* n_rows);
 
 /* ---- sampler steps ------------------------------------------------------------------------
  * Batched tensors are [row][image][elems]: for one image this is exactly the reference layout.
