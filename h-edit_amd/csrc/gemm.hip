@@ -24,6 +24,7 @@
 //   * split-K (grid.y) for the low-resolution, weight-heavy layers: fp32 partial slabs + a
 //     reduce/epilogue kernel.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -52,6 +53,11 @@ struct Smem {
   static constexpr int STAGES = (BM == 256 && BN <= 160) ? 3 : 2;
   static constexpr int EPI = BM * (BN + 8) * 2;          // the epilogue stages the output tile in the same LDS
   static constexpr int TOTAL = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
+  // row-sharing 3x3 conv (kernel mode 4): two activation tiles + a ring of three weight tiles + one zero row per
+  // activation tile, placed at the same distance behind each of them
+  static constexpr int RS_W0 = 2 * A_BYTES;
+  static constexpr int RS_ZERO = RS_W0 + 3 * W_BYTES;               // zero row of activation tile 0 (tile 1: + A_BYTES)
+  static constexpr int RS_TOTAL = RS_ZERO + A_BYTES + 128;
 };
 
 // CHUNK: the in-block form of the canonical K-chunking (see gemm_canonical_chunk): the fp32 sum is formed
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       const int r = m - b * hw;
       const int oy = r / p.Wout;
       const int ox = r - oy * p.Wout;
-      if (MODE == 3) {
+      if (MODE == 3 || MODE == 5) {
         // 3x3 on the 2x nearest-upsampled image: tap (dy,dx) of output pixel (oy,ox) reads input
         // pixel ((oy+dy)>>1, (ox+dx)>>1) = (oy>>1, ox>>1) + (fy, fx) with fy = -1/0 for even oy
         // (dy = -1 / else) and 0/+1 for odd oy (else / dy = +1): the gather is again "centre
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       const int ci0 = (kt / 9) * BK;
       k0 = tap * p.Cin + ci0;
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      if (MODE == 3) {
+      if (MODE == 3 || MODE == 5) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
           const int fy = (a_oy[i] + dy) >> 1, fx = (a_ox[i] + dx) >> 1;      // in {-1, 0, +1}
@@ -215,6 +221,13 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
         const unsigned tapd = (unsigned)((dy * p.Win + dx) * p.Cin * 2);
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) d.a_voff[i] = ((a_mask[i] >> tap) & 1u) ? a_off[i] + tapd : OOB;
+#ifdef GEMM_EXP_DX
+        // timing experiment only (wrong results): activation rows fetched for the centre column of taps only
+        if (dx != 0) {
+#pragma unroll
+          for (int i = 0; i < A_CH; ++i) d.a_voff[i] = OOB;
+        }
+#endif
         d.a_soff = ci0 * 2;
       }
     }
@@ -297,7 +310,193 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   const int a_rd = (wm * 64 + fr) * 128 + rd_x;
   const int w_rd = (wn * (BN / 2) + fr) * 128 + rd_x;
 
-  if constexpr (S::STAGES == 3) {
+  if constexpr (MODE == 4 || MODE == 5) {
+    // ---- 3x3 stride-1 conv, the three taps of one kernel row share ONE staged activation tile.
+    // Output pixel m, tap (dy, dx) reads input pixel m + dy*W + dx: for a tile of 256 consecutive pixels the
+    // taps (dy,-1), (dy,0), (dy,+1) read the SAME 256 input rows shifted by one LDS row, so the tile is staged
+    // once per dy (the centre-tap gather, rows outside the image zero-filled by the buffer range check) and the
+    // fragment reads of the side taps address row +-1.  With W | 256 the tile starts at x = 0: the rows a shift
+    // would take from outside the tile (row -1, row 256) belong to pixels whose side tap is outside the image
+    // anyway, and those lanes read a zero row instead.  A K-tile then moves 1/3 activation tile + one weight tile
+    // from L2 (31 KB instead of 52 KB at BN = 160) with 13 instead of 21 LDS-DMA instructions per wave and three
+    // K-tiles; the MFMA chain of every output element is unchanged (same bits as modes 1 / the split-K path).
+    // Mode 5 = the same on the 2x nearest-upsampled image (mode 3's gather): the staged tile is a row of the
+    // UPSAMPLED image (input pixel ((oy+dy)>>1, ox>>1) for output-resolution pixel (oy, ox)), so the side taps are
+    // again one LDS row away and W below is the output width.
+    //   LDS: act tile g&1 (32 KB each) | weight ring, stage = tap column (3 x BN x 128 B) | zero rows
+    //   DMA: weights three K-tiles ahead (as the ring loop below); the activation tile of tap row g+1 in two halves
+    //        behind the weight DMAs of K-tiles (g-1,2) and (g,0), i.e. >= 2 K-tiles before its first use
+    constexpr int AP = S::A_BYTES;
+    static_assert(BM == 256 && A_CH == 4, "row-sharing conv: 256-row tile");
+    constexpr bool UP = MODE == 5;
+    const int Wimg = UP ? p.Wout : p.Win;
+    const int G = kt_total / 3;                 // tap rows: 3 per 64-channel slab
+    if (tid < 64) reinterpret_cast<uint32_t*>(smem + S::RS_ZERO + (tid >> 5) * AP)[tid & 31] = 0u;
+    // side-tap read offsets (relative to the activation tile): row -1 / +1, or the zero row at the image edge
+    int a_rdl[MI], a_rdr[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * 64 + i * 16 + fr;
+      const int x = (m0 + row) % Wimg;
+      const int rl = row - 1, rr = row + 1;
+      a_rdl[i] = x == 0 ? S::RS_ZERO + (fq << 4) : rl * 128 + ((fq ^ (rl & 7)) << 4);
+      a_rdr[i] = x == Wimg - 1 ? S::RS_ZERO + (fq << 4) : rr * 128 + ((fq ^ (rr & 7)) << 4);
+    }
+    bf16x8 xa[MI], wa[NI], xb[MI], wb[NI];
+    auto read_a = [&](int ab, int col, int ks, bf16x8 (&xf)[MI]) __attribute__((always_inline)) {
+      if (col == 1) {
+        const char* pa = smem + ab + (a_rd ^ (ks << 6));
+#pragma unroll
+        for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(pa + i * 2048);
+      } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          xf[i] = *reinterpret_cast<const bf16x8*>(smem + ab + ((col == 0 ? a_rdl[i] : a_rdr[i]) ^ (ks << 6)));
+      }
+    };
+    auto read_w = [&](int stage, int ks, bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
+      const char* pw = smem + S::RS_W0 + stage * S::W_BYTES + (w_rd ^ (ks << 6));
+#pragma unroll
+      for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + j * 2048);
+    };
+    auto mfmas = [&](const bf16x8 (&xf)[MI], const bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    };
+    // half `part` (DMA groups 2*part, 2*part+1 of this wave) of the activation tile of tap row g -> tile g&1
+    struct ASrc { unsigned v[2]; int s; };
+    // (register diet, mode 4: the pixel offset is linear in the pixel index, so DMA group i of this wave sits 8 pixels
+    //  = i * 8 * Cin * 2 bytes behind group 0; the centre-column validity of the three tap rows is 3 bits per group,
+    //  the row parity of the upsampling gather one more)
+    const unsigned a_off0 = a_off[0];
+    unsigned a_ok = 0;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      a_ok |= (((a_mask[i] >> 1) & 1u) | (((a_mask[i] >> 4) & 1u) << 1) | (((a_mask[i] >> 7) & 1u) << 2)) << (3 * i);
+      if (UP) a_ok |= (unsigned)(a_oy[i] & 1) << (12 + i);
+    }
+    const unsigned grp_step = (unsigned)(8 * p.Cin * 2);
+    const int row_bytes = p.Win * p.Cin * 2;
+    auto a_prep = [&](int g, int part, ASrc& d) __attribute__((always_inline)) {
+      const int slab = g / 3, dyi = g - slab * 3;
+      const bool live = g < G;                  // (one dummy half is issued past the end: keeps the vmcnt pattern)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int i = part * 2 + q;
+        const bool ok = live && ((a_ok >> (3 * i + dyi)) & 1u);
+        if (UP) {
+          const int fy = ((int)((a_ok >> (12 + i)) & 1u) + dyi - 1) >> 1;       // input row delta in {-1, 0, +1}
+          d.v[q] = ok ? a_off[i] + (unsigned)(fy * row_bytes) : OOB;
+        } else {
+          d.v[q] = ok ? a_off0 + (unsigned)i * grp_step + (unsigned)((dyi - 1) * row_bytes) : OOB;
+        }
+      }
+      d.s = slab * BK * 2;
+    };
+    auto a_fire = [&](int g, int part, const ASrc& d) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      char* sa = smem + (g & 1) * AP;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(sa + a_lds[part * 2 + q]), 16, d.v[q], d.s, 0, 0);
+#else
+      (void)g; (void)part; (void)d;
+#endif
+    };
+    auto w_fire = [&](int kt, int stage) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const int slab = kt / 9, tap = kt - slab * 9;
+      const int soff = (tap * p.Cin + slab * BK) * 2;
+      char* sw = smem + S::RS_W0 + stage * S::W_BYTES;
+#pragma unroll
+      for (int i = 0; i < W_CH; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(sw + w_lds[i]), 16, w_off[i], soff, 0, 0);
+#else
+      (void)kt; (void)stage;
+#endif
+    };
+    // prologue, in the issue order of the steady state: act(0) | w(0) | w(1) | [act(1) first half, w(2)]
+    ASrc asrc;
+    a_prep(0, 0, asrc); a_fire(0, 0, asrc);
+    a_prep(0, 1, asrc); a_fire(0, 1, asrc);
+    w_fire(0, 0);
+    w_fire(1, 1);
+    a_prep(1, 0, asrc); a_fire(1, 0, asrc);
+    w_fire(2, 2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * W_CH + 2) : "memory");
+    __builtin_amdgcn_s_barrier();
+    read_a(0, 0, 0, xa);
+    read_w(0, 0, wa);
+    // one K-tile = tap column `col` of tap row g.  fire: the DMA slot behind the mid-tile barrier.
+    auto tile = [&](auto col_c, int g, bool steady) __attribute__((always_inline)) {
+      constexpr int col = decltype(col_c)::value;
+      const int j = g * 3 + col;
+      const int ab = (g & 1) * AP;
+      read_a(ab, col, 1, xb);
+      read_w(col, 1, wb);
+      __builtin_amdgcn_s_setprio(1);
+      if (steady && col != 1) a_prep(col == 2 ? g + 2 : g + 1, col == 2 ? 0 : 1, asrc);
+      mfmas(xa, wa);
+#pragma unroll
+      for (int r = 0; r < MI * NI / 2; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);      // offsets of this K-tile's DMA slot
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (steady) {
+        // my DMAs of K-tile j+1 have landed: only the slot issued during K-tile j-1 may still be in flight
+        if (col == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(W_CH) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(W_CH + 2) : "memory");
+      } else if (col == 0) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(W_CH + 2) : "memory");
+      } else if (col == 1) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      __builtin_amdgcn_s_setprio(1);
+      if (col < 2) {
+        read_a(ab, col + 1, 0, xa);
+        read_w(col + 1, 0, wa);
+      } else if (steady) {
+        read_a(ab ^ AP, 0, 0, xa);
+        read_w(0, 0, wa);
+      }
+      if (steady) {
+        if (col != 1) a_fire(col == 2 ? g + 2 : g + 1, col == 2 ? 0 : 1, asrc);
+        w_fire(j + 3, col);
+      }
+      mfmas(xb, wb);
+      if (steady) {
+        constexpr int GR = (MI + NI + 1) / 2;                   // MFMA pairs that carry 2 fragment reads each
+#pragma unroll
+        for (int r = 0; r < MI * NI / 2; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // 2 MFMA
+          if (r < GR) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 ds_read
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);  // M0 + scalar offset
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 LDS-DMA
+          }
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if constexpr (CHUNK) {
+        if (j == next_flush && j + 1 < kt_total) { flush(); next_flush += p.chunk_kt; }
+      }
+    };
+    int g = 0;
+    for (; g + 1 < G; ++g) {
+      tile(std::integral_constant<int, 0>{}, g, true);
+      tile(std::integral_constant<int, 1>{}, g, true);
+      tile(std::integral_constant<int, 2>{}, g, true);
+    }
+    tile(std::integral_constant<int, 0>{}, g, false);
+    tile(std::integral_constant<int, 1>{}, g, false);
+    tile(std::integral_constant<int, 2>{}, g, false);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the epilogue
+  } else if constexpr (S::STAGES == 3) {
     // Three LDS stages as a ring with the DMA TWO tiles ahead and a counted vmcnt: the queue never
     // drains (one to two tiles = 52-104 KB in flight), which is what the measured ~0.85 us
     // issue-to-landed time of an LDS-DMA under load needs -- the 2-stage loop below can only give a
@@ -690,14 +889,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 template <int BM, int BN, int MODE, bool CHUNK>
 int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
   using S = Smem<BM, BN>;
+  constexpr int LDS = (MODE == 4 || MODE == 5) ? S::RS_TOTAL : S::TOTAL;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, S::TOTAL));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), splits);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, CHUNK>), grid, dim3(BM * 2), S::TOTAL, st, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, CHUNK>), grid, dim3(BM * 2), LDS, st, p);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }
@@ -723,6 +923,23 @@ int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
   const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.N, BN);
   const bool big = mode == 256 || (mode != 128 && splits == 1 && (p.geglu || p.K / BK >= 16) && tiles256 >= 200);
   const bool chunk = splits == 1 && p.chunk_kt > 0 && p.chunk_kt < p.K / BK;
+  if constexpr (MODE == 1) {
+    // stride-1 3x3 on the 256-row tile with an image width that divides it: the row-sharing loop (kernel mode 4)
+    static const bool rs_on = !(getenv("HEDIT_CONV_ROWSHARE") && atoi(getenv("HEDIT_CONV_ROWSHARE")) == 0);
+    if (rs_on && big && splits == 1 && p.Hout == p.Hin && p.Wout == p.Win && p.Win > 0 && 256 % p.Win == 0) {
+      if (!chunk) return launch_igemm_impl<256, BN, 4, false>(p, splits, st);
+      // (with the second accumulator set of the chunk fold the 160-column tile spills in this loop, also with a single
+      //  set of weight fragments refilled column by column: 128 columns only)
+      if constexpr (BN == 128) return launch_igemm_impl<256, BN, 4, true>(p, splits, st);
+    }
+  }
+  if constexpr (MODE == 3) {
+    static const bool rs_on = !(getenv("HEDIT_CONV_ROWSHARE") && atoi(getenv("HEDIT_CONV_ROWSHARE")) == 0);
+    if (rs_on && big && splits == 1 && p.Wout > 0 && 256 % p.Wout == 0) {
+      if (!chunk) return launch_igemm_impl<256, BN, 5, false>(p, splits, st);
+      if constexpr (BN == 128) return launch_igemm_impl<256, BN, 5, true>(p, splits, st);
+    }
+  }
   if (chunk)
     return big ? launch_igemm_impl<256, BN, MODE, true>(p, splits, st) : launch_igemm_impl<128, BN, MODE, true>(p, splits, st);
   return big ? launch_igemm_impl<256, BN, MODE, false>(p, splits, st) : launch_igemm_impl<128, BN, MODE, false>(p, splits, st);
@@ -856,6 +1073,11 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
   // 160-column tile would spill inside the K loop, so that one combination takes the 128-column tile
   // (the tile shape never changes a result)
   if (splits == 1 && p.chunk_kt > 0 && p.mode == 3) bn = 128;
+  // stride-1 3x3 with the chunk fold: the row-sharing loop exists for the 128-column tile only (+6 % over the
+  // 160-column tile of the plain loop when the narrower tiles still fill the chip)
+  if (splits == 1 && p.chunk_kt > 0 && p.mode == 1 && p.Hout == p.Hin && p.Wout == p.Win && p.Win > 0 && 256 % p.Win == 0 &&
+      p.N % 128 == 0 && (long)cdiv(p.M, 256) * (p.N / 128) >= 512)
+    bn = 128;
   if (p.geglu) {
     ARG_CHECK(p.N % 32 == 0 && p.mode == 0 && p.residual == nullptr && p.ldc % 8 == 0, "gemm: geglu epilogue needs N % 32 == 0, linear mode, no residual");
     ARG_CHECK(splits == 1 && p.chunk_kt == 0, "gemm: the geglu epilogue takes no K-chunking");

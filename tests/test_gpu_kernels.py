@@ -77,6 +77,45 @@ def test_gemm_conv3x3(lib, mode, B, H, Wd, Cin, Cout):
     assert G.rel_err(got, want) < 6e-3
 
 
+@pytest.mark.parametrize("mode,B,H,Cin,Cout,splits", [
+    (1, 100, 8, 128, 640, 0),      # W = 8: a 16-row sub-tile spans two image rows
+    (1, 100, 8, 128, 1024, -2),    # chunk fold on the 128-column tile
+    (1, 52, 16, 64, 640, 0), (1, 13, 64, 64, 320, 0), (1, 26, 32, 128, 256, -3), (1, 3, 128, 64, 192, 0),
+    (3, 56, 8, 64, 640, 0), (3, 14, 32, 64, 320, 0), (3, 52, 8, 128, 1024, -2)])
+def test_conv3x3_row_sharing_loop_bits(lib, mode, B, H, Cin, Cout, splits):
+    """Large launches of the stride-1 / upsampling 3x3 take the 256-row kernel whose three taps of a kernel row share one
+    staged activation tile (gemm.hip, kernel modes 4 / 5).  The MFMA chain per output element is the one of every other
+    loop, so: the first images equal, bit for bit, the same images convolved in a launch too small for that kernel, the
+    chunk fold equals the split-K slabs, and the whole result matches torch."""
+    g = torch.Generator().manual_seed(mode * 77 + B + Cin)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = G.f32(torch.randn(Cout, generator=g))
+    xb = G.bf(x.permute(0, 2, 3, 1))
+    wq = torch.empty(Cout * 9 * Cin, dtype=torch.bfloat16, device=G.dev())
+    wd = G.f32(w)
+    _lib.check(lib.hedit_k_pack_conv3x3(_lib.ptr(wd), _lib.ptr(wq), Cout, Cin, None))
+    Ho = H if mode == 1 else 2 * H
+    res = G.bf(torch.randn(B * Ho * Ho, Cout, generator=g))
+
+    def conv(n, sp):
+        return run_gemm(lib, xb[:n].contiguous(), wq, bias, res[: n * Ho * Ho].contiguous(), n * Ho * Ho, Cout, 9 * Cin, Cin, Cout, Cout,
+                        mode=mode, conv=(H, H, Cin, Ho, Ho), splits=sp)
+
+    big = conv(B, splits)
+    assert (B * Ho * Ho + 255) // 256 * ((Cout + 159) // 160) >= 200          # the 256-row kernel is the one that ran
+    small = conv(1, splits)
+    assert torch.equal(big[: Ho * Ho], small)
+    if splits < 0:
+        assert torch.equal(big, conv(B, -splits))
+    xr = xb.float().permute(0, 3, 1, 2)
+    if mode == 3:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    want = F.conv2d(xr, G.bf(w).float(), bias, padding=1).permute(0, 2, 3, 1).reshape(B * Ho * Ho, Cout)
+    want = want.to(torch.bfloat16).float() + res.float()
+    assert G.rel_err(big.float(), want) < 6e-3
+
+
 @pytest.mark.parametrize("B,HW,Cc,silu", [(2, 256, 64, 1), (4, 4096, 320, 1), (2, 64, 1280, 0), (1, 1024, 960, 1),
                                            (2, 256, 2560, 1), (3, 100, 128, 0)])
 def test_groupnorm(lib, B, HW, Cc, silu):
