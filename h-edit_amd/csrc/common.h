@@ -89,25 +89,30 @@ __device__ inline float gelu_erf_fast(float x) {
   return 0.5f * x * (1.0f + erfv);
 }
 
-// v * gelu(x) for two values at once on the packed-fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32): the
-// same A&S 7.1.26 erf as gelu_erf_fast with the Horner chain as real FMAs, 11 VALU instructions per
-// element instead of 23 (this unit is built with -ffp-contract=off, so the scalar form above stays
-// separate multiplies and adds).  GEGLU epilogues are VALU-bound, see DESIGN.md.
+// v * gelu(x) for two values at once on the packed-fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32).  GEGLU epilogues are
+// VALU-bound (a 256 x 256 FF1 tile spends as long in this function as in its K = 320 MFMA loop), and transcendental
+// instructions issue at quarter rate, so erf is taken from Abramowitz-Stegun 7.1.28,
+//   erf(z) = 1 - (1 + a1 z + ... + a6 z^6)^-16,  |error| <= 3e-7,
+// one v_rcp per element and no v_exp (7.1.26, used by gelu_erf_fast above, needs both): |gelu error| < 1e-6 absolute,
+// far below the bf16 output resolution.  The 1/sqrt(2) of z = |x| / sqrt(2) is folded into the coefficients; a
+// denominator that overflows to +inf gives erf = 1, as it should.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ inline f32x2 mul_gelu2(f32x2 v, f32x2 x) {
-  const f32x2 ax = __builtin_elementwise_abs(x) * 0.70710678118654752f;
-  const f32x2 d = __builtin_elementwise_fma(ax, (f32x2){0.3275911f, 0.3275911f}, (f32x2){1.f, 1.f});
-  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-  f32x2 poly = {1.061405429f, 1.061405429f};
-  poly = __builtin_elementwise_fma(poly, t, (f32x2){-1.453152027f, -1.453152027f});
-  poly = __builtin_elementwise_fma(poly, t, (f32x2){1.421413741f, 1.421413741f});
-  poly = __builtin_elementwise_fma(poly, t, (f32x2){-0.284496736f, -0.284496736f});
-  poly = __builtin_elementwise_fma(poly, t, (f32x2){0.254829592f, 0.254829592f});
-  poly *= t;
-  const f32x2 a2 = ax * ax * -1.4426950408889634f;
-  const f32x2 e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
-  // Phi(x) = 0.5 + sign(x) * 0.5 * erf|.| ,  0.5 * erf|.| = 0.5 - 0.5 * poly * e
-  const f32x2 h = __builtin_elementwise_fma(poly * -0.5f, e, (f32x2){0.5f, 0.5f});
+  const f32x2 ax = __builtin_elementwise_abs(x);
+  f32x2 q = {5.3829750e-06f, 5.3829750e-06f};                                        // a6 * 2^-3
+  q = __builtin_elementwise_fma(q, ax, (f32x2){4.8890634e-05f, 4.8890634e-05f});     // a5 * 2^-2.5
+  q = __builtin_elementwise_fma(q, ax, (f32x2){3.8003575e-05f, 3.8003575e-05f});     // a4 * 2^-2
+  q = __builtin_elementwise_fma(q, ax, (f32x2){3.2776263e-03f, 3.2776263e-03f});     // a3 * 2^-1.5
+  q = __builtin_elementwise_fma(q, ax, (f32x2){2.1141006e-02f, 2.1141006e-02f});     // a2 * 2^-1
+  q = __builtin_elementwise_fma(q, ax, (f32x2){4.9867347e-02f, 4.9867347e-02f});     // a1 * 2^-0.5
+  q = __builtin_elementwise_fma(q, ax, (f32x2){1.f, 1.f});
+  q *= q;
+  q *= q;
+  q *= q;
+  q *= q;
+  const f32x2 r = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
+  // Phi(x) = 0.5 + sign(x) * 0.5 * erf|.| ,  0.5 * erf|.| = 0.5 - 0.5 * r
+  const f32x2 h = __builtin_elementwise_fma(r, (f32x2){-0.5f, -0.5f}, (f32x2){0.5f, 0.5f});
   const f32x2 hs = {copysignf(h[0], x[0]), copysignf(h[1], x[1])};
   return v * x * (hs + 0.5f);
 }

@@ -732,6 +732,12 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     }
     return;
   }
+#ifdef GEMM_EXP_NOEPI        // timing experiment only
+  if (p.geglu) {
+    if (acc[0][0][0] == 123.456f) p.C[0] = 1;
+    return;
+  }
+#endif
   if (p.geglu) {
     // FF1 with the GEGLU fused: weight rows were interleaved at load time so that sub-tiles
     // (j, j+1) of a wave are (value, gate) of the same 16 output columns:
@@ -739,21 +745,30 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     if constexpr ((NI & 1) == 0) {
       constexpr int ON = BN / 2, CSG = ON + 8;
       bf16_t* sg = reinterpret_cast<bf16_t*>(smem);
+      // the bias of every column pair is requested up front, all at once (the fragment registers are free now): inside
+      // the loop each pair paid its own dependent global-load round trip, 16 of them in a row on the 256-column tile
+      f32x4 bv[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int nb = n0 + wn * (BN / 2) + j * 16 + fq * 4;
+        bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias && nb < p.N) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + nb);
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int ml = wm * 64 + i * 16 + fr;
 #pragma unroll
         for (int j = 0; j < NI; j += 2) {
-          const int nv = n0 + wn * (BN / 2) + j * 16 + fq * 4;      // interleaved column of the value
-          f32x4 v = acc[i][j], g = acc[i][j + 1];
-          if (p.bias && nv + 16 < p.N + 16) {
-            v += *reinterpret_cast<const f32x4*>(p.bias + nv);
-            g += *reinterpret_cast<const f32x4*>(p.bias + nv + 16);
-          }
+          const f32x4 v = acc[i][j] + bv[j], g = acc[i][j + 1] + bv[j + 1];      // (no bias: + 0)
           const int ol = wn * (ON / 2) + (j / 2) * 16 + fq * 4;      // output column inside the tile
           uint2 o;
+#ifdef GEMM_EXP_NOGELU      // timing experiment only
+          const f32x2 r0 = (f32x2){v[0], v[1]} * (f32x2){g[0], g[1]};
+          const f32x2 r1 = (f32x2){v[2], v[3]} * (f32x2){g[2], g[3]};
+#else
           const f32x2 r0 = mul_gelu2((f32x2){v[0], v[1]}, (f32x2){g[0], g[1]});
           const f32x2 r1 = mul_gelu2((f32x2){v[2], v[3]}, (f32x2){g[2], g[3]});
+#endif
           o.x = pack_bf16x2(r0[0], r0[1]);
           o.y = pack_bf16x2(r1[0], r1[1]);
           *reinterpret_cast<uint2*>(sg + ml * CSG + ol) = o;
@@ -762,11 +777,26 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       __syncthreads();
       constexpr int GCH = ON / 8;
       const int on0 = n0 / 2;
-      for (int idx = tid; idx < BM * GCH; idx += NT) {
+#ifdef GEMM_EXP_NOSTORE     // timing experiment only
+      if (p.M > 0) return;
+#endif
+      // all LDS reads of a thread first, then its stores: as a rolled loop every 16-byte piece waited for its own LDS
+      // round trip before the store could issue
+      constexpr int GIT = BM * GCH / NT;
+      static_assert(BM * GCH % NT == 0, "geglu tile rows must divide evenly over the block");
+      u32x4 og[GIT];
+#pragma unroll
+      for (int it = 0; it < GIT; ++it) {
+        const int idx = tid + it * NT;
+        const int ml = idx / GCH, c = idx - ml * GCH;
+        og[it] = *reinterpret_cast<const u32x4*>(sg + ml * CSG + c * 8);
+      }
+#pragma unroll
+      for (int it = 0; it < GIT; ++it) {
+        const int idx = tid + it * NT;
         const int ml = idx / GCH, c = idx - ml * GCH;
         const int m = m0 + ml, n = on0 + c * 8;
-        if (m >= p.M || n >= p.N / 2) continue;
-        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = *reinterpret_cast<const uint4*>(sg + ml * CSG + c * 8);
+        if (m < p.M && n < p.N / 2) *reinterpret_cast<u32x4*>(p.C + (long)m * p.ldc + n) = og[it];
       }
     }
     return;
@@ -821,20 +851,30 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
                        bf16_to_f32((bf16_t)(a >> 16)) + bf16_to_f32((bf16_t)(b >> 16)));
   };
   if (aligned8) {
+    // all LDS reads of a thread first (every piece is inside the staged tile), then the residual adds, then the
+    // stores under their range checks: with the check in front, each piece waited for its own LDS round trip
+    u32x4 ov[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * NT;
+      const int ml = idx / CHUNKS, c = idx - ml * CHUNKS;
+      ov[it] = *reinterpret_cast<const u32x4*>(sc + ml * CS + c * 8);
+    }
+    if (p.residual) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        ov[it][0] = add2(ov[it][0], resid[it][0]);
+        ov[it][1] = add2(ov[it][1], resid[it][1]);
+        ov[it][2] = add2(ov[it][2], resid[it][2]);
+        ov[it][3] = add2(ov[it][3], resid[it][3]);
+      }
+    }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int idx = tid + it * NT;
       const int ml = idx / CHUNKS, c = idx - ml * CHUNKS;
       const int m = m0 + ml, n = n0 + c * 8;
-      if (m >= p.M || n >= p.N) continue;
-      u32x4 u = *reinterpret_cast<const u32x4*>(sc + ml * CS + c * 8);
-      if (p.residual) {
-        u[0] = add2(u[0], resid[it][0]);
-        u[1] = add2(u[1], resid[it][1]);
-        u[2] = add2(u[2], resid[it][2]);
-        u[3] = add2(u[3], resid[it][3]);
-      }
-      *reinterpret_cast<u32x4*>(p.C + (long)m * p.ldc + n) = u;
+      if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(p.C + (long)m * p.ldc + n) = ov[it];
     }
   } else {
     // ragged right edge (N % 8 == 4) or rows that are only 8-byte aligned: 8-byte pieces
