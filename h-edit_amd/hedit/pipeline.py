@@ -34,7 +34,7 @@ class HEditPipeline:
             from .vae import AutoencoderKL
             vae = AutoencoderKL(vae_config, device=device)
             vae.init_random(seed + 11)
-        return cls(unet, DDIMScheduler(), WordTokenizer(), enc, vae, device)
+        return cls(unet, DDIMScheduler(), WordTokenizer(stable_ids=True), enc, vae, device)
 
     @classmethod
     def from_pretrained(cls, path, device="cuda:0", tokenizer=None, text_encoder=None):

@@ -8,6 +8,7 @@ HEditPipeline instead.
 """
 import math
 import types
+import zlib
 
 import torch
 import torch.nn as nn
@@ -19,16 +20,25 @@ class WordTokenizer:
     model_max_length = 77
     bos_token_id, eos_token_id = 49406, 49407
 
-    def __init__(self, vocab_size=49408):
+    def __init__(self, vocab_size=49408, stable_ids=False):
         self.vocab_size = vocab_size
+        self.stable_ids = stable_ids
         self._ids = {}
         self._words = {}
 
     def _id(self, w):
+        # default: ids in order of first sight (what the committed golden vectors were generated with).  stable_ids: a
+        # word's id is a function of the word (CRC-32 into the id range; a collision moves to the next free id), so a
+        # synthetic-weights run gives a prompt the same embedding whether its image is edited alone or inside a
+        # lock-step batch (the drivers' --random_init pipelines)
         if w not in self._ids:
-            i = 1 + len(self._ids)
-            if i >= self.bos_token_id:
+            if len(self._ids) >= self.bos_token_id - 1:
                 raise RuntimeError("WordTokenizer vocabulary exhausted")
+            i = 1 + len(self._ids)
+            if self.stable_ids:
+                i = 1 + zlib.crc32(w.encode("utf-8")) % (self.bos_token_id - 1)
+                while i in self._words:
+                    i = 1 + i % (self.bos_token_id - 1)
             self._ids[w] = i
             self._words[i] = w
         return self._ids[w]

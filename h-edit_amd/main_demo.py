@@ -62,6 +62,7 @@ def build_parser():
     p.add_argument("--random_init", action="store_true", help="synthetic SD-1.x-shaped weights (no checkpoint)")
     p.add_argument("--tiny", action="store_true", help="with --random_init: the small test configuration")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--batch", type=int, default=1, help="demo entries edited in lock-step per pass (batched engine)")
     return p
 
 
@@ -109,6 +110,26 @@ def main(argv=None):
     size = model.unet.sample_size * model.vae.factor
 
     written = []
+    if args.batch > 1:
+        # lock-step groups on the batched engine (main_p2p.edit_group), with this driver's replace / equalizer rules
+        from main_p2p import edit_group
+        mine = list(D.shard(len(full_data), rank, world))
+        sub = (args.mode + '_total_steps_' + str(args.num_diffusion_steps) + '_skip_' + str(args.skip) + '_' +
+               weight_string + xa_sa_string)
+        for lo in range(0, len(mine), args.batch):
+            entries = []
+            for idx in mine[lo:lo + args.batch]:
+                it = full_data[idx]
+                src = it.get("source_prompt", "").replace("[", "").replace("]", "")
+                tar = it.get("target_prompt", "").replace("[", "").replace("]", "")
+                _, eq_heuristic = preprocessing(src, tar, is_global_edit=True)
+                item = {"original_prompt": src, "editing_prompt": tar, "blended_word": it["blended_word"],
+                        "_replace": len(src.split(" ")) == len(tar.split(" ")), "_eq_extra": eq_heuristic}
+                image_path = data_path + it["image"]
+                entries.append((str(idx), item, image_path, image_path.replace(data_path, os.path.join(output_path, sub))))
+            written += edit_group(args, model, entries, scale, size, device)
+        print(f"rank {rank}/{world}: wrote {len(written)} image(s)")
+        return written
     for idx in D.shard(len(full_data), rank, world):
         item = full_data[idx]
         eta = args.eta

@@ -52,6 +52,7 @@ def build_parser():
     p.add_argument("--random_init", action="store_true", help="synthetic SD-1.x-shaped weights (no checkpoint)")
     p.add_argument("--tiny", action="store_true", help="with --random_init: the small test configuration")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--batch", type=int, default=1, help="dataset entries edited in lock-step per pass (batched engine)")
     return p
 
 
@@ -61,6 +62,46 @@ def load_image(image_path, device, size=512):
     a = torch.from_numpy(np.asarray(Image.open(image_path).convert("RGB"), dtype=np.uint8).copy()).permute(2, 0, 1)
     image = a[:3].unsqueeze(0).float() / 127.5 - 1.
     return torch.nn.functional.interpolate(image, (size, size)).to(device)
+
+
+def edit_group(args, model, entries, scale, size, device):
+    """--batch N: the n entries of one group in lock-step on hedit.engine.HEditEngine (rows [x_orig|null]*n,
+    [x_k|null]*n, [x_orig|src]*n, [x_k|tar]*n: the mutual self-attention plan already maps row (kind, i) to the source
+    row of image i).  entries: [(item, image_path, save_path)].  Same per-image arithmetic as the one-image path."""
+    from hedit.engine import HEditEngine
+    eng = HEditEngine(model)
+    eta = args.eta
+    is_ddim_inversion = eta == 0
+    if is_ddim_inversion:
+        model.scheduler = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                        clip_sample=False, set_alpha_to_one=False)
+    model.scheduler.config.timestep_spacing = "leading"
+    model.scheduler.set_timesteps(args.num_diffusion_steps)
+    n = len(entries)
+    xs = torch.cat([load_image(ip, device, size) for _, ip, _ in entries])
+    w0 = (model.vae.encode(xs).latent_dist.mean * scale).float()
+    src_p = [""] * n                      # MasaCtrl runs without the source prompt (main_masactrl.py:178)
+    tar_p = [item["editing_prompt"].replace("[", "").replace("]", "") for item, _, _ in entries]
+    if is_ddim_inversion:
+        _, zs, wts = eng.ddim_inversion(w0, src_p, args.cfg_src)
+        eta = 1.0
+    elif 0 < eta <= 1:
+        zs, wts = eng.ddpm_inversion(w0, src_p, eta=eta, cfg_src=args.cfg_src)
+    else:
+        raise SystemExit("Warning: out of range for eta")
+    editor = MutualSelfAttentionControl(args.step, args.layer)
+    regiter_attention_editor_diffusers(model, editor)
+    after = args.num_diffusion_steps - args.skip
+    edited, _ = eng.run(wts[after].contiguous(), zs[:after].contiguous(), [[a, b] for a, b in zip(src_p, tar_p)],
+                        [args.cfg_src, args.cfg_src_edit, args.cfg_tar], editor, eta=eta, p2p=True, implicit=True,
+                        K=args.optimization_steps, after_skip_steps=after, ddim_inv=is_ddim_inversion, rec_pull=False)
+    x0_dec = model.vae.decode(1 / scale * edited).sample
+    out = []
+    for i, (_, _, save_path) in enumerate(entries):
+        os.makedirs(os.path.dirname(save_path), exist_ok=True)
+        image_grid(x0_dec[i:i + 1]).save(save_path)
+        out.append(save_path)
+    return out
 
 
 def main(argv=None):
@@ -90,6 +131,19 @@ def main(argv=None):
     size = model.unet.sample_size * model.vae.factor
     keys = [k for k, item in full_data.items() if item["editing_type_id"] in args.edit_category_list]
     written = []
+    if args.batch > 1:
+        mine = list(D.shard(len(keys), rank, world))
+        sub = (args.mode + '_total_steps_' + str(args.num_diffusion_steps) + '_skip_' + str(args.skip) + '_' +
+               weight_string + step_layer_string)
+        for lo in range(0, len(mine), args.batch):
+            entries = []
+            for idx in mine[lo:lo + args.batch]:
+                item = full_data[keys[idx]]
+                image_path = os.path.join(f"{data_path}/annotation_images", item["image_path"])
+                entries.append((item, image_path, image_path.replace(data_path, os.path.join(output_path, sub))))
+            written += edit_group(args, model, entries, scale, size, device)
+        print(f"rank {rank}/{world}: wrote {len(written)} image(s)")
+        return written
     for idx in D.shard(len(keys), rank, world):
         item = full_data[keys[idx]]
         eta = args.eta

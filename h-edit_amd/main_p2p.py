@@ -118,10 +118,16 @@ def edit_group(args, model, entries, scale, size, device):
         blended_word = item["blended_word"].split(" ") if item["blended_word"] != "" else []
         same_len = len(original_prompt.split(" ")) == len(editing_prompt.split(" "))
         replace = same_len and key in (_REPLACE_KEYS_DDIM if is_ddim_inversion else _REPLACE_KEYS_DDPM)
+        if "_replace" in item:            # (the demo driver's rule: main_demo.py)
+            replace = item["_replace"]
         if args.mode.endswith('p2p'):
             blend_word = ((blended_word[0],), (blended_word[1],)) if len(blended_word) else None
             eq_val = 1.25 if args.optimization_steps > 1 else 2.0
             eq_params = {"words": (blended_word[1],), "values": (eq_val,)} if len(blended_word) else None
+            extra = item.get("_eq_extra")
+            if extra is not None:
+                eq_params = extra if eq_params is None else {"words": eq_params["words"] + extra["words"],
+                                                             "values": eq_params["values"] + extra["values"]}
             ctrls.append(make_controller(prompts=[original_prompt, editing_prompt], is_replace_controller=replace,
                                          cross_replace_steps=args.xa, self_replace_steps=args.sa, blend_word=blend_word,
                                          equilizer_params=eq_params, num_steps=after_skip_steps, tokenizer=model.tokenizer,
@@ -233,6 +239,8 @@ def main(argv=None):
         after_skip_steps = args.num_diffusion_steps - args.skip
         same_len = len(original_prompt.split(" ")) == len(editing_prompt.split(" "))
         replace = same_len and key in (_REPLACE_KEYS_DDIM if is_ddim_inversion else _REPLACE_KEYS_DDPM)
+        if "_replace" in item:            # (the demo driver's rule: main_demo.py)
+            replace = item["_replace"]
         prompts = [original_prompt, editing_prompt]
         if args.mode.endswith('p2p'):
             blend_word = ((blended_word[0],), (blended_word[1],)) if len(blended_word) else None

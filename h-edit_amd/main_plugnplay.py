@@ -51,6 +51,7 @@ def build_parser():
     p.add_argument("--random_init", action="store_true", help="synthetic SD-1.x-shaped weights (no checkpoint)")
     p.add_argument("--tiny", action="store_true", help="with --random_init: the small test configuration")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--batch", type=int, default=1, help="dataset entries edited in lock-step per pass (batched engine)")
     return p
 
 
@@ -76,6 +77,45 @@ def load_pnp_model(args, device):
         vcfg.update(block_out_channels=(64, 64, 128))                 # f = 4: 256 x 256 images
         return HEditPipeline.from_random(ucfg, seed=args.seed, device=device, text_layers=2, vae_config=vcfg)
     return load_model(args, device)
+
+
+def edit_group(args, model, entries, scale, size, device):
+    """--batch N: the n entries of one group in lock-step (hedit.engine.HEditEngine.run_pnp: the injected pass has rows
+    [x_orig|src]*n, [x_k|tar]*n and row n + i takes row i's q, k / features).  entries: [(item, image_path, save_path)]."""
+    from hedit.engine import HEditEngine
+    eng = HEditEngine(model)
+    eta = args.eta
+    is_ddim_inversion = eta == 0
+    if is_ddim_inversion:
+        model.scheduler = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                        clip_sample=False, set_alpha_to_one=False)
+    model.scheduler.config.timestep_spacing = "leading"
+    model.scheduler.set_timesteps(args.num_diffusion_steps)
+    xs = torch.cat([load_image(ip, device, size) for _, ip, _ in entries])
+    w0 = (model.vae.encode(xs).latent_dist.mean * scale).float()
+    src_p = [item["original_prompt"].replace("[", "").replace("]", "") for item, _, _ in entries]
+    tar_p = [item["editing_prompt"].replace("[", "").replace("]", "") for item, _, _ in entries]
+    if is_ddim_inversion:
+        _, zs, wts = eng.ddim_inversion(w0, src_p, args.cfg_src)
+        eta = 1.0
+    elif 0 < eta <= 1:
+        zs, wts = eng.ddpm_inversion(w0, src_p, eta=eta, cfg_src=args.cfg_src)
+    else:
+        raise SystemExit("Warning: out of range for eta")
+    after = args.num_diffusion_steps - args.skip
+    pnp_f_t, pnp_attn_t = int(after * args.pnp_f_t), int(after * args.pnp_attn_t)
+    register_attention_control_efficient(model, model.scheduler.timesteps[:pnp_attn_t] if pnp_attn_t >= 0 else [])
+    register_conv_control_efficient(model, model.scheduler.timesteps[:pnp_f_t] if pnp_f_t >= 0 else [])
+    edited, _ = eng.run_pnp(wts[after].contiguous(), zs[:after].contiguous(), [[a, b] for a, b in zip(src_p, tar_p)],
+                            [args.cfg_src, args.cfg_src_edit, args.cfg_tar], eta=eta, K=args.optimization_steps,
+                            after_skip_steps=after, ddim_inv=is_ddim_inversion)
+    x0_dec = model.vae.decode(1 / scale * edited).sample
+    out = []
+    for i, (_, _, save_path) in enumerate(entries):
+        os.makedirs(os.path.dirname(save_path), exist_ok=True)
+        image_grid(x0_dec[i:i + 1]).save(save_path)
+        out.append(save_path)
+    return out
 
 
 def main(argv=None):
@@ -105,6 +145,19 @@ def main(argv=None):
     size = model.unet.sample_size * model.vae.factor
     keys = [k for k, item in full_data.items() if item["editing_type_id"] in args.edit_category_list]
     written = []
+    if args.batch > 1:
+        mine = list(D.shard(len(keys), rank, world))
+        sub = (args.mode + '_total_steps_' + str(args.num_diffusion_steps) + '_skip_' + str(args.skip) + '_' +
+               weight_string + step_layer_string)
+        for lo in range(0, len(mine), args.batch):
+            entries = []
+            for idx in mine[lo:lo + args.batch]:
+                item = full_data[keys[idx]]
+                image_path = os.path.join(f"{data_path}/annotation_images", item["image_path"])
+                entries.append((item, image_path, image_path.replace(data_path, os.path.join(output_path, sub))))
+            written += edit_group(args, model, entries, scale, size, device)
+        print(f"rank {rank}/{world}: wrote {len(written)} image(s)")
+        return written
     for idx in D.shard(len(keys), rank, world):
         item = full_data[keys[idx]]
         eta = args.eta

@@ -212,6 +212,58 @@ def test_demo_driver_writes_edited_images(tmp_path):
         assert np.array(Image.open(written[0])).shape == (256, 256, 3)
 
 
+def _load_driver(fname):
+    spec = importlib.util.spec_from_file_location("hedit_" + fname.replace(".", "_"), os.path.join(ROOT, "h-edit_amd", fname))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    return drv
+
+
+@pytest.mark.parametrize("fname,extra", [
+    ("main_masactrl.py", ["--edit_category_list", "0", "7", "--step", "1", "--layer", "2", "--optimization_steps", "2"]),
+    ("main_plugnplay.py", ["--edit_category_list", "0", "1", "--mode", "h_edit_D_pnp", "--eta", "0.0", "--pnp_f_t", "0.6",
+                           "--pnp_attn_t", "0.4"])])
+def test_masactrl_and_pnp_drivers_batch_flag(tmp_path, fname, extra):
+    """--batch 2 on the MasaCtrl and Plug-and-Play drivers: two entries in lock-step on the batched engine; h-Edit-D draws no
+    random numbers and the kernels are batch-invariant, so the PNGs are byte-identical to the one-at-a-time run."""
+    from PIL import Image
+    drv = _load_driver(fname)
+    d = _dataset(tmp_path)
+    common = ["--data_path", str(d), "--random_init", "--tiny", "--num_diffusion_steps", "4"] + extra
+    one = drv.main(common + ["--output_path", str(tmp_path / "r1")])
+    two = drv.main(common + ["--output_path", str(tmp_path / "r2"), "--batch", "2"])
+    assert len(one) == len(two) == 2
+    for a, b in zip(sorted(one), sorted(two)):
+        assert os.path.basename(a) == os.path.basename(b)
+        assert np.array_equal(np.array(Image.open(a)), np.array(Image.open(b)))
+
+
+def test_demo_driver_batch_flag(tmp_path):
+    """--batch 2 on the demo driver (its own replace / equalizer rules handed to the lock-step group)"""
+    import yaml
+    from PIL import Image
+    drv = _load_driver("main_demo.py")
+    d = tmp_path / "demo"
+    d.mkdir()
+    y, x = np.mgrid[0:96, 0:128]
+    Image.fromarray(np.stack([(x * 3) % 256, (y * 5) % 256, (x + y) % 256], -1).astype(np.uint8)).save(d / "lizard.png")
+    Image.fromarray(np.stack([(x * 7) % 256, (y * 2) % 256, (x * y) % 256], -1).astype(np.uint8)).save(d / "cat.png")
+    with open(d / "demo.yaml", "w") as f:
+        yaml.safe_dump([dict(image="/lizard.png", source_prompt="a green lizard is sitting on a branch",
+                             target_prompt="a brown lizard is sitting on a branch", blended_word="lizard lizard",
+                             editing_instruction=""),
+                        dict(image="/cat.png", source_prompt="a cat", target_prompt="a cat wearing a big hat", blended_word="",
+                             editing_instruction="")], f)
+    common = ["--data_path", str(d), "--random_init", "--tiny", "--num_diffusion_steps", "4", "--mode", "h_edit_D_p2p",
+              "--eta", "0.0", "--implicit"]
+    one = drv.main(common + ["--output_path", str(tmp_path / "r1")])
+    two = drv.main(common + ["--output_path", str(tmp_path / "r2"), "--batch", "2"])
+    assert len(one) == len(two) == 2
+    for a, b in zip(sorted(one), sorted(two)):
+        assert os.path.basename(a) == os.path.basename(b)
+        assert np.array_equal(np.array(Image.open(a)), np.array(Image.open(b)))
+
+
 def test_face_driver_writes_swapped_images(tmp_path, capsys):
     """main_edit_face.py (reference face-swapping/main_edit.py:134-224): {idx, source, ref} pairs -> inversion, h_Edit_R with
     the identity reward, a [ref | source | result] sheet per pair; with and without the post-processing mask."""

@@ -61,7 +61,8 @@ def test_driver_flags_match_the_reference_cli():
                               implicit=False, optimization_steps=1, weight_reconstruction=0.1, xa=0.4, sa=0.35)
     for k, v in reference_defaults.items():
         assert a[k] == v, k
-    assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed"}
+    assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed", "batch"}
+    assert a["batch"] == 1
     b = vars(m.build_parser().parse_args(["--implicit", "--mode", "h_edit_D_p2p", "--eta", "0.0", "--edit_category_list", "0", "3"]))
     assert b["implicit"] is True and b["eta"] == 0.0 and b["edit_category_list"] == ["0", "3"]
 
@@ -81,7 +82,7 @@ def test_style_driver_flags_match_the_reference_cli():
                               weight_edit_clip_for_ef=1.5)
     for k, v in reference_defaults.items():
         assert a[k] == v, k
-    assert set(a) - set(reference_defaults) == {"model_path", "clip_path", "random_init", "tiny", "seed"}
+    assert set(a) - set(reference_defaults) == {"model_path", "clip_path", "random_init", "tiny", "seed", "batch"}
 
 
 def test_masactrl_driver_flags_match_the_reference_cli():
@@ -98,7 +99,8 @@ def test_masactrl_driver_flags_match_the_reference_cli():
                               weight_reconstruction=0.1, layer=10, step=4)
     for k, v in reference_defaults.items():
         assert a[k] == v, k
-    assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed"}
+    assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed", "batch"}
+    assert a["batch"] == 1
 
 
 def test_pnp_driver_flags_match_the_reference_cli():
@@ -115,7 +117,8 @@ def test_pnp_driver_flags_match_the_reference_cli():
                               weight_reconstruction=0.1, pnp_f_t=0.45, pnp_attn_t=0.35)
     for k, v in reference_defaults.items():
         assert a[k] == v, k
-    assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed"}
+    assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed", "batch"}
+    assert a["batch"] == 1
 
 
 def test_demo_driver_flags_match_the_reference_cli():
@@ -131,7 +134,8 @@ def test_demo_driver_flags_match_the_reference_cli():
                               optimization_steps=1, weight_reconstruction=0.1, xa=0.4, sa=0.35)
     for k, v in reference_defaults.items():
         assert a[k] == v, k
-    assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed"}
+    assert set(a) - set(reference_defaults) == {"model_path", "random_init", "tiny", "seed", "batch"}
+    assert a["batch"] == 1
 
 
 def test_face_driver_flags_match_the_reference_cli():
@@ -148,7 +152,7 @@ def test_face_driver_flags_match_the_reference_cli():
                               optimization_steps=3, post_processing=True, weight_edit_face=50.0)
     for k, v in reference_defaults.items():
         assert a[k] == v, k
-    assert set(a) - set(reference_defaults) == {"ddpm_ckpt", "arcface_ckpt", "mask_dir", "random_init", "tiny", "seed"}
+    assert set(a) - set(reference_defaults) == {"ddpm_ckpt", "arcface_ckpt", "mask_dir", "random_init", "tiny", "seed", "batch", "lpips_ckpt", "no_lpips"}
 
 
 def test_soft_erosion_and_segmentation_encoding():
