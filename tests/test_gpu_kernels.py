@@ -80,6 +80,7 @@ def test_gemm_conv3x3(lib, mode, B, H, Wd, Cin, Cout):
 @pytest.mark.parametrize("mode,B,H,Cin,Cout,splits", [
     (1, 100, 8, 128, 1280, 0),     # W = 8: a 16-row sub-tile spans two image rows
     (1, 100, 8, 128, 1024, -2),    # chunk fold on the 128-column tile
+    (1, 101, 8, 64, 1280, 0),      # ragged last tile (rows beyond M), four images per tile
     (1, 52, 16, 64, 640, 0), (1, 13, 64, 64, 320, 0), (1, 26, 32, 128, 256, -3), (1, 3, 128, 64, 192, 0),
     (3, 56, 8, 64, 640, 0), (3, 14, 32, 64, 320, 0), (3, 52, 8, 128, 1024, -2)])
 def test_conv3x3_row_sharing_loop_bits(lib, mode, B, H, Cin, Cout, splits):
