@@ -1,6 +1,7 @@
 // HBM-bound kernels around the GEMMs: GroupNorm(+SiLU), LayerNorm, GEGLU, concat, casts, the
 // time-embedding GEMV chain, conv_in / conv_out and weight packing.  NHWC bf16 activations, all
 // global accesses 16 B per lane along the contiguous channel axis, fp32 statistics.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -132,6 +133,41 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
       for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
     }
     *reinterpret_cast<uint4*>(y + i * 8) = pack8(f);
+  }
+}
+
+// stage 3, row form: a thread keeps ONE group of 8 channels (its 8 scale / shift pairs in registers) and walks the pixels
+// of its slab, so an iteration is one 16-byte load and one 16-byte store; the form above re-reads 64 bytes of the
+// coefficient table per 16 bytes of data.  Same arithmetic per element.
+__global__ __launch_bounds__(256) void gn_apply_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                            const float* __restrict__ ss, int HW, int C, int silu, int nslab) {
+  const int CV = C / 8;
+  const int slab = blockIdx.x, b = blockIdx.y;
+  const int pix_per = (HW + nslab - 1) / nslab;
+  const int p0 = slab * pix_per;
+  int p1 = p0 + pix_per;
+  if (p1 > HW) p1 = HW;
+  const int R = 256 / CV;                     // (launched only for CV <= 256)
+  const int r = threadIdx.x / CV;
+  const int cv = threadIdx.x - r * CV;
+  if (r >= R) return;
+  const float4* t = reinterpret_cast<const float4*>(ss + ((long)b * C + cv * 8) * 2);
+  const float4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+  const bf16_t* xb = x + (long)b * HW * C + cv * 8;
+  bf16_t* yb = y + (long)b * HW * C + cv * 8;
+  for (int p = p0 + r; p < p1; p += R) {
+    uint4 u = *reinterpret_cast<const uint4*>(xb + (long)p * C);
+    float f[8];
+    unpack8(u, f);
+    f[0] = f[0] * t0.x + t0.y; f[1] = f[1] * t0.z + t0.w;
+    f[2] = f[2] * t1.x + t1.y; f[3] = f[3] * t1.z + t1.w;
+    f[4] = f[4] * t2.x + t2.y; f[5] = f[5] * t2.z + t2.w;
+    f[6] = f[6] * t3.x + t3.y; f[7] = f[7] * t3.z + t3.w;
+    if (silu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+    }
+    *reinterpret_cast<uint4*>(yb + (long)p * C) = pack8(f);
   }
 }
 
@@ -489,6 +525,16 @@ int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, gamma, beta, ss, HW, C, G, nslab, eps, stats);
   LAUNCH_CHECK();
   const long total_v = (long)B * HW * CV;
+  static const bool rows_on = !(getenv("HEDIT_GN_APPLY_ROWS") && atoi(getenv("HEDIT_GN_APPLY_ROWS")) == 0);
+  if (rows_on && CV <= 256 && HW >= 1024) {      // (smaller images: too few pixels per thread row to pay for the set-up)
+    // enough slabs for >= ~4096 workgroups over the batch, at least 8 pixels per thread row
+    int ns = (int)(4096 / (B > 0 ? B : 1)) + 1;
+    const int max_ns = HW / (R * 8) > 0 ? HW / (R * 8) : 1;
+    if (ns > max_ns) ns = max_ns;
+    hipLaunchKernelGGL(gn_apply_rows_kernel, dim3(ns, B), dim3(256), 0, st, x, y, ss, HW, C, silu, ns);
+    LAUNCH_CHECK();
+    return HEDIT_OK;
+  }
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(total_v)), dim3(256), 0, st, x, y, ss, total_v, HW, C, silu);
   LAUNCH_CHECK();
   return HEDIT_OK;
