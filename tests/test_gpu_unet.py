@@ -180,3 +180,31 @@ def test_c_abi_error_paths(tiny):
     h = C.c_void_p()
     assert lib.hedit_unet_create(C.byref(bad), C.byref(h)) != 0
     assert b"head dim" in lib.hedit_last_error() or b"block_out_channels" in lib.hedit_last_error()
+
+
+def test_per_launch_profile_records(tiny):
+    """hedit_prof_enable / hedit_prof_records: one row per sampled launch in launch order (class, ms, flops, algorithmic
+    bytes, M, N, K, tag); the per-class totals of hedit_prof_collect are the sums of the rows; profiling never changes a
+    result."""
+    hip, _, _ = tiny
+    x, ctx = _inputs(3, TINY_CONFIG, 77)
+    kw = dict(encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"use_controller": False})
+    plain = hip.unet(G.f32(x), 321, **kw).sample
+    hip.unet.prof_enable(True, 4096)
+    hip.unet.prof_reset()
+    prof = hip.unet(G.f32(x), 321, **kw).sample
+    rows = hip.unet.prof_records()
+    totals = hip.unet.prof_collect()
+    hip.unet.prof_enable(False, 4096)
+    assert torch.equal(plain, prof)
+    kinds = hip.unet.PROF_KINDS
+    assert rows.shape[1] == 8 and rows.shape[0] == sum(v[2] for v in totals.values()) > 50
+    assert set(rows[:, 0].astype(int)) <= set(range(len(kinds))) and (rows[:, 1] > 0).all()
+    for i, k in enumerate(kinds):
+        sel = rows[rows[:, 0] == i]
+        assert abs(sel[:, 1].sum() - totals[k][0]) < 1e-3 * max(1.0, totals[k][0])
+        assert abs(sel[:, 2].sum() - totals[k][1]) <= 1e-6 * max(1.0, totals[k][1])
+    gemm = rows[(rows[:, 0] <= 1) & (rows[:, 4] > 0)]
+    assert len(gemm) > 20
+    assert ((gemm[:, 2] - 2.0 * gemm[:, 4] * gemm[:, 5] * gemm[:, 6]) == 0).all()      # flops = 2 M N K of the recorded shape
+    assert (gemm[:, 6] % 64 == 0).all()

@@ -160,3 +160,19 @@ def test_sample_xts_and_slerp_helpers():
     assert torch.allclose(slerp_tensor(0.0, a, b), a, atol=1e-5) and torch.allclose(slerp_tensor(1.0, a, b), b, atol=1e-5)
     mid = slerp(0.5, a.flatten(1), b.flatten(1))
     assert mid.shape == (2, 48)
+
+
+def test_word_tokenizer_stable_ids_do_not_depend_on_prompt_order():
+    """The synthetic-weights pipelines (drivers with --random_init, HEditPipeline.from_random) give a word the same id
+    whatever was tokenised before it, so a prompt embeds identically alone and inside a lock-step batch; the default
+    (ids in order of first sight) is what the golden vectors were generated with and stays."""
+    from hedit.text import WordTokenizer
+    a, b = WordTokenizer(stable_ids=True), WordTokenizer(stable_ids=True)
+    p1, p2 = "a cat sitting on a bench", "a blue car on a road"
+    ia1, ia2 = a.encode(p1), a.encode(p2)
+    ib2, ib1 = b.encode(p2), b.encode(p1)
+    assert ia1 == ib1 and ia2 == ib2
+    assert a.decode(ia1[1:-1]) == p1.replace(" ", "")
+    assert len(set(ia1[1:-1])) == len(set(p1.split(" ")))
+    c, d = WordTokenizer(), WordTokenizer()
+    assert c.encode(p1)[1:4] == [1, 2, 3] and d.encode(p2)[1:4] == [1, 2, 3]
