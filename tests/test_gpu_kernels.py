@@ -337,6 +337,17 @@ def test_step_kernels_match_reference_vectors(lib, golden_dir):
                 G.sync()
                 want = torch.from_numpy(g[f"prev_t{t}_eta{int(eta)}_ddim{int(ddim)}"])
                 assert G.max_err(out, want) < 2e-5 * max(1.0, want.abs().max().item())
+        # hedit_step_tweedie against the reference's reverse_step_pred_x0 (inversion_utils.py:128-140; g2 tweedie_t*),
+        # eps handed over as its CFG parts (e_u + w (e_c - e_u) with e_u = 0.25 eps, e_c = 0.5 eps, w = 3) and whole
+        ab = float(sch.alphas_cumprod[t])
+        want0 = torch.from_numpy(g[f"tweedie_t{t}"])
+        for eu, ec, w in ((0.25 * eps, 0.5 * eps, 3.0), (eps, eps, 7.5)):
+            eud, ecd, xd = G.f32(eu), G.f32(ec), G.f32(x)
+            z0 = torch.zeros_like(xd)
+            _lib.check(lib.hedit_step_tweedie(_lib.ptr(eud), _lib.ptr(ecd), elems, _lib.ptr(xd), _lib.ptr(z0), x.shape[0], elems,
+                                              w, math.sqrt(ab), math.sqrt(1.0 - ab), 1.0, None))
+            G.sync()
+            assert G.max_err(z0, want0) < 2e-5 * max(1.0, want0.abs().max().item())
     # update kernel, k = 0 and k > 0, two images
     gen = torch.Generator().manual_seed(3)
     n, el = 2, 4 * 16 * 16
