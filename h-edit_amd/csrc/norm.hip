@@ -225,25 +225,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 // 128-byte line per load), a wave normalises 8 rows, and the two reductions stay inside the 8-lane
 // groups.  Same arithmetic order per row as layernorm_kernel up to the reduction tree.
 constexpr int LNN_MAXV = 5;
+template <int LANES>     // 8 / 16 / 32 lanes per row, up to LNN_MAXV 16-byte chunks per lane (C = 320 / 640 / 1280: five each)
 __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                long rows, int C, float eps) {
-  const int l8 = threadIdx.x & 7;
-  const long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int l8 = threadIdx.x & (LANES - 1);
+  const long row = (long)blockIdx.x * (256 / LANES) + threadIdx.x / LANES;
   const bool live = row < rows;
-  const int CV = C / 8, NV = CV / 8;       // chunks per row, chunks per lane
+  const int CV = C / 8, NV = CV / LANES;       // chunks per row, chunks per lane
   float f[LNN_MAXV][8];
   float s = 0.f;
 #pragma unroll
   for (int v = 0; v < LNN_MAXV; ++v) {
     if (v < NV && live) {
-      uint4 u = *reinterpret_cast<const uint4*>(x + row * C + (l8 + v * 8) * 8);
+      uint4 u = *reinterpret_cast<const uint4*>(x + row * C + (l8 + v * LANES) * 8);
       unpack8(u, f[v]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += f[v][j];
     }
   }
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+#pragma unroll
+  for (int o = 1; o < LANES; o <<= 1) s += __shfl_xor(s, o, 64);
   const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
@@ -253,12 +255,13 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const bf16_t* __r
       for (int j = 0; j < 8; ++j) { float d = f[v][j] - mean; q += d * d; }
     }
   }
-  q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+#pragma unroll
+  for (int o = 1; o < LANES; o <<= 1) q += __shfl_xor(q, o, 64);
   const float rstd = rsqrtf(q / (float)C + eps);
 #pragma unroll
   for (int v = 0; v < LNN_MAXV; ++v) {
     if (v < NV && live) {
-      const int cv = l8 + v * 8;
+      const int cv = l8 + v * LANES;
       const float4* g4 = reinterpret_cast<const float4*>(gamma + cv * 8);
       const float4* b4 = reinterpret_cast<const float4*>(beta + cv * 8);
       float4 g0 = g4[0], g1 = g4[1], b0 = b4[0], b1 = b4[1];
@@ -544,7 +547,17 @@ int layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float
                      float eps, hipStream_t st) {
   ARG_CHECK(C % 8 == 0 && C / 8 <= 64 * LN_MAXV, "layernorm: C");
   if (C % 64 == 0 && C / 64 <= LNN_MAXV) {     // 8 lanes per row
-    hipLaunchKernelGGL(layernorm_narrow_kernel, dim3(cdiv(rows, 32)), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps);
+    hipLaunchKernelGGL(layernorm_narrow_kernel<8>, dim3(cdiv(rows, 32)), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps);
+    LAUNCH_CHECK();
+    return HEDIT_OK;
+  }
+  if (C % 128 == 0 && C / 128 <= LNN_MAXV) {   // 16 lanes per row (C = 640)
+    hipLaunchKernelGGL(layernorm_narrow_kernel<16>, dim3(cdiv(rows, 16)), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps);
+    LAUNCH_CHECK();
+    return HEDIT_OK;
+  }
+  if (C % 256 == 0 && C / 256 <= LNN_MAXV) {   // 32 lanes per row (C = 1280)
+    hipLaunchKernelGGL(layernorm_narrow_kernel<32>, dim3(cdiv(rows, 8)), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps);
     LAUNCH_CHECK();
     return HEDIT_OK;
   }

@@ -4,6 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
 import torch
 from hedit import _lib
+v = os.environ.get("HEDIT_LIB_VARIANT")
+if v:
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"lib_{v}.so.bin")
 lib = _lib.lib(); dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 
