@@ -410,23 +410,25 @@ __global__ void timestep_embed_ddpm_kernel(float t, float* out, int dim) {
 }
 
 // ------------------------------------------------------------------ conv_in (Cin <= 8, K = 9 Cin tiny -> VALU)
-// Block = 64 consecutive pixels x all output channels.  The 9*Cin input taps of the block's pixels
+// Block = CI_PIX consecutive pixels x all output channels.  The 9*Cin input taps of the block's pixels
 // and the whole (transposed) weight matrix live in LDS; a thread produces 8 consecutive output
-// channels of one pixel -> 16-byte NHWC stores.
+// channels of FOUR pixels (the weight vector of a tap is read once for the four: the loop is LDS-read-bound) -> 16-byte
+// NHWC stores.  Every output element is the same k-ordered fp32 chain whatever the blocking.
+constexpr int CI_PIX = 128;
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                       bf16_t* __restrict__ y, int B, int Cin, int H, int Wd, int Cout) {
   extern __shared__ float lds[];
   const int K = Cin * 9;
   float* sw = lds;                    // [K][Cout]   (k = ci*9 + tap)
-  float* sx = lds + (long)K * Cout;   // [64][K]
+  float* sx = lds + (long)K * Cout;   // [K][CI_PIX]  (tap-major: the four pixels of a thread are one 16-byte read)
   for (int i = threadIdx.x; i < K * Cout; i += 256) {
     const int co = i / K, k = i - co * K;      // global layout [Cout][Cin][3][3] = [Cout][K]
     sw[k * Cout + co] = w[i];
   }
-  const long pix0 = (long)blockIdx.x * 64;
+  const long pix0 = (long)blockIdx.x * CI_PIX;
   const long npix = (long)B * H * Wd;
-  for (int i = threadIdx.x; i < 64 * K; i += 256) {
-    const int pl = i / K, k = i - pl * K;
+  for (int i = threadIdx.x; i < CI_PIX * K; i += 256) {
+    const int k = i / CI_PIX, pl = i - k * CI_PIX;
     const long pix = pix0 + pl;
     float v = 0.f;
     if (pix < npix) {
@@ -435,25 +437,33 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
       const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
       if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd) v = x[(((long)b * Cin + ci) * H + iy) * Wd + ix];
     }
-    sx[pl * K + k] = v;
+    sx[k * CI_PIX + pl] = v;
   }
   __syncthreads();
   const int CV = Cout / 8;
-  for (int i = threadIdx.x; i < 64 * CV; i += 256) {
-    const int pl = i / CV, cv = i - pl * CV;
-    const long pix = pix0 + pl;
-    if (pix >= npix) continue;
-    float acc[8];
+  for (int i = threadIdx.x; i < (CI_PIX / 4) * CV; i += 256) {
+    const int pg = i / CV, cv = i - pg * CV;           // pixel group (4 pixels), channel group (8 channels)
+    float acc[4][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = bias[cv * 8 + j];
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[q][j] = bias[cv * 8 + j];
     for (int k = 0; k < K; ++k) {
-      const float xv = sx[pl * K + k];
+      const float4 xv = *reinterpret_cast<const float4*>(sx + k * CI_PIX + pg * 4);
       const float4 w0 = *reinterpret_cast<const float4*>(sw + k * Cout + cv * 8);
       const float4 w1 = *reinterpret_cast<const float4*>(sw + k * Cout + cv * 8 + 4);
-      acc[0] += xv * w0.x; acc[1] += xv * w0.y; acc[2] += xv * w0.z; acc[3] += xv * w0.w;
-      acc[4] += xv * w1.x; acc[5] += xv * w1.y; acc[6] += xv * w1.z; acc[7] += xv * w1.w;
+      const float xq[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[q][0] += xq[q] * w0.x; acc[q][1] += xq[q] * w0.y; acc[q][2] += xq[q] * w0.z; acc[q][3] += xq[q] * w0.w;
+        acc[q][4] += xq[q] * w1.x; acc[q][5] += xq[q] * w1.y; acc[q][6] += xq[q] * w1.z; acc[q][7] += xq[q] * w1.w;
+      }
     }
-    *reinterpret_cast<uint4*>(y + pix * Cout + cv * 8) = pack8(acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long pix = pix0 + pg * 4 + q;
+      if (pix < npix) *reinterpret_cast<uint4*>(y + pix * Cout + cv * 8) = pack8(acc[q]);
+    }
   }
 }
 
@@ -659,8 +669,8 @@ int timestep_embed_ddpm_launch(float t, float* out, int dim, hipStream_t st) {
 int conv_in_launch(const float* x, const float* w, const float* bias, bf16_t* y, int B, int Cin, int H, int W,
                    int Cout, hipStream_t st) {
   ARG_CHECK(Cout % 8 == 0, "conv_in: Cout % 8");
-  const size_t lds = ((size_t)Cin * 9 * Cout + 64 * (size_t)Cin * 9) * sizeof(float);
-  ARG_CHECK(lds <= 160 * 1024, "conv_in: Cin*9*(Cout+64) floats must fit 160 KiB of LDS");
+  const size_t lds = ((size_t)Cin * 9 * Cout + CI_PIX * (size_t)Cin * 9) * sizeof(float);
+  ARG_CHECK(lds <= 160 * 1024, "conv_in: Cin*9*(Cout+128) floats must fit 160 KiB of LDS");
   if (lds > 64 * 1024) {
     static size_t attr_set = 0;
     if (lds > attr_set) {
@@ -668,7 +678,7 @@ int conv_in_launch(const float* x, const float* w, const float* bias, bf16_t* y,
       attr_set = lds;
     }
   }
-  hipLaunchKernelGGL(conv_in_kernel, dim3(cdiv((long)B * H * W, 64)), dim3(256), lds, st, x, w, bias, y, B, Cin, H, W, Cout);
+  hipLaunchKernelGGL(conv_in_kernel, dim3(cdiv((long)B * H * W, CI_PIX)), dim3(256), lds, st, x, w, bias, y, B, Cin, H, W, Cout);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }
