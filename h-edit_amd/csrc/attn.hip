@@ -107,11 +107,7 @@ struct SelfCfg {
   static constexpr int KI = DCH, VI = D / 8;           // 1 KiB DMA instructions per tile (K, V^T)
   static constexpr int TI = KI + VI, NI = (TI + 3) / 4;
   // LDS ring: 4 stages (DMA two tiles ahead) when two workgroups of that still fit a CU, else 3
-#ifdef SA_NSTG3
-  static constexpr int NSTG = 3;
-#else
   static constexpr int NSTG = 2 * 4 * STAGE <= 160 * 1024 ? 4 : 3;
-#endif
   static constexpr int PD = NSTG - 2;                  // prefetch distance in KV tiles
   static constexpr int DUMP = TI % 4 ? 4096 : 0;       // parking area for DMA slots without a chunk
   static constexpr int TOTAL = NSTG * STAGE + DUMP;
@@ -476,7 +472,6 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
   constexpr int my_dma = C::NI;
   auto hand_over = [&](int tn) __attribute__((always_inline)) {
     if (tn < ntiles) {
-#ifndef SA_NOBAR     // (SA_NOBAR / SA_NODMA: measurement-only builds, see tools/build_variant.sh)
       if (C::PD == 2 && tn + 1 < ntiles) {
         // tile tn has landed when at most the DMAs of tile tn+1 are outstanding
         if (my_dma == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -487,10 +482,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       asm volatile("s_barrier" ::: "memory");
-#endif
-#ifndef SA_NODMA
       if (tn + C::PD < ntiles) dma_tile(tn + C::PD, (tn + C::PD) % C::NSTG);
-#endif
     }
   };
 

@@ -232,11 +232,10 @@ int conv3x3(VF& f, const bf16_t* X, int Hin, int Win, int Cin, const bf16_t* W, 
 }
 
 // conv3x3 (stride 1, pad 1) with Cout <= 4 output channels, fp32 NCHW result: the [*][4] fp32 products of an N = 4 MFMA
-// GEMM (weights [4][9 C], rows beyond Cout zero) + a bias / layout pass.  HEDIT_CONVOUT=valu selects the older
-// one-wave-per-pixel kernel (A/B runs); it is also the path when C is not a multiple of 64.
+// GEMM (weights [4][9 C], rows beyond Cout zero) + a bias / layout pass; the one-wave-per-pixel kernel remains for
+// channel counts that are not a multiple of 64.
 int conv_out(VF& f, const bf16_t* x, int H, int W, int C, const bf16_t* w, const float* bias, int Cout, float* y) {
-  static const bool valu = [] { const char* e = getenv("HEDIT_CONVOUT"); return e && std::string(e) == "valu"; }();
-  if (valu || C % 64 != 0) {
+  if (C % 64 != 0) {
     RUN(f, conv_out_launch(x, w, bias, y, f.B, H, W, C, Cout, f.st));
     return HEDIT_OK;
   }

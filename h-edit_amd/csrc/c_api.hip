@@ -139,6 +139,28 @@ int hedit_k_gemm_geglu(const void* A, const void* w_packed, const float* bias_pa
   return gemm_launch(p, 1, nullptr, S(stream));
 } catch (...) { return hedit_abi_catch(); }
 
+int hedit_k_ffn_channels(void) { return ffn_fused_channels(); }
+size_t hedit_k_ffn_stream_bytes(void) { return ffn_stream_bytes(); }
+size_t hedit_k_ffn_bias_bytes(void) { return ffn_bias_bytes(); }
+
+int hedit_k_ffn_pack(const float* w1, const float* b1, const float* w2, void* stream_out, float* bias1_out, void* stream) try {
+  ARG_CHECK(w1 && b1 && w2 && stream_out && bias1_out, "ffn_pack args");
+  int rc = ffn_pack_launch(w1, nullptr, reinterpret_cast<bf16_t*>(stream_out), S(stream));
+  if (rc != HEDIT_OK) return rc;
+  rc = ffn_pack_launch(nullptr, w2, reinterpret_cast<bf16_t*>(stream_out), S(stream));
+  if (rc != HEDIT_OK) return rc;
+  return ffn_pack_bias_launch(b1, bias1_out, S(stream));
+} catch (...) { return hedit_abi_catch(); }
+
+int hedit_k_ffn_fused(const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* w_stream,
+                      const float* bias1_packed, const float* bias2, void* out, int64_t ldo, int M, int C, void* stream) try {
+  FfnParams f{};
+  f.x = reinterpret_cast<const bf16_t*>(x); f.ldx = (long)ldx; f.gamma = gamma; f.beta = beta; f.eps = eps;
+  f.stream = reinterpret_cast<const bf16_t*>(w_stream); f.bias1p = bias1_packed; f.bias2 = bias2;
+  f.out = reinterpret_cast<bf16_t*>(out); f.ldo = (long)ldo; f.M = M; f.C = C;
+  return ffn_fused_launch(f, S(stream));
+} catch (...) { return hedit_abi_catch(); }
+
 size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C) { return groupnorm_ws_bytes(B, HW, C); }
 
 int hedit_k_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G,

@@ -23,17 +23,10 @@
 //     ahead, counted vmcnt -- the queue never drains.
 //   * split-K (grid.y) for the low-resolution, weight-heavy layers: fp32 partial slabs + a
 //     reduce/epilogue kernel.
-#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
-
-// Build-time switches, MEASUREMENT ONLY (tools/build_variant.sh builds a side library with them; the
-// product library never defines any): GEMM_NODMA (K loop without operand traffic), GEMM_NOBAR (and
-// without the mid-tile barrier), GEMM_NOMFMA (operand traffic without the multiply),
-// GEMM_LOAD_NOLDS (same global loads into dead registers instead of LDS), GEMM_AUX_A / GEMM_AUX_W
-// (cache-policy bits of the LDS-DMA).  Their results are in DESIGN.md section 5, item 8.
 
 namespace {
 
@@ -221,49 +214,21 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
         const unsigned tapd = (unsigned)((dy * p.Win + dx) * p.Cin * 2);
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) d.a_voff[i] = ((a_mask[i] >> tap) & 1u) ? a_off[i] + tapd : OOB;
-#ifdef GEMM_EXP_DX
-        // timing experiment only (wrong results): activation rows fetched for the centre column of taps only
-        if (dx != 0) {
-#pragma unroll
-          for (int i = 0; i < A_CH; ++i) d.a_voff[i] = OOB;
-        }
-#endif
         d.a_soff = ci0 * 2;
       }
     }
     d.w_soff = k0 * 2;
   };
-#ifndef GEMM_AUX_A
-#define GEMM_AUX_A 0
-#endif
-#ifndef GEMM_AUX_W
-#define GEMM_AUX_W 0
-#endif
   auto fire_dma = [&](int buf, const DmaArgs& d) __attribute__((always_inline)) {
     char* sa = smem + buf * S::STAGE;
     char* sw = sa + S::A_BYTES;
 #if defined(__HIP_DEVICE_COMPILE__)
-#ifdef GEMM_LOAD_NOLDS
-    // timing experiment only: the same global traffic, landing in dead registers instead of LDS
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      u32x4 t = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, d.a_voff[i], d.a_soff, 0));
-      asm volatile("" ::"v"(t));
-    }
-#pragma unroll
-    for (int i = 0; i < W_CH; ++i) {
-      u32x4 t = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[i], d.w_soff, 0));
-      asm volatile("" ::"v"(t));
-    }
-    (void)sa; (void)sw;
-#else
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(sa + a_lds[i]), 16, d.a_voff[i], d.a_soff, 0, GEMM_AUX_A);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(sa + a_lds[i]), 16, d.a_voff[i], d.a_soff, 0, 0);
 #pragma unroll
     for (int i = 0; i < W_CH; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(sw + w_lds[i]), 16, w_off[i], d.w_soff, 0, GEMM_AUX_W);
-#endif
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(sw + w_lds[i]), 16, w_off[i], d.w_soff, 0, 0);
 #else
     (void)sa; (void)sw; (void)d;
 #endif
@@ -607,9 +572,6 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + j * 2048);
     };
     auto mfma_group = [&](const bf16x8 (&xf)[MI], const bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
-#ifdef GEMM_NOMFMA
-      acc[0][0][1] += (float)xf[0][0] + (float)wf[0][0] + (float)xf[MI - 1][7] + (float)wf[NI - 1][7];
-#else
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -617,7 +579,6 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
-#endif
     };
     // Steady state of one K-tile i (two MFMA groups of MI*NI, one barrier between them):
     //   group 1 = MFMAs of k-step 0, with the fragment reads of k-step 1 in front and the source
@@ -652,16 +613,11 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       }
     };
     auto mfmas = [&](const bf16x8 (&xf)[MI], const bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
-#ifdef GEMM_NOMFMA
-      // timing experiment only: operand traffic without the multiply
-      acc[0][0][0] += (float)xf[0][0] + (float)wf[0][0] + (float)xf[MI - 1][7] + (float)wf[NI - 1][7];
-#else
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-#endif
     };
     if (nk > 0) {
       issue_glds(kt_begin, 0);
@@ -678,14 +634,10 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       mfmas(xa, wa);
       weave_prep();
       __builtin_amdgcn_s_setprio(0);
-#ifndef GEMM_NOBAR
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
       __builtin_amdgcn_s_setprio(1);
       read_frags(cur ^ 1, 0, xa, wa);
-#ifndef GEMM_NODMA
       fire_dma(cur, nsrc);
-#endif
       mfmas(xb, wb);
       weave_fire();
       __builtin_amdgcn_s_setprio(0);
@@ -732,12 +684,6 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     }
     return;
   }
-#ifdef GEMM_EXP_NOEPI        // timing experiment only
-  if (p.geglu) {
-    if (acc[0][0][0] == 123.456f) p.C[0] = 1;
-    return;
-  }
-#endif
   if (p.geglu) {
     // FF1 with the GEGLU fused: weight rows were interleaved at load time so that sub-tiles
     // (j, j+1) of a wave are (value, gate) of the same 16 output columns:
@@ -762,13 +708,8 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
           const f32x4 v = acc[i][j] + bv[j], g = acc[i][j + 1] + bv[j + 1];      // (no bias: + 0)
           const int ol = wn * (ON / 2) + (j / 2) * 16 + fq * 4;      // output column inside the tile
           uint2 o;
-#ifdef GEMM_EXP_NOGELU      // timing experiment only
-          const f32x2 r0 = (f32x2){v[0], v[1]} * (f32x2){g[0], g[1]};
-          const f32x2 r1 = (f32x2){v[2], v[3]} * (f32x2){g[2], g[3]};
-#else
           const f32x2 r0 = mul_gelu2((f32x2){v[0], v[1]}, (f32x2){g[0], g[1]});
           const f32x2 r1 = mul_gelu2((f32x2){v[2], v[3]}, (f32x2){g[2], g[3]});
-#endif
           o.x = pack_bf16x2(r0[0], r0[1]);
           o.y = pack_bf16x2(r1[0], r1[1]);
           *reinterpret_cast<uint2*>(sg + ml * CSG + ol) = o;
@@ -777,9 +718,6 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       __syncthreads();
       constexpr int GCH = ON / 8;
       const int on0 = n0 / 2;
-#ifdef GEMM_EXP_NOSTORE     // timing experiment only
-      if (p.M > 0) return;
-#endif
       // all LDS reads of a thread first, then its stores: as a rolled loop every 16-byte piece waited for its own LDS
       // round trip before the store could issue
       constexpr int GIT = BM * GCH / NT;
@@ -946,27 +884,17 @@ int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
 // than the 4-wave 128-row kernel when the K loop is long and there is at least one tile per CU
 // (3x3 convs, FF2: 1.17-1.26 vs 1.10-1.16 PF/s) and for the fused FF1+GEGLU at every K (+2 / +9 /
 // +14 % at K = 320 / 640 / 1280: half as many tiles pay the GELU epilogue's LDS pass); plain
-// launches with few K-tiles lose to its longer per-tile prologue / epilogue (K = 320: -3...-9 %).  HEDIT_GEMM_BM=128|256 forces one of them (A/B runs).
+// launches with few K-tiles lose to its longer per-tile prologue / epilogue (K = 320: -3...-9 %).
 // (The tile shape never changes a result: every output element is the same k-ordered MFMA chain.)
-static int big_tile_mode() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("HEDIT_GEMM_BM");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
 
 template <int BN, int MODE>
 int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
-  const int mode = big_tile_mode();
   const long tiles256 = (long)cdiv(p.M, 256) * cdiv(p.N, BN);
-  const bool big = mode == 256 || (mode != 128 && splits == 1 && (p.geglu || p.K / BK >= 16) && tiles256 >= 200);
+  const bool big = splits == 1 && (p.geglu || p.K / BK >= 16) && tiles256 >= 200;
   const bool chunk = splits == 1 && p.chunk_kt > 0 && p.chunk_kt < p.K / BK;
   if constexpr (MODE == 1) {
     // stride-1 3x3 on the 256-row tile with an image width that divides it: the row-sharing loop (kernel mode 4)
-    static const bool rs_on = !(getenv("HEDIT_CONV_ROWSHARE") && atoi(getenv("HEDIT_CONV_ROWSHARE")) == 0);
-    if (rs_on && big && splits == 1 && p.Hout == p.Hin && p.Wout == p.Win && p.Win > 0 && 256 % p.Win == 0) {
+    if (big && splits == 1 && p.Hout == p.Hin && p.Wout == p.Win && p.Win > 0 && 256 % p.Win == 0) {
       if (!chunk) return launch_igemm_impl<256, BN, 4, false>(p, splits, st);
       // (with the second accumulator set of the chunk fold the 160-column tile spills in this loop, also with a single
       //  set of weight fragments refilled column by column: 128 columns only)
@@ -974,8 +902,7 @@ int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
     }
   }
   if constexpr (MODE == 3) {
-    static const bool rs_on = !(getenv("HEDIT_CONV_ROWSHARE") && atoi(getenv("HEDIT_CONV_ROWSHARE")) == 0);
-    if (rs_on && big && splits == 1 && p.Wout > 0 && 256 % p.Wout == 0) {
+    if (big && splits == 1 && p.Wout > 0 && 256 % p.Wout == 0) {
       if (!chunk) return launch_igemm_impl<256, BN, 5, false>(p, splits, st);
       if constexpr (BN == 128) return launch_igemm_impl<256, BN, 5, true>(p, splits, st);
     }
@@ -988,16 +915,10 @@ int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
 }  // namespace
 
 int gemm_pick_bn(int N);
-static int ff1_bn() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("HEDIT_FF1_BN");
-    v = e ? atoi(e) : 256;       // 256 x 256 tile (8 waves, 64 x 128 each, two LDS stages): +13...18 % on the three FF1 shapes
-  }                               // over 256 x 128 (23 % less operand traffic per MFMA); HEDIT_FF1_BN=128 for A/B runs
-  return v;
-}
 static int pick_bn(const GemmParams& p) {
-  if (p.geglu) return (ff1_bn() == 256 && p.N % 256 == 0 && (long)cdiv(p.M, 256) * (p.N / 256) >= 200) ? 256 : 128;
+  // FF1 + GEGLU: 256 x 256 tile (8 waves, 64 x 128 each, two LDS stages), +13...18 % on the FF1 shapes over 256 x 128
+  // (23 % less operand traffic per MFMA) when it still fills the chip
+  if (p.geglu) return (p.N % 256 == 0 && (long)cdiv(p.M, 256) * (p.N / 256) >= 200) ? 256 : 128;
   return gemm_pick_bn(p.N);
 }
 

@@ -35,6 +35,26 @@ int gemm_plan_splits(int M, int N, int K, int chunk_kt);   // slabs this launch 
 size_t gemm_partial_bytes(int M, int N, int splits);
 int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st);
 
+// ---------------------------------------------------------------- ffn.hip
+// out = x + FF2(GEGLU(FF1(LayerNorm(x)))) in one kernel (C = ffn_fused_channels() only): the weights come as a
+// pre-packed stream (ffn_pack_launch: call once with w1 = ff.net.0.proj.weight [8C][C], once with w2 = ff.net.2.weight
+// [C][4C], either order) and the FF1 bias in packed order (ffn_pack_bias_launch)
+struct FfnParams {
+  const bf16_t* x; long ldx;     // [M][ldx]: LayerNorm input AND residual
+  const float* gamma; const float* beta; float eps;
+  const bf16_t* stream;          // ffn_stream_bytes()
+  const float* bias1p;           // ffn_bias_bytes()
+  const float* bias2;            // [C]
+  bf16_t* out; long ldo;
+  int M, C;
+};
+int ffn_fused_channels();
+size_t ffn_stream_bytes();
+size_t ffn_bias_bytes();
+int ffn_pack_launch(const float* w1, const float* w2, bf16_t* stream, hipStream_t st);
+int ffn_pack_bias_launch(const float* b1, float* out, hipStream_t st);
+int ffn_fused_launch(const FfnParams& f, hipStream_t st);
+
 #define HEDIT_MAXW 77
 #define HEDIT_WPAD 96
 #define HEDIT_CTXP 80           // context rows per batch item in K / V^T buffers (77 + zero pad)

@@ -538,8 +538,7 @@ int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, gamma, beta, ss, HW, C, G, nslab, eps, stats);
   LAUNCH_CHECK();
   const long total_v = (long)B * HW * CV;
-  static const bool rows_on = !(getenv("HEDIT_GN_APPLY_ROWS") && atoi(getenv("HEDIT_GN_APPLY_ROWS")) == 0);
-  if (rows_on && CV <= 256 && HW >= 1024) {      // (smaller images: too few pixels per thread row to pay for the set-up)
+  if (CV <= 256 && HW >= 1024) {      // (smaller images: too few pixels per thread row to pay for the set-up)
     // enough slabs for >= ~4096 workgroups over the batch, at least 8 pixels per thread row
     int ns = (int)(4096 / (B > 0 ? B : 1)) + 1;
     const int max_ns = HW / (R * 8) > 0 ? HW / (R * 8) : 1;

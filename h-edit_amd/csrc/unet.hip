@@ -25,7 +25,8 @@ namespace {
 struct Slot {
   std::string name;
   int kind;        // 0 fp32 copy, 1 linear -> bf16 (scaled), 2 conv3x3 OIHW -> bf16 [O][9][I],
-                   // 3 / 4: FF1 weight / bias with GEGLU (value16|gate16) row interleave
+                   // 3 / 4: FF1 weight / bias with GEGLU (value16|gate16) row interleave,
+                   // 5 / 6 / 7: FF1 weight / FF1 bias / FF2 weight of the one-kernel feed-forward (ffn.hip)
   void* dst;
   size_t numel;
   int O, I;
@@ -45,6 +46,8 @@ struct Attn {
   int C;
   float *gn_g, *gn_b, *pin_b, *ln1g, *ln1b, *ln2g, *ln2b, *ln3g, *ln3b, *o1_b, *o2_b, *ff1_b, *ff2_b, *pout_b;
   bf16_t *pin, *w_qk, *w_v1, *w_o1, *w_q2, *w_k2, *w_v2, *w_o2, *ff1, *ff2, *pout;
+  bf16_t* ffs = nullptr;     // C == ffn_fused_channels(): the feed-forward runs as one kernel (ffn.hip) on this weight
+  float* ff1_bp = nullptr;   // stream + packed FF1 bias; ff1 / ff2 / ff1_b are then not materialised
 };
 
 struct Block {
@@ -168,11 +171,22 @@ Attn make_attn(hedit_unet* h, const std::string& pre, int C) {
   a.o2_b = f32p(h, tb + ".attn2.to_out.0.bias", C);
   a.ln3g = f32p(h, tb + ".norm3.weight", C);
   a.ln3b = f32p(h, tb + ".norm3.bias", C);
-  a.ff1 = linp(h, tb + ".ff.net.0.proj.weight", 8 * C, C);
-  h->slots.back().kind = 3;
-  a.ff1_b = f32p(h, tb + ".ff.net.0.proj.bias", 8 * C);
-  h->slots.back().kind = 4;
-  a.ff2 = linp(h, tb + ".ff.net.2.weight", C, 4 * C);
+  if (C == ffn_fused_channels()) {
+    // one-kernel feed-forward: both weights go into the stream, the FF1 bias into its packed form (kinds 5 / 6 / 7)
+    a.ffs = dalloc<bf16_t>(h, ffn_stream_bytes() / sizeof(bf16_t));
+    a.ff1_bp = dalloc<float>(h, ffn_bias_bytes() / sizeof(float));
+    add_slot(h, tb + ".ff.net.0.proj.weight", 5, a.ffs, (size_t)8 * C * C, 8 * C, C);
+    h->slots.back().ndim = 2; h->slots.back().dims[0] = 8 * C; h->slots.back().dims[1] = C;
+    add_slot(h, tb + ".ff.net.0.proj.bias", 6, a.ff1_bp, (size_t)8 * C);
+    add_slot(h, tb + ".ff.net.2.weight", 7, a.ffs, (size_t)4 * C * C, C, 4 * C);
+    h->slots.back().ndim = 2; h->slots.back().dims[0] = C; h->slots.back().dims[1] = 4 * C;
+  } else {
+    a.ff1 = linp(h, tb + ".ff.net.0.proj.weight", 8 * C, C);
+    h->slots.back().kind = 3;
+    a.ff1_b = f32p(h, tb + ".ff.net.0.proj.bias", 8 * C);
+    h->slots.back().kind = 4;
+    a.ff2 = linp(h, tb + ".ff.net.2.weight", C, 4 * C);
+  }
   a.ff2_b = f32p(h, tb + ".ff.net.2.bias", C);
   a.pout = linp(h, pre + ".proj_out.weight", C, C);
   a.pout_b = f32p(h, pre + ".proj_out.bias", C);
@@ -412,6 +426,22 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   f.ar.free(t1);
 
   // ---- GEGLU feed-forward
+  if (a.ffs) {
+    // LayerNorm -> FF1 -> GEGLU -> FF2 -> + residual in one kernel: rows in registers, weights streamed (ffn.hip)
+    TRY(aalloc(f, &t3, M * C));
+    FfnParams fp{};
+    fp.x = t2; fp.ldx = C; fp.gamma = a.ln3g; fp.beta = a.ln3b; fp.eps = 1e-5f;
+    fp.stream = a.ffs; fp.bias1p = a.ff1_bp; fp.bias2 = a.ff2_b; fp.out = t3; fp.ldo = C; fp.M = (int)M; fp.C = C;
+    {
+      ProfScope ps(f, PK_LINEAR, 2.0 * M * 12.0 * C * C, 4.0 * M * C + 24.0 * C * C);
+      if (ps.rec >= 0) {
+        auto& r = f.h->prof_recs[ps.rec];
+        r.m = (int)M; r.n = C; r.k = 12 * C; r.tag = 128;     // tag 128: fused feed-forward
+      }
+      RUN(f, ffn_fused_launch(fp, f.st));
+    }
+    f.ar.free(t2);
+  } else {
   TRY(aalloc(f, &tn, M * C));
   { ProfScope ps(f, PK_NORM, 0.0, 4.0 * M * C); RUN(f, layernorm_launch(t2, tn, a.ln3g, a.ln3b, (long)M, C, 1e-5f, f.st)); }
   TRY(aalloc(f, &gf, M * 4 * C));
@@ -427,6 +457,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   TRY(linear(f, gf, (int)M, 4 * C, a.ff2, C, a.ff2_b, t2, t3, C));
   f.ar.free(gf);
   f.ar.free(t2);
+  }
 
   if (dst) {
     y = dst;
@@ -586,8 +617,7 @@ int forward_impl(hedit_unet* h, const float* x, float t, const float* ctx, int B
     bf16_t* a;
     TRY(aalloc(f, &a, (size_t)B * H * W * ch0));
     TRY(groupnorm(f, cur, a, h->gn_out_g, h->gn_out_b, H * W, ch0, 1e-5f, 1));
-    static const bool valu = [] { const char* e = getenv("HEDIT_CONVOUT"); return e && std::string(e) == "valu"; }();
-    if (valu || c.out_channels != 4 || ch0 % 64 != 0) {
+    if (c.out_channels != 4 || ch0 % 64 != 0) {
       RUN(f, conv_out_launch(a, h->conv_out_w, h->conv_out_b, eps_out, B, H, W, ch0, c.out_channels, st));
     } else {
       // conv_out as an N = 4 MFMA GEMM (fp32 products) + bias / NCHW pass: the one-wave-per-pixel kernel re-reads the
@@ -770,6 +800,12 @@ int hedit_unet_load(hedit_unet* h, const char* name, const float* w, size_t nume
     TRY(pack_geglu_rows_launch(w, reinterpret_cast<bf16_t*>(s.dst), nullptr, s.O, s.I, st));
   } else if (s.kind == 4) {
     TRY(pack_geglu_rows_launch(w, nullptr, reinterpret_cast<float*>(s.dst), (int)numel, 1, st));
+  } else if (s.kind == 5) {
+    TRY(ffn_pack_launch(w, nullptr, reinterpret_cast<bf16_t*>(s.dst), st));
+  } else if (s.kind == 6) {
+    TRY(ffn_pack_bias_launch(w, reinterpret_cast<float*>(s.dst), st));
+  } else if (s.kind == 7) {
+    TRY(ffn_pack_launch(nullptr, w, reinterpret_cast<bf16_t*>(s.dst), st));
   } else {
     TRY(pack_conv3x3_launch(w, reinterpret_cast<bf16_t*>(s.dst), s.O, s.I, st));
   }

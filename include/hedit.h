@@ -257,6 +257,18 @@ int hedit_k_pack_geglu(const float* w, const float* bias, void* w_packed_bf16, f
                        int inner, int K, void* stream);
 int hedit_k_gemm_geglu(const void* A, const void* w_packed, const float* bias_packed, void* C, int M,
                        int inner, int K, int lda, int ldc, void* stream);
+/* The whole GEGLU feed-forward of a BasicTransformerBlock in one launch (csrc/ffn.hip; replaces diffusers'
+ * `hidden_states = self.ff(self.norm3(hidden_states)) + hidden_states`, oracle/sd_unet.py transformer block):
+ * out[M][C] = x + ff.net.2( GEGLU( ff.net.0.proj( LayerNorm(x) ) ) ), x / out bf16 with row strides ldx / ldo
+ * (multiples of 8).  Exists for C == hedit_k_ffn_channels() (320).  hedit_k_ffn_pack turns the checkpoint tensors
+ * w1 = ff.net.0.proj.weight [8C][C], b1 = ff.net.0.proj.bias [8C], w2 = ff.net.2.weight [C][4C] (fp32, device) into the
+ * weight stream (hedit_k_ffn_stream_bytes) and the packed FF1 bias (hedit_k_ffn_bias_bytes). */
+int hedit_k_ffn_channels(void);
+size_t hedit_k_ffn_stream_bytes(void);
+size_t hedit_k_ffn_bias_bytes(void);
+int hedit_k_ffn_pack(const float* w1, const float* b1, const float* w2, void* stream_out, float* bias1_out, void* stream);
+int hedit_k_ffn_fused(const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* w_stream,
+                      const float* bias1_packed, const float* bias2, void* out, int64_t ldo, int M, int C, void* stream);
 size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C);
 int hedit_k_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW,
                       int C, int G, float eps, int silu, void* ws, void* stream);

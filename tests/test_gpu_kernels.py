@@ -175,6 +175,73 @@ def test_gemm_geglu_fused(lib, M, inner, K):
     assert ((out.float() - want).abs() <= want.abs() * 2 ** -7 + 2e-3).all()
 
 
+def _ffn_setup(lib, M, seed):
+    Cc = lib.hedit_k_ffn_channels()
+    g = torch.Generator().manual_seed(seed)
+    x = G.bf(torch.randn(M, Cc, generator=g) * 1.5 + 0.2)
+    gamma, beta = G.f32(1 + 0.1 * torch.randn(Cc, generator=g)), G.f32(0.1 * torch.randn(Cc, generator=g))
+    w1 = G.f32(torch.randn(8 * Cc, Cc, generator=g) / math.sqrt(Cc))
+    b1 = G.f32(torch.randn(8 * Cc, generator=g) * 0.5)
+    w2 = G.f32(torch.randn(Cc, 4 * Cc, generator=g) / math.sqrt(4 * Cc))
+    b2 = G.f32(torch.randn(Cc, generator=g) * 0.5)
+    ws = torch.empty(lib.hedit_k_ffn_stream_bytes(), dtype=torch.uint8, device=G.dev())
+    bp = torch.empty(lib.hedit_k_ffn_bias_bytes(), dtype=torch.uint8, device=G.dev())
+    _lib.check(lib.hedit_k_ffn_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(ws), _lib.ptr(bp), None))
+    return Cc, x, gamma, beta, w1, b1, w2, b2, ws, bp
+
+
+def _ffn_run(lib, x, gamma, beta, ws, bp, b2, Cc):
+    out = torch.zeros_like(x)
+    _lib.check(lib.hedit_k_ffn_fused(_lib.ptr(x), Cc, _lib.ptr(gamma), _lib.ptr(beta), 1e-5, _lib.ptr(ws), _lib.ptr(bp),
+                                     _lib.ptr(b2), _lib.ptr(out), Cc, x.shape[0], Cc, None))
+    G.sync()
+    return out
+
+
+@pytest.mark.parametrize("M", [128, 100, 4096, 5 * 4096 + 37])
+def test_ffn_fused(lib, M):
+    """LayerNorm -> FF1 -> GEGLU -> FF2 -> + residual in one kernel (csrc/ffn.hip) == the block's feed-forward
+    (diffusers BasicTransformerBlock: ff(norm3(h)) + h, GEGLU with exact erf GELU; oracle/sd_unet.py) in fp32 on the
+    bf16-rounded operands, and == the unfused kernel chain (layernorm, FF1+GEGLU GEMM, FF2 GEMM + residual) up to the
+    summation order inside a 32-deep FF2 k-step."""
+    Cc, x, gamma, beta, w1, b1, w2, b2, ws, bp = _ffn_setup(lib, M, 11 + M)
+    out = _ffn_run(lib, x, gamma, beta, ws, bp, b2, Cc)
+    xn = F.layer_norm(x.float(), (Cc,), gamma, beta, 1e-5).to(torch.bfloat16).float()
+    proj = xn @ w1.to(torch.bfloat16).float().t() + b1
+    h, gate = proj.chunk(2, dim=-1)
+    hid = (h * F.gelu(gate)).to(torch.bfloat16).float()
+    y = (hid @ w2.to(torch.bfloat16).float().t() + b2).to(torch.bfloat16).float()
+    want = y + x.float()
+    assert torch.isfinite(out.float()).all()
+    assert G.rel_err(out.float(), want) < 6e-3
+    # the unfused chain of the same library
+    xn_k = torch.empty_like(x)
+    _lib.check(lib.hedit_k_layernorm(_lib.ptr(x), _lib.ptr(xn_k), _lib.ptr(gamma), _lib.ptr(beta), M, Cc, 1e-5, None))
+    wp = torch.empty(8 * Cc, Cc, dtype=torch.bfloat16, device=G.dev())
+    b1p = torch.empty(8 * Cc, dtype=torch.float32, device=G.dev())
+    _lib.check(lib.hedit_k_pack_geglu(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(wp), _lib.ptr(b1p), 4 * Cc, Cc, None))
+    hid_k = torch.empty(M, 4 * Cc, dtype=torch.bfloat16, device=G.dev())
+    _lib.check(lib.hedit_k_gemm_geglu(_lib.ptr(xn_k), _lib.ptr(wp), _lib.ptr(b1p), _lib.ptr(hid_k), M, 4 * Cc, Cc, Cc, 4 * Cc, None))
+    w2b = w2.to(torch.bfloat16).contiguous()
+    out_k = torch.empty_like(x)
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(hid_k), _lib.ptr(w2b), _lib.ptr(b2), _lib.ptr(x), _lib.ptr(out_k), M, Cc, 4 * Cc,
+                                4 * Cc, Cc, Cc, 0, 0, 0, 0, 0, 0, 1, None, None))
+    G.sync()
+    assert G.rel_err(out.float(), out_k.float()) < 4e-3
+
+
+def test_ffn_fused_rows_are_independent_and_repeatable(lib):
+    """A row's result is a function of that row alone (bitwise): alone, inside a ragged batch, twice."""
+    Cc, x, gamma, beta, w1, b1, w2, b2, ws, bp = _ffn_setup(lib, 3 * 4096 + 5, 7)
+    full = _ffn_run(lib, x, gamma, beta, ws, bp, b2, Cc)
+    again = _ffn_run(lib, x, gamma, beta, ws, bp, b2, Cc)
+    assert torch.equal(full, again)
+    part = _ffn_run(lib, x[4096 + 77:4096 + 77 + 300].contiguous(), gamma, beta, ws, bp, b2, Cc)
+    assert torch.equal(full[4096 + 77:4096 + 77 + 300], part)
+    one = _ffn_run(lib, x[-1:].contiguous(), gamma, beta, ws, bp, b2, Cc)
+    assert torch.equal(full[-1:], one)
+
+
 def attn_ref(q, k, v, heads):
     """q (B,N,C) pre-scaled in log2 units, k (B,M,C), v (B,M,C) -> probs (B,h,N,M), out (B,N,C)"""
     B, N, Cc = q.shape

@@ -1,0 +1,63 @@
+"""Fused feed-forward (csrc/ffn.hip) against the unfused chain (layernorm, FF1+GEGLU GEMM, FF2 GEMM + residual) at the
+bench's level-0 shape.  Usage: python tools/ffn_bench.py [rows=120] [reps=20]"""
+import math, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+import torch
+from hedit import _lib
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+lib = _lib.lib()
+dev = "cuda:0"
+C = lib.hedit_k_ffn_channels()
+M = rows * 4096
+g = torch.Generator().manual_seed(0)
+x = (torch.randn(M, C, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+gamma = torch.ones(C, device=dev); beta = torch.zeros(C, device=dev)
+w1 = (torch.randn(8 * C, C, generator=g) / math.sqrt(C)).to(dev)
+b1 = torch.zeros(8 * C, device=dev)
+w2 = (torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)).to(dev)
+b2 = torch.zeros(C, device=dev)
+ws = torch.empty(lib.hedit_k_ffn_stream_bytes(), dtype=torch.uint8, device=dev)
+bp = torch.empty(lib.hedit_k_ffn_bias_bytes(), dtype=torch.uint8, device=dev)
+_lib.check(lib.hedit_k_ffn_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(ws), _lib.ptr(bp), None))
+out = torch.empty_like(x)
+xn = torch.empty_like(x)
+wp = torch.empty(8 * C, C, dtype=torch.bfloat16, device=dev)
+b1p = torch.empty(8 * C, dtype=torch.float32, device=dev)
+_lib.check(lib.hedit_k_pack_geglu(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(wp), _lib.ptr(b1p), 4 * C, C, None))
+hid = torch.empty(M, 4 * C, dtype=torch.bfloat16, device=dev)
+w2b = w2.to(torch.bfloat16).contiguous()
+out_k = torch.empty_like(x)
+
+
+def fused():
+    _lib.check(lib.hedit_k_ffn_fused(_lib.ptr(x), C, _lib.ptr(gamma), _lib.ptr(beta), 1e-5, _lib.ptr(ws), _lib.ptr(bp),
+                                     _lib.ptr(b2), _lib.ptr(out), C, M, C, None))
+
+
+def unfused():
+    _lib.check(lib.hedit_k_layernorm(_lib.ptr(x), _lib.ptr(xn), _lib.ptr(gamma), _lib.ptr(beta), M, C, 1e-5, None))
+    _lib.check(lib.hedit_k_gemm_geglu(_lib.ptr(xn), _lib.ptr(wp), _lib.ptr(b1p), _lib.ptr(hid), M, 4 * C, C, C, 4 * C, None))
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(hid), _lib.ptr(w2b), _lib.ptr(b2), _lib.ptr(x), _lib.ptr(out_k), M, C, 4 * C,
+                                4 * C, C, C, 0, 0, 0, 0, 0, 0, 1, None, None))
+
+
+def timeit(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+flops = 2.0 * M * 12 * C * C
+tf, tu = timeit(fused), timeit(unfused)
+err = ((out.float() - out_k.float()).norm() / out_k.float().norm()).item()
+print(f"rows {rows} (M = {M}): fused {tf * 1e3:.1f} us = {flops / tf / 1e9:.0f} TF/s | unfused chain {tu * 1e3:.1f} us = "
+      f"{flops / tu / 1e9:.0f} TF/s | speed-up {tu / tf:.2f} | rel diff {err:.2e}")
