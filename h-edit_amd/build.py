@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # per-unit extras.  attn.hip: the row-max chains run on raw MFMA results; without the no-NaN promise
 # every fmaxf operand is first canonicalised (v_max x,x), tripling the instruction count of the
 # softmax's max pass.  (NaN inputs propagate to NaN outputs either way.)
-UNIT_FLAGS = {"attn.hip": ["-fno-honor-nans"]}
+UNIT_FLAGS = {"attn.hip": ["-fno-honor-nans"], "ffn.hip": ["-fno-honor-nans"]}   # (ffn.hip: max(x, 0) of the GELU)
 
 
 def _deps_mtime():

@@ -43,7 +43,7 @@ constexpr int FPAIRS = FH / 16;         // (value16 | gate16) row pairs of FF1
 constexpr int FGROUPS = FH / 32;        // 32-deep k-steps of FF2
 constexpr int SLOT = 64 * FC;           // bytes: 32 rows x C (FF1 pair) = C rows x 32 (FF2 group)
 constexpr int PIECES = SLOT / 1024;     // DMA instructions per slot
-constexpr int RING = 7, AHEAD = 6;
+constexpr int RING = 6, AHEAD = 5;        // ring positions are compile-time constants: two group iterations = one lap
 constexpr int NSLOTS = FPAIRS + FGROUPS + 1;      // + the all-zero "group -1" slot of the first iteration
 constexpr int STREAM_SLOTS = NSLOTS + AHEAD + 1;  // the DMA runs this far past the end (zero slots)
 constexpr int BIAS_OFF = RING * SLOT;
@@ -94,9 +94,8 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__
       const int u = row;                                       // packed row 32 t + u: u < 16 value, else gate
       const int src = u < 16 ? t * 16 + u : FH + t * 16 + (u - 16);
       const float* s = w1 + (long)src * FC + seg * 64 + c * 8;
-      const float sc = u < 16 ? 0.5f : 1.0f;                   // value rows halved (exact): see gelu_op
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = s[e] * sc;
+      for (int e = 0; e < 8; ++e) v[e] = s[e];
     } else if (w2 && g >= 0) {
       // FF2 group image: [C rows][64 B], piece p of row n holds k-chunk p ^ ((-(n >> 2)) & 3)
       const int n = off / 64, p = (off % 64) / 16;
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(256) void ffn_pack_bias_kernel(const float* __restr
   float v = 0.f;
   if (idx < 2 * FH) {
     const int t = idx >> 5, u = idx & 31;
-    v = u < 16 ? 0.5f * b1[t * 16 + u] : b1[FH + t * 16 + (u - 16)];
+    v = b1[u < 16 ? t * 16 + u : FH + t * 16 + (u - 16)];
   }
   out[idx] = v;
 }
@@ -144,61 +143,64 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // MFMAs as inline asm so that the register file of the operands is OURS to choose: the FF1 accumulators live in
 // VGPRs (the GEGLU arithmetic reads them; the compiler's MFMA form would park them in AGPRs behind 32 v_accvgpr_read
-// per pair), the FF2 accumulators in AGPRs (160 registers nothing but MFMAs touch until the epilogue).  What the
-// compiler does not do for an asm MFMA is hazard padding, so every consumer is kept far away by construction: an
-// FF1 accumulator is first read 20+ MFMAs after its last write, an FF2 accumulator only in the epilogue, and each
-// accumulator chain is revisited every 4th (FF1) / 120th (FF2) MFMA.
+// per pair), the FF2 accumulators and the LayerNorm fragments in AGPRs (240 registers nothing but MFMAs touch until
+// the epilogue).  What the compiler does not do for an asm MFMA is hazard padding, so every hazard is excluded by
+// construction: an FF1 accumulator is first read 20+ MFMAs after its last write, an FF2 accumulator only in the
+// epilogue (behind s_nops and a re-definition, see there), each accumulator chain is revisited every 4th (FF1) /
+// 120th (FF2) MFMA, and no VALU result feeds an MFMA closer than a few bundles.
 __device__ __forceinline__ void mfma_v(f32x4& acc, const bf16x8& w, const bf16x8& a) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(a));
 }
 // first MFMA of an FF1 chain: the accumulator start (bias) is a separate, read-only operand -- a v_mov into the
 // accumulator right in front of an asm MFMA would be a VALU-write -> MFMA-read hazard nobody pads.  The other way
 // round (the MFMA still reading C while something overwrites it) is excluded by keeping C's registers live for
 // another eight MFMAs (the empty asm statements at bundle 12)
 __device__ __forceinline__ void mfma_v0(f32x4& acc, const bf16x8& w, const bf16x8& a, const f32x4& c) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(w), "v"(a), "v"(c));
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(w), "a"(a), "v"(c));
 }
 __device__ __forceinline__ void mfma_a(f32x4& acc, const bf16x8& w, const bf16x8& a) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
 }
 
-// GEGLU of one FF1 pair = 8 elements per lane (2 row tiles x 4 hidden units), as a list of 124 single VALU
+// GEGLU of one FF1 pair = 8 elements per lane (2 row tiles x 4 hidden units), as a list of 108 single VALU
 // operations in stage-major order (operation k: stage k / 8 of element k % 8, then four bf16 packs), so that the
-// kernel can hand them out two per MFMA.  With v' = value / 2 (folded into the packed weights and biases) and x = gate:
-//   v x Phi(x) = w + w * copysign(1 - q(|x|)^-16, x),   w = v' x,   q = 1 + a1 |x| + ... + a6 |x|^6
-// (Abramowitz-Stegun 7.1.28, |erf error| <= 3e-7; the same polynomial as mul_gelu2 in common.h, in plain fp32
-// operations: packed fp32 VALU is slow beside MFMAs).
+// kernel can hand them out two per MFMA.  With v = value, x = gate:
+//   v gelu(x),   gelu(x) = x Phi(x) = max(x, 0) - |x| r(|x|),   r(z) = erfc(z / sqrt 2) / 2 = q(z)^-16,
+// q a degree-5 polynomial (the Abramowitz-Stegun 7.1.28 form, refitted with the 1/2 and the 1/sqrt 2 folded in:
+// |gelu error| < 5e-6 absolute, three decimal orders below the bf16 resolution of the result; tools/gelu_fit.py).
+// Plain fp32 operations: packed fp32 VALU is slow beside MFMAs.  No cancellation anywhere: for large |x| the
+// second term vanishes (q^16 overflows to +inf, 1/inf = 0).
 struct Gelu8 {
-  float x[8], w[8], q[8];
+  float q[8], g[8];
   uint32_t h[4];       // bf16 pairs: h[2 i + half] = elements (i, 2 half), (i, 2 half + 1)
 };
-constexpr int GELU_OPS = 124;
+constexpr int GELU_OPS = 13 * 8 + 4;
 // (the empty volatile asm pins each result where it is written: instruction selection otherwise sinks an operation
 //  down to its consumer, out of the bundle it was meant to fill; the operation itself stays compiler-visible, so its
 //  hazards and waits are the compiler's business)
 #define GELU_PIN(v) asm volatile("" : "+v"(v))
 template <int K>
 __device__ __forceinline__ void gelu_op(Gelu8& g, const f32x4 (&S)[2][2]) {
-  if constexpr (K < 120) {
+  if constexpr (K < 104) {
     constexpr int st = K / 8, e = K % 8, i = e / 4, r = e % 4;
-    if constexpr (st == 0) { g.x[e] = S[1][i][r]; g.w[e] = S[0][i][r] * g.x[e]; GELU_PIN(g.w[e]); }
+    const float x = S[1][i][r];
+    if constexpr (st == 0) g.q[e] = __builtin_fmaf(9.73478169e-05f, __builtin_fabsf(x), -1.02176718e-04f);
+    else if constexpr (st == 1) g.q[e] = __builtin_fmaf(g.q[e], __builtin_fabsf(x), 3.62392071e-03f);
+    else if constexpr (st == 2) g.q[e] = __builtin_fmaf(g.q[e], __builtin_fabsf(x), 2.19443815e-02f);
+    else if constexpr (st == 3) g.q[e] = __builtin_fmaf(g.q[e], __builtin_fabsf(x), 5.21099924e-02f);
+    else if constexpr (st == 4) g.q[e] = __builtin_fmaf(g.q[e], __builtin_fabsf(x), 1.04427174e+00f);
+    else if constexpr (st <= 8) g.q[e] = g.q[e] * g.q[e];
+    else if constexpr (st == 9) g.q[e] = __builtin_amdgcn_rcpf(g.q[e]);
+    if constexpr (st <= 9) GELU_PIN(g.q[e]);
     else {
-      if constexpr (st == 1) g.q[e] = __builtin_fmaf(5.3829750e-06f, __builtin_fabsf(g.x[e]), 4.8890634e-05f);
-      else if constexpr (st == 2) g.q[e] = __builtin_fmaf(g.q[e], __builtin_fabsf(g.x[e]), 3.8003575e-05f);
-      else if constexpr (st == 3) g.q[e] = __builtin_fmaf(g.q[e], __builtin_fabsf(g.x[e]), 3.2776263e-03f);
-      else if constexpr (st == 4) g.q[e] = __builtin_fmaf(g.q[e], __builtin_fabsf(g.x[e]), 2.1141006e-02f);
-      else if constexpr (st == 5) g.q[e] = __builtin_fmaf(g.q[e], __builtin_fabsf(g.x[e]), 4.9867347e-02f);
-      else if constexpr (st == 6) g.q[e] = __builtin_fmaf(g.q[e], __builtin_fabsf(g.x[e]), 1.0f);
-      else if constexpr (st <= 10) g.q[e] = g.q[e] * g.q[e];
-      else if constexpr (st == 11) g.q[e] = __builtin_amdgcn_rcpf(g.q[e]);
-      else if constexpr (st == 12) g.q[e] = 1.0f - g.q[e];
-      else if constexpr (st == 13) g.q[e] = copysignf(g.q[e], g.x[e]);
-      if constexpr (st <= 13) GELU_PIN(g.q[e]);
-      else { g.w[e] = __builtin_fmaf(g.w[e], g.q[e], g.w[e]); GELU_PIN(g.w[e]); }
+      if constexpr (st == 10) g.g[e] = __builtin_fmaxf(x, 0.f);
+      else if constexpr (st == 11) g.g[e] = __builtin_fmaf(-__builtin_fabsf(x), g.q[e], g.g[e]);
+      else g.g[e] = g.g[e] * S[0][i][r];
+      GELU_PIN(g.g[e]);
     }
   } else {
-    constexpr int p = K - 120;
-    g.h[p] = pack_bf16x2(g.w[2 * p], g.w[2 * p + 1]);
+    constexpr int p = K - 104;
+    g.h[p] = pack_bf16x2(g.g[2 * p], g.g[2 * p + 1]);
     GELU_PIN(g.h[p]);
   }
 }
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnKernelParams p) {
         for (int e = 0; e < 8; ++e) o[e] = (f[e] - mean[i]) * rstd[i] * gg[e] + bb[e];
         const u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
         A[i][ks] = __builtin_bit_cast(bf16x8, pk);
+        asm volatile("" : "+a"(A[i][ks]));       // home in the AGPR file from here on (every use is an MFMA operand)
       }
     }
   }
@@ -308,68 +311,75 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnKernelParams p) {
   // fragment read offsets inside a slot
   const int w1_lo = fr * 128 + ((fq ^ (fr & 7)) << 4);                    // FF1 pair image, even k-step (odd: ^ 64)
   const int w2_lo = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);           // FF2 group image
-  const int bias_lo = BIAS_OFF + fq * 16;
-  // fragment n (0 .. 19) of an FF1 pair slot: k-step n / 2, (value | gate) tile n % 2; of an FF2 group slot: output tile n
+  int bias_rd = BIAS_OFF + fq * 16;                                       // packed bias of the next FF1 pair to start
+  // fragment n (0 .. 19) of an FF1 pair slot: k-step n / 2, (value | gate) tile n % 2; of an FF2 group slot: output tile n.
+  // ds_read offsets are 16-bit immediates, so each lane offset exists twice: for ring positions 0-2 and 3-5 (the
+  // empty asm keeps the compiler from re-deriving them with a v_add per read)
+  constexpr int HALF = (RING / 2) * SLOT;
+  static_assert(HALF < 65536, "half a ring must be addressable by a ds_read offset");
+  int w1e[2], w1o[2], w2b[2];       // (LDS byte offsets)
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    w1e[hf] = hf * HALF + w1_lo;
+    w1o[hf] = hf * HALF + (w1_lo ^ 64);
+    w2b[hf] = hf * HALF + w2_lo;
+    asm volatile("" : "+v"(w1e[hf]), "+v"(w1o[hf]), "+v"(w2b[hf]));
+  }
   auto rd1 = [&](int pos, int n) __attribute__((always_inline)) {
-    const int ks = n >> 1, j = n & 1;
-    return *reinterpret_cast<const bf16x8*>(smem + pos * SLOT + (ks >> 1) * 4096 + j * 2048 + (w1_lo ^ ((ks & 1) << 6)));
+    const int ks = n >> 1, j = n & 1, hf = pos / (RING / 2);
+    return *reinterpret_cast<const bf16x8*>(smem + (((ks & 1) ? w1o[hf] : w1e[hf]) + (pos - hf * (RING / 2)) * SLOT + (ks >> 1) * 4096 + j * 2048));
   };
   auto rd2 = [&](int pos, int n) __attribute__((always_inline)) {
-    return *reinterpret_cast<const bf16x8*>(smem + pos * SLOT + n * 1024 + w2_lo);
+    const int hf = pos / (RING / 2);
+    return *reinterpret_cast<const bf16x8*>(smem + (w2b[hf] + (pos - hf * (RING / 2)) * SLOT + n * 1024));
   };
-  // accumulator start of FF1 pair t: the packed bias (value rows already halved)
-  auto rdb = [&](int t, int j) __attribute__((always_inline)) {
-    return *reinterpret_cast<const f32x4*>(smem + bias_lo + t * 128 + j * 64);
-  };
-  auto ring_next = [](int pos) __attribute__((always_inline)) { return pos == RING - 1 ? 0 : pos + 1; };
+  // accumulator start of an FF1 pair: the packed bias
+  auto rdb = [&](int j) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(smem + bias_rd + j * 64); };
 
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");           // slots 0 .. AHEAD-1 and the biases are in LDS
 
-  // One slot = 40 "bundles" of [1 MFMA | 2-3 GEGLU operations | every other one a fragment read 8 bundles ahead (the
-  // last four reads of a slot fetch the first fragments of the next one) | five of them a DMA piece], pinned by
+  // One slot = 40 "bundles" of [1 MFMA | 1-2 GEGLU operations | every other one a fragment read 16 bundles ahead (the
+  // last eight reads of a slot fetch the first fragments of the next one) | five of them a DMA piece], pinned by
   // sched_barrier so that the VALU and LDS work sits in the MFMAs' shadow instead of in a block of its own.  At a
-  // slot boundary: [my DMA pieces of the slot after next have landed: vmcnt(4 slots in flight)] [my reads of the
-  // slot just finished have returned: lgkmcnt(the 4 newest = next slot's)] barrier; the finished slot's ring
+  // slot boundary: [my DMA pieces of the slot after next have landed: vmcnt(3 slots in flight)] [my reads of the
+  // slot just finished have returned: lgkmcnt(the 8 newest = next slot's)] barrier; the finished slot's ring
   // position is then refilled during the next slot.
-  constexpr int LEAD = 4;                    // fragment reads in flight ahead of their MFMAs
+  constexpr int LEAD = 8;                    // fragment reads in flight ahead of their MFMAs
   constexpr int NB = 40;                     // bundles (MFMAs) per slot
-  int s = 0, pos = 0;                        // stream slot being consumed, its ring position
+  int s = 0;                                 // stream slot being consumed
   auto boundary = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"((AHEAD - 2) * PPW), "n"(LEAD) : "memory");
   };
 
-  f32x4 S0[2][2], S1[2][2];
+  f32x4 Se0[2][2], Se1[2][2], So0[2][2], So1[2][2];      // FF1 accumulators of the even / odd group iteration
   u32x2 hlo[2];
   bf16x8 pre[LEAD];                          // first fragments of the slot about to start
   f32x4 binit[2];                            // accumulator start of the FF1 pair about to start
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) S1[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 2; ++i) So1[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 2; ++i) hlo[i] = (u32x2){0u, 0u};
 #pragma unroll
   for (int n = 0; n < LEAD; ++n) pre[n] = rd1(0, n);
-  binit[0] = rdb(0, 0);
-  binit[1] = rdb(0, 1);
+  binit[0] = rdb(0);
+  binit[1] = rdb(1);
+  bias_rd += 128;
 
-  // group iteration g: slot A = FF1 pair 2g -> S0, slot B = FF1 pair 2g+1 -> S1, slot C = FF2 group g-1 (group -1: zero
-  // weights); GEGLU of pair 2g-1 (S1 of the previous iteration -> hhi, completes group g-1) during A and the first
-  // half of B, GEGLU of pair 2g (S0 -> next hlo) during the second half of B and C.  LAST: the slot after C is the
-  // final FF2 slot (group 39) instead of another slot A.
-  auto iteration = [&](int g, auto last_c) __attribute__((always_inline)) {
+  // group iteration g on ring positions PA, PA+1, PA+2: slot A = FF1 pair 2g -> S0, slot B = FF1 pair 2g+1 -> S1,
+  // slot C = FF2 group g-1 (group -1: zero weights); GEGLU of pair 2g-1 (Sp = S1 of the previous iteration, completes
+  // group g-1) during A and the first half of B, GEGLU of pair 2g (S0 -> next hlo) during the second half of B and C.
+  // LAST: the slot after C is the final FF2 slot (group 39) instead of another slot A.
+  auto iteration = [&](auto pa_c, auto last_c, const f32x4 (&Sp)[2][2], f32x4 (&S0)[2][2], f32x4 (&S1)[2][2]) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_c)::value;
-    const int pA = pos, pB = ring_next(pA), pC = ring_next(pB), pN = ring_next(pC);
+    constexpr int PA = decltype(pa_c)::value, PB = PA + 1, PC = PA + 2, PN = (PA + 3) % RING, PP = (PA + RING - 1) % RING;
     Gelu8 G1, G0;
-    f32x4 S1p[2][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) S1p[j][i] = S1[j][i];
     bf16x8 fa[20 + LEAD], fb[20 + LEAD], fc[20 + LEAD];
 #pragma unroll
     for (int n = 0; n < LEAD; ++n) fa[n] = pre[n];
-    f32x4 bB[2];
+    f32x4 bB[2], bA[2];
+    u32x4 H[2];      // activation fragments of FF2 group g-1, assembled (and pinned) long before slot C reads them
     // ---------------- slot A
     static_for<NB>([&](auto b_) {
       constexpr int b = decltype(b_)::value;
@@ -378,19 +388,17 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnKernelParams p) {
       else mfma_v(S0[j][i], fa[n], A[i][ks]);
       if constexpr (b == 12) asm volatile("" ::"v"(binit[0]), "v"(binit[1]));     // (see mfma_v0: keeps the C operand's registers intact)
       if constexpr (b % 2 == 0) {
-        if constexpr (n + LEAD < 20) fa[n + LEAD] = rd1(pA, n + LEAD);
-        else fb[n + LEAD - 20] = rd1(pB, n + LEAD - 20);
+        if constexpr (n + LEAD < 20) fa[n + LEAD] = rd1(PA, n + LEAD);
+        else fb[n + LEAD - 20] = rd1(PB, n + LEAD - 20);
       }
-      if constexpr (b == 27) { bB[0] = rdb(2 * g + 1, 0); }
-      if constexpr (b == 29) { bB[1] = rdb(2 * g + 1, 1); }
-      if constexpr (b % 8 == 4) dma_piece(s + AHEAD, pA == 0 ? RING - 1 : pA - 1, b / 8);
-      gelu_ops<(b * GELU_OPS) / 60, ((b + 1) * GELU_OPS) / 60>(G1, S1p);
+      if constexpr (b == 19) bB[0] = rdb(0);
+      if constexpr (b == 21) { bB[1] = rdb(1); bias_rd += 128; }
+      if constexpr (b % 8 == 4) dma_piece(s + AHEAD, PP, b / 8);
+      gelu_ops<(b * GELU_OPS) / 60, ((b + 1) * GELU_OPS) / 60>(G1, Sp);
       __builtin_amdgcn_sched_barrier(0);
     });
     boundary();
     // ---------------- slot B
-    f32x4 bA[2];
-    u32x4 H[2];      // activation fragments of FF2 group g-1, assembled (and pinned) long before slot C reads them
     static_for<NB>([&](auto b_) {
       constexpr int b = decltype(b_)::value;
       constexpr int n = b / 2, ks = n / 2, j = n % 2, i = b % 2;
@@ -398,11 +406,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnKernelParams p) {
       else mfma_v(S1[j][i], fb[n], A[i][ks]);
       if constexpr (b == 12) asm volatile("" ::"v"(bB[0]), "v"(bB[1]));
       if constexpr (b % 2 == 0) {
-        if constexpr (n + LEAD < 20) fb[n + LEAD] = rd1(pB, n + LEAD);
-        else fc[n + LEAD - 20] = rd2(pC, n + LEAD - 20);
+        if constexpr (n + LEAD < 20) fb[n + LEAD] = rd1(PB, n + LEAD);
+        else fc[n + LEAD - 20] = rd2(PC, n + LEAD - 20);
       }
-      if constexpr (b % 8 == 4) dma_piece(s + 1 + AHEAD, pA, b / 8);
-      if constexpr (b < 20) gelu_ops<((b + 40) * GELU_OPS) / 60, ((b + 41) * GELU_OPS) / 60>(G1, S1p);
+      if constexpr (b % 8 == 4) dma_piece(s + 1 + AHEAD, PA, b / 8);
+      if constexpr (b < 20) gelu_ops<((b + 40) * GELU_OPS) / 60, ((b + 41) * GELU_OPS) / 60>(G1, Sp);
       else gelu_ops<((b - 20) * GELU_OPS) / 60, ((b - 19) * GELU_OPS) / 60>(G0, S0);
       if constexpr (b == 19) {
 #pragma unroll
@@ -420,15 +428,15 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnKernelParams p) {
       constexpr int n = b / 2, i = b % 2;
       mfma_a(O[n][i], fc[n], __builtin_bit_cast(bf16x8, H[i]));
       if constexpr (b % 2 == 0) {
-        if constexpr (n + LEAD < 20) fc[n + LEAD] = rd2(pC, n + LEAD);
-        else if constexpr (LAST) pre[n + LEAD - 20] = rd2(pN, n + LEAD - 20);
-        else pre[n + LEAD - 20] = rd1(pN, n + LEAD - 20);
+        if constexpr (n + LEAD < 20) fc[n + LEAD] = rd2(PC, n + LEAD);
+        else if constexpr (LAST) pre[n + LEAD - 20] = rd2(PN, n + LEAD - 20);
+        else pre[n + LEAD - 20] = rd1(PN, n + LEAD - 20);
       }
       if constexpr (!LAST) {
-        if constexpr (b == 27) { bA[0] = rdb(2 * g + 2, 0); }
-        if constexpr (b == 29) { bA[1] = rdb(2 * g + 2, 1); }
+        if constexpr (b == 19) bA[0] = rdb(0);
+        if constexpr (b == 21) { bA[1] = rdb(1); bias_rd += 128; }
       }
-      if constexpr (b % 8 == 4) dma_piece(s + 2 + AHEAD, pB, b / 8);
+      if constexpr (b % 8 == 4) dma_piece(s + 2 + AHEAD, PB, b / 8);
       gelu_ops<((b + 20) * GELU_OPS) / 60, ((b + 21) * GELU_OPS) / 60>(G0, S0);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -437,14 +445,19 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnKernelParams p) {
     for (int i = 0; i < 2; ++i) hlo[i] = (u32x2){G0.h[2 * i], G0.h[2 * i + 1]};
     if constexpr (!LAST) { binit[0] = bA[0]; binit[1] = bA[1]; }
     s += 3;
-    pos = pN;
   };
-  for (int g = 0; g < FGROUPS - 1; ++g) iteration(g, std::false_type{});
-  iteration(FGROUPS - 1, std::true_type{});
-  // ---- tail: GEGLU of the last pair, then the last FF2 slot
+  using P0 = std::integral_constant<int, 0>;
+  using P3 = std::integral_constant<int, 3>;
+  for (int gg = 0; gg < FGROUPS / 2 - 1; ++gg) {
+    iteration(P0{}, std::false_type{}, So1, Se0, Se1);
+    iteration(P3{}, std::false_type{}, Se1, So0, So1);
+  }
+  iteration(P0{}, std::false_type{}, So1, Se0, Se1);
+  iteration(P3{}, std::true_type{}, Se1, So0, So1);
+  // ---- tail: GEGLU of the last pair, then the last FF2 slot (ring position 0 again)
   {
     Gelu8 G1;
-    gelu_ops<0, GELU_OPS>(G1, S1);
+    gelu_ops<0, GELU_OPS>(G1, So1);
     u32x4 H[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnKernelParams p) {
       constexpr int b = decltype(b_)::value;
       constexpr int n = b / 2, i = b % 2;
       mfma_a(O[n][i], fc[n], __builtin_bit_cast(bf16x8, H[i]));
-      if constexpr (b % 2 == 0 && n + LEAD < 20) fc[n + LEAD] = rd2(pos, n + LEAD);
+      if constexpr (b % 2 == 0 && n + LEAD < 20) fc[n + LEAD] = rd2(0, n + LEAD);
       __builtin_amdgcn_sched_barrier(0);
     });
   }

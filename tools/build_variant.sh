@@ -6,9 +6,9 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; UNIT=$2; EXTRA=$3
 mkdir -p /tmp/hedit_variants
 OBJ=/tmp/hedit_variants/${UNIT}_${NAME}.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result $EXTRA -c $ROOT/h-edit_amd/csrc/$UNIT.hip -o $OBJ
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-honor-nans -Wno-unused-result $EXTRA -c $ROOT/h-edit_amd/csrc/$UNIT.hip -o $OBJ
 OBJS=""
-for u in gemm norm attn step grad pnet unet vae ddpm irse lpips vit c_api; do
+for u in gemm ffn norm attn step grad pnet unet vae ddpm irse lpips vit c_api; do
   if [ $u == $UNIT ]; then OBJS="$OBJS $OBJ"; else OBJS="$OBJS $ROOT/h-edit_amd/build/$u.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/h-edit_amd/hedit/lib_$NAME.so.bin $OBJS

@@ -1,10 +1,13 @@
-"""Fused feed-forward (csrc/ffn.hip) against the unfused chain (layernorm, FF1+GEGLU GEMM, FF2 GEMM + residual) at the
+"""HEDIT_LIB_VARIANT=name loads h-edit_amd/hedit/lib_name.so.bin (tools/build_variant.sh) instead of the product library.
+Fused feed-forward (csrc/ffn.hip) against the unfused chain (layernorm, FF1+GEGLU GEMM, FF2 GEMM + residual) at the
 bench's level-0 shape.  Usage: python tools/ffn_bench.py [rows=120] [reps=20]"""
 import math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
 import torch
 from hedit import _lib
+if os.environ.get("HEDIT_LIB_VARIANT"):       # tools/build_variant.sh side library (measurement builds)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"lib_{os.environ['HEDIT_LIB_VARIANT']}.so.bin")
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20

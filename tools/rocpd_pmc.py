@@ -8,7 +8,8 @@ ix = {k: i for i, k in enumerate(cols)}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     name = r[ix.get('kernel_name', ix.get('name'))]
-    if 'igemm' not in name and 'self_attn' not in name and 'cross_attn' not in name and 'gn_' not in name:
+    want = sys.argv[2:] or ['igemm', 'self_attn', 'cross_attn', 'gn_', 'ffn_']
+    if not any(w in name for w in want):
         continue
     key = (name.split('::')[-1][:40], r[ix['grid_size_x']] if 'grid_size_x' in ix else 0)
     agg[key][r[ix['counter_name']]].append(r[ix['value']])
