@@ -5,11 +5,13 @@ face-swapping/arcface/arcface_model.py:11-67 and its IR-SE50 backbone
 squeeze-excitation) -> l2-normalised 512-d feature; ``get_cosine_loss`` = 1 - cos(feature(image),
 feature(reference face)).
 
-On the GPU the network runs natively (backend "hip": ``hedit_irse50_cos_fwd_bwd`` of libhedit_hip.so, csrc/irse.hip):
+The network runs natively and only natively (``hedit_irse50_cos_fwd_bwd`` of libhedit_hip.so, csrc/irse.hip):
 the face loop only needs the loss and its gradient w.r.t. the image (h_edit_R.py:103-106), which one native
-call produces together (fp32-quality split-bf16 contractions on the MFMA GEMM kernel); ``get_cosine_loss`` wraps
-it in an autograd node so the caller's ``torch.autograd.grad(loss, x_{t-1})`` works unchanged.  The torch module
-below (backend "torch") is the parameter container and the CPU mirror the golden-vector tests run.
+call produces together (fp32-quality split-bf16 contractions on the MFMA GEMM kernel); ``get_cosine_loss`` and
+``get_cosine_sim`` wrap it in autograd nodes so the caller's ``torch.autograd.grad(loss, x_{t-1})`` works unchanged.
+The torch modules below are PARAMETER CONTAINERS (the checkpoint's state_dict layout, no forward): there is no
+torch / CPU execution path in the product -- the fp32 restatement the golden vectors pin lives in
+oracle/reward_nets.py (test infrastructure).
 state_dict keys are the reference's (``input_layer.0.weight``, ``body.3.res_layer.5.fc1.weight`` ...), so
 its ``model_ir_se50.pth`` loads directly from a local path; nothing is downloaded.
 ``LPIPS_Loss`` (arcface_model.py:69-94) wraps the third-party ``lpips`` package, absent offline: pass any
@@ -29,13 +31,9 @@ class _SE(nn.Module):
         self.fc1 = nn.Conv2d(c, c // reduction, 1, bias=False)
         self.fc2 = nn.Conv2d(c // reduction, c, 1, bias=False)
 
-    def forward(self, x):
-        s = torch.sigmoid(self.fc2(F.relu(self.fc1(x.mean((2, 3), keepdim=True)))))
-        return x * s
-
 
 class _Unit(nn.Module):
-    """bottleneck_IR_SE (helpers.py:97-119): BN -> conv3x3 -> PReLU -> conv3x3(stride) -> BN -> SE, plus a
+    """Parameters of bottleneck_IR_SE (helpers.py:97-119): BN -> conv3x3 -> PReLU -> conv3x3(stride) -> BN -> SE, plus a
     strided identity (MaxPool2d(1, stride)) or 1x1 conv + BN shortcut."""
 
     def __init__(self, cin, depth, stride):
@@ -48,13 +46,9 @@ class _Unit(nn.Module):
         self.res_layer = nn.Sequential(nn.BatchNorm2d(cin), nn.Conv2d(cin, depth, 3, 1, 1, bias=False), nn.PReLU(depth),
                                        nn.Conv2d(depth, depth, 3, stride, 1, bias=False), nn.BatchNorm2d(depth), _SE(depth))
 
-    def forward(self, x):
-        sc = self.shortcut_layer(x) if self.shortcut_layer is not None else x[:, :, ::self.stride, ::self.stride]
-        return self.res_layer(x) + sc
-
 
 class Backbone(nn.Module):
-    """IR-SE50 at input_size 112 (what IDLoss builds: Backbone(112, 50, mode='ir_se'))."""
+    """Parameters of IR-SE50 at input_size 112 (what IDLoss builds: Backbone(112, 50, mode='ir_se'))."""
 
     def __init__(self, input_size=112, num_layers=50, drop_ratio=0.6, mode="ir_se", affine=True):
         super().__init__()
@@ -68,10 +62,6 @@ class Backbone(nn.Module):
         self.body = nn.Sequential(*units)
         self.output_layer = nn.Sequential(nn.BatchNorm2d(512), nn.Dropout(drop_ratio), nn.Flatten(),
                                           nn.Linear(512 * 7 * 7, 512), nn.BatchNorm1d(512, affine=affine))
-
-    def forward(self, x):
-        x = self.output_layer(self.body(self.input_layer(x)))
-        return x / torch.norm(x, 2, 1, True)
 
     def init_random(self, seed=0):
         g = torch.Generator().manual_seed(seed)
@@ -104,7 +94,7 @@ class _NativeCosLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, image, owner):
-        loss, grad = owner._native_loss_and_grad(image.detach())
+        loss, grad = owner._native_loss_and_grad(image.detach(), 1.0 / image.shape[0])
         ctx.save_for_backward(grad)
         return loss.mean()
 
@@ -114,14 +104,29 @@ class _NativeCosLoss(torch.autograd.Function):
         return grad * g, None
 
 
+class _NativeCosSim(torch.autograd.Function):
+    """cos(feature(image_b), feature(reference)) per image, differentiable (the reference's get_cosine_sim is): the
+    native call returns 1 - cos_b and the gradient of each image's own loss"""
+
+    @staticmethod
+    def forward(ctx, image, owner):
+        loss, grad = owner._native_loss_and_grad(image.detach(), 1.0)
+        ctx.save_for_backward(grad)
+        return 1.0 - loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return -grad * g.view(-1, 1, 1, 1), None
+
+
 class IDLoss(nn.Module):
     """``IDLoss(ref_path)`` as the reference, plus where the backbone weights come from: ``weights`` = local
-    path of model_ir_se50.pth or a state_dict; None = seeded random weights (synthetic runs).
-    backend: "hip" (default on a GPU device: the native executor, no fallback) or "torch" (the CPU mirror)."""
+    path of model_ir_se50.pth or a state_dict; None = seeded random weights (synthetic runs).  Every method takes CUDA
+    tensors and runs on the HIP executor; there is no CPU / torch path."""
 
-    def __init__(self, ref_path=None, weights=None, ref=None, device=None, seed=0, backend=None):
+    def __init__(self, ref_path=None, weights=None, ref=None, device=None, seed=0):
         super().__init__()
-        self._backend = backend
         self._h = None
         self._ws = None
         self.facenet = Backbone(input_size=112, num_layers=50, drop_ratio=0.6, mode="ir_se")
@@ -142,11 +147,10 @@ class IDLoss(nn.Module):
             self.to(device)
 
     # ------------------------------------------------------------------ native executor (csrc/irse.hip)
-    def _use_hip(self, x):
-        b = self._backend or ("hip" if x.is_cuda else "torch")
-        if b == "hip" and not x.is_cuda:
-            raise RuntimeError("IDLoss backend 'hip' needs CUDA tensors (there is no CPU fallback)")
-        return b == "hip"
+    @staticmethod
+    def _require_gpu(x):
+        if not x.is_cuda:
+            raise RuntimeError("IDLoss runs on the HIP executor only: pass CUDA tensors (there is no CPU / torch path)")
 
     def _native(self, device):
         """create / load / finalize the native backbone on first use (parameters by the reference's names)"""
@@ -207,12 +211,11 @@ class IDLoss(nn.Module):
     def _ref_feature(self, device):
         if self._ref_feat is None or self._ref_feat.device != device:
             with torch.no_grad():      # constant w.r.t. the image; the reference re-encodes it on every call (:51)
-                self._ref_feat = (self._native_features(self.ref.to(device)) if self._use_hip(self.ref.to(device))
-                                  else F.normalize(self.extract_feats(self.ref), p=2, dim=-1))
+                self._ref_feat = self._native_features(self.ref.to(device))
         return self._ref_feat
 
-    def _native_loss_and_grad(self, x):
-        """(loss [B] = 1 - cos per image, d mean(loss) / d x) for x (B,3,256,256)"""
+    def _native_loss_and_grad(self, x, scale):
+        """(loss [B] = 1 - cos per image, d (scale * sum(loss)) / d x) for x (B,3,256,256)"""
         from .. import _lib
         x = x.float().contiguous()
         B = x.shape[0]
@@ -225,26 +228,24 @@ class IDLoss(nn.Module):
         loss = torch.empty(B, device=x.device)
         grad = torch.empty_like(x)
         with torch.cuda.device(x.device):
-            _lib.check(self._lib.hedit_irse50_cos_fwd_bwd(h, _lib.ptr(x), _lib.ptr(ref), int(per_image), B, 1.0 / B, _lib.ptr(loss),
+            _lib.check(self._lib.hedit_irse50_cos_fwd_bwd(h, _lib.ptr(x), _lib.ptr(ref), int(per_image), B, float(scale), _lib.ptr(loss),
                                                           _lib.ptr(grad), _lib.ptr(ws), ws.numel(), _lib.cur_stream()))
         return loss, grad
 
     # ------------------------------------------------------------------ the reference's surface
     def extract_feats(self, x):
-        if self._use_hip(x):
-            return self._native_features(x)
-        x = self._to256(x)
-        x = x[:, :, 35:223, 32:220]                       # crop the face region
-        return self.facenet(F.adaptive_avg_pool2d(x, (112, 112)))
+        """l2-normalised 512-d features (arcface_model.py:40-47).  Not differentiable here: differentiate through
+        get_cosine_sim / get_cosine_loss, which is what the loop does."""
+        self._require_gpu(x)
+        if x.requires_grad:
+            raise NotImplementedError("IDLoss.extract_feats has no autograd node; use get_cosine_sim / get_cosine_loss")
+        return self._native_features(x)
 
     def get_cosine_sim(self, image):
-        if self._use_hip(image):
-            return (self._native_features(image) * self._ref_feature(image.device)).sum(-1)
-        img_feat = F.normalize(self.extract_feats(image), p=2, dim=-1)
-        return F.cosine_similarity(self._ref_feature(img_feat.device), img_feat, dim=-1)
+        self._require_gpu(image)
+        return _NativeCosSim.apply(self._to256(image), self)
 
     def get_cosine_loss(self, image):
-        if self._use_hip(image):
-            # the 256 x 256 pooling (if any) stays a torch op in front of the native node
-            return _NativeCosLoss.apply(self._to256(image), self)
-        return (1 - self.get_cosine_sim(image)).mean()
+        self._require_gpu(image)
+        # the 256 x 256 pooling (if any) stays a torch op in front of the native node
+        return _NativeCosLoss.apply(self._to256(image), self)

@@ -9,21 +9,20 @@ the package's state_dict names (``net.slice1.0.weight``, ``lin0.model.1.weight``
 locally saved ``lpips.LPIPS(net='vgg').state_dict()`` loads directly; nothing is downloaded.  PARITY UNPINNED: the
 package is not in the reference tree and the reference holds no vector for it.
 
-On the GPU the loss AND its gradient w.r.t. the image come from one native call (backend "hip":
-``hedit_lpips_fwd_bwd``, csrc/lpips.hip), wrapped in an autograd node so that the loop's
-``torch.autograd.grad(lpips_loss, x_{t-1})`` (inversion/h_edit_R.py:124-132) works unchanged; the torch module is the
-parameter container and the CPU mirror the native path is tested against."""
+The loss AND its gradient w.r.t. the image come from one native call (``hedit_lpips_fwd_bwd``, csrc/lpips.hip),
+wrapped in an autograd node so that the loop's ``torch.autograd.grad(lpips_loss, x_{t-1})``
+(inversion/h_edit_R.py:124-132) works unchanged.  ``LPIPSNet`` is a PARAMETER CONTAINER (no forward): there is no
+torch / CPU execution path in the product -- the fp32 restatement the native path is tested against lives in
+oracle/reward_nets.py (test infrastructure)."""
 import ctypes as C
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 _VGG = ((3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256),
         (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512))
 _SLICE = (1, 1, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5)
 _IDX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)          # torchvision vgg16.features indices of the convolutions
-_TAPS = {1: 0, 3: 1, 6: 2, 9: 3, 12: 4}                           # conv index -> lin index (a 2x2 max pool follows taps 0..3)
 
 
 class _Lin(nn.Module):
@@ -38,12 +37,9 @@ class _Scaling(nn.Module):
         self.register_buffer("shift", torch.tensor([-.030, -.088, -.188])[None, :, None, None])
         self.register_buffer("scale", torch.tensor([.458, .448, .450])[None, :, None, None])
 
-    def forward(self, x):
-        return (x - self.shift) / self.scale
-
 
 class LPIPSNet(nn.Module):
-    """lpips.LPIPS(net='vgg', version '0.1', lpips=True, spatial=False) in eval mode."""
+    """Parameters of lpips.LPIPS(net='vgg', version '0.1', lpips=True, spatial=False)."""
 
     def __init__(self):
         super().__init__()
@@ -55,25 +51,6 @@ class LPIPSNet(nn.Module):
             getattr(self.net, f"slice{sl}").add_module(str(idx), nn.Conv2d(cin, cout, 3, padding=1))
         for t, c in enumerate((64, 128, 256, 512, 512)):
             self.add_module(f"lin{t}", _Lin(c))
-
-    def features(self, x):
-        h = self.scaling_layer(x)
-        outs = []
-        for l, (sl, idx) in enumerate(zip(_SLICE, _IDX)):
-            h = F.relu(getattr(getattr(self.net, f"slice{sl}"), str(idx))(h))
-            if l in _TAPS:
-                outs.append(h)
-                if _TAPS[l] < 4:
-                    h = F.max_pool2d(h, 2, 2)
-        return outs
-
-    def forward(self, x, y):
-        val = 0
-        for t, (fx, fy) in enumerate(zip(self.features(x), self.features(y))):
-            nx = fx / (fx.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
-            ny = fy / (fy.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
-            val = val + getattr(self, f"lin{t}").model[1]((nx - ny) ** 2).mean((2, 3), keepdim=True)
-        return val
 
     def init_random(self, seed=0):
         g = torch.Generator().manual_seed(seed)
@@ -106,9 +83,9 @@ class _NativeLpips(torch.autograd.Function):
 class LPIPS_Loss(nn.Module):
     """``LPIPS_Loss(src_path)`` as the reference; plus ``src`` (tensor in [-1, 1], (1,3,H,W) or one source per image
     (n,3,H,W) for lock-step batches), ``weights`` (local path of a saved lpips state_dict, or a dict; None = seeded
-    random weights for synthetic runs) and ``backend`` ("hip" on a GPU device -- no fallback -- or "torch")."""
+    random weights for synthetic runs).  CUDA tensors only: the HIP executor is the one execution path."""
 
-    def __init__(self, src_path=None, src=None, weights=None, device=None, seed=0, backend=None):
+    def __init__(self, src_path=None, src=None, weights=None, device=None, seed=0):
         super().__init__()
         self.lpips_loss = LPIPSNet()
         if weights is None:
@@ -126,7 +103,6 @@ class LPIPS_Loss(nn.Module):
             from .arcface_model import load_face_image
             src = load_face_image(src_path)
         self.register_buffer("src", src.float())
-        self._backend = backend
         self._h = None
         self._ws = None
         self._src_feats = None
@@ -134,12 +110,6 @@ class LPIPS_Loss(nn.Module):
             self.to(device)
 
     # ------------------------------------------------------------------ native executor (csrc/lpips.hip)
-    def _use_hip(self, x):
-        b = self._backend or ("hip" if x.is_cuda else "torch")
-        if b == "hip" and not x.is_cuda:
-            raise RuntimeError("LPIPS_Loss backend 'hip' needs CUDA tensors (there is no CPU fallback)")
-        return b == "hip"
-
     def _native(self, device):
         from .. import _lib
         if self._h is not None:
@@ -208,6 +178,6 @@ class LPIPS_Loss(nn.Module):
 
     # ------------------------------------------------------------------ the reference's surface
     def get_lpips_loss(self, x):
-        if self._use_hip(x):
-            return _NativeLpips.apply(x, self)
-        return self.lpips_loss(x, self.src.to(x.device)).mean()
+        if not x.is_cuda:
+            raise RuntimeError("LPIPS_Loss runs on the HIP executor only: pass CUDA tensors (there is no CPU / torch path)")
+        return _NativeLpips.apply(x, self)

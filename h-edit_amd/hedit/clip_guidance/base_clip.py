@@ -9,12 +9,13 @@ projection and the text tower cannot influence the residual or its gradient and 
 Parameters carry the OpenAI CLIP state_dict names (``visual.conv1.weight`` ...), so a local
 checkpoint of the reference's model (ViT-B/16) loads directly; nothing is ever downloaded.
 
-On the GPU the encoder runs natively (backend "hip": ``hedit_vit_gram_fwd_bwd`` of libhedit_hip.so, csrc/vit.hip):
-the Frobenius norm of the Gram residual AND its gradient w.r.t. the resized, normalised image come from one call
-(fp32 token stream, split-bf16 contractions with fp32 accumulation -- finer than the reference's fp16 CLIP,
-model.py:414-435); the bicubic resize and the normalisation in front of it stay torch ops, so autograd carries the
-gradient on into the VAE decoder's HIP backward (hedit.vae).  The torch modules below (fp16 weights, LayerNorm in
-fp32, QuickGELU, as model.py:153-164) are the parameter container and the CPU mirror the golden vectors pin."""
+The encoder runs natively and only natively (``hedit_vit_gram`` / ``hedit_vit_gram_fwd_bwd`` of libhedit_hip.so,
+csrc/vit.hip): the Frobenius norm of the Gram residual AND its gradient w.r.t. the resized, normalised image come
+from one call (fp32 token stream, split-bf16 contractions with fp32 accumulation -- finer than the reference's fp16
+CLIP, model.py:414-435); the bicubic resize and the normalisation in front of it stay torch ops, so autograd carries
+the gradient on into the VAE decoder's HIP backward (hedit.vae).  The torch modules below are PARAMETER CONTAINERS
+(the OpenAI state_dict layout, no forward): there is no torch / CPU execution path in the product -- the fp32
+restatement the golden vectors pin lives in oracle/reward_nets.py (test infrastructure)."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -26,7 +27,7 @@ VIT_B16 = dict(width=768, layers=3, heads=12, patch_size=16, input_resolution=22
 
 
 class _Block(nn.Module):
-    """ResidualAttentionBlock (model.py:167-190): x + MHA(LN(x)); x + MLP(LN(x)), QuickGELU."""
+    """Parameters of a ResidualAttentionBlock (model.py:167-190): x + MHA(LN(x)); x + MLP(LN(x)), QuickGELU."""
 
     def __init__(self, d, heads):
         super().__init__()
@@ -41,21 +42,6 @@ class _Block(nn.Module):
         self.mlp.c_fc = nn.Linear(d, 4 * d)
         self.mlp.c_proj = nn.Linear(4 * d, d)
 
-    @staticmethod
-    def _ln(ln, x):                      # LayerNorm computed in fp32 whatever the stream dtype (model.py:153-159)
-        return F.layer_norm(x.float(), ln.normalized_shape, ln.weight.float(), ln.bias.float(), ln.eps).to(x.dtype)
-
-    def forward(self, x):                # x: (N, L, D)
-        N, L, D = x.shape
-        h = self.heads
-        qkv = F.linear(self._ln(self.ln_1, x), self.attn.in_proj_weight, self.attn.in_proj_bias)
-        q, k, v = (t.reshape(N, L, h, D // h).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
-        p = torch.softmax((q * (D // h) ** -0.5) @ k.transpose(-1, -2), dim=-1)
-        a = (p @ v).transpose(1, 2).reshape(N, L, D)
-        x = x + self.attn.out_proj(a)
-        y = self.mlp.c_fc(self._ln(self.ln_2, x))
-        return x + self.mlp.c_proj(y * torch.sigmoid(1.702 * y))
-
 
 class _Visual(nn.Module):
     def __init__(self, width, layers, heads, patch_size, input_resolution):
@@ -69,7 +55,7 @@ class _Visual(nn.Module):
 
 
 class ClipVisualPrefix(nn.Module):
-    """conv1 -> [class; patches] + positional -> ln_pre -> the first ``layers`` blocks (model.py:339-357)."""
+    """Parameters of conv1 -> [class; patches] + positional -> ln_pre -> the first ``layers`` blocks (model.py:339-357)."""
 
     def __init__(self, width=768, layers=3, heads=12, patch_size=16, input_resolution=224):
         super().__init__()
@@ -79,25 +65,6 @@ class ClipVisualPrefix(nn.Module):
     @property
     def dtype(self):
         return self.visual.conv1.weight.dtype
-
-    def block_features(self, x):
-        """-> token features after the last kept block, (N, L, D) (the reference's ``feats[layers-1]`` is
-        the same tensor in (L, N, D) layout)."""
-        v = self.visual
-        # conv1 has kernel = stride = patch: it is one linear map per non-overlapping patch.  Written as
-        # unfold + matmul, forward and backward are plain GEMMs (MIOpen's backward-data search for this
-        # 16x16/16 fp16 conv ran a naive 7 s kernel per call on gfx950)
-        x = x.type(self.dtype)
-        N, C, H, W = x.shape
-        p = v.conv1.kernel_size[0]
-        x = x.reshape(N, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(N, (H // p) * (W // p), C * p * p)
-        x = x @ v.conv1.weight.reshape(v.conv1.weight.shape[0], -1).t()
-        cls = v.class_embedding.to(x.dtype) + torch.zeros(x.shape[0], 1, x.shape[-1], dtype=x.dtype, device=x.device)
-        x = torch.cat([cls, x], dim=1) + v.positional_embedding.to(x.dtype)
-        x = _Block._ln(v.ln_pre, x)
-        for blk in v.transformer.resblocks:
-            x = blk(x)
-        return x
 
     def load_clip_state_dict(self, sd):
         """Load from a full OpenAI-CLIP state_dict (extra keys -- later blocks, text tower -- are ignored)."""
@@ -136,15 +103,41 @@ class _NativeGramNorm(torch.autograd.Function):
     """sum_b |Gram(x_b) - Gram_ref|_F with the gradient w.r.t. x from the same native call"""
 
     @staticmethod
-    def forward(ctx, x, owner):
-        loss, grad = owner._native_loss_and_grad(x.detach())
+    def forward(ctx, x, owner, ref=None):
+        loss, grad = owner._native_loss_and_grad(x.detach(), ref=ref)
         ctx.save_for_backward(grad)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g.view(-1, 1, 1, 1), None
+        return grad * g.view(-1, 1, 1, 1), None, None
+
+
+class _NativeGramResidual(torch.autograd.Function):
+    """Gram(x_b) - Gram_ref as a differentiable (B, D, D) tensor, for callers that take the residual itself (the
+    reference's closure: torch.linalg.norm(get_gram_matrix_residual(img)), h_edit.py:172-175).  Backward for an
+    arbitrary upstream gradient U_b through the executor's norm-gradient entry: with the per-image reference
+    R_b = Gram_b - U_b that entry back-propagates (Gram_b - R_b) / |Gram_b - R_b| = U_b / |U_b|, so |U_b| times its
+    result is exactly J^T U_b."""
+
+    @staticmethod
+    def forward(ctx, x, owner):
+        xd = x.detach()
+        gram = owner._native_gram(xd)
+        ctx.owner = owner
+        ctx.save_for_backward(xd, gram)
+        return gram - owner._native_ref(x.device)
+
+    @staticmethod
+    def backward(ctx, up):
+        xd, gram = ctx.saved_tensors
+        up = up.float()
+        nrm = up.flatten(1).norm(dim=1)
+        live = nrm > 0
+        ref = torch.where(live.view(-1, 1, 1), gram - up, gram - 1.0).contiguous()      # (a dead row must not divide by 0)
+        _, grad = ctx.owner._native_loss_and_grad(xd, ref=ref)
+        return grad * torch.where(live, nrm, torch.zeros_like(nrm)).view(-1, 1, 1, 1), None
 
 
 class CLIPEncoder(nn.Module):
@@ -153,9 +146,8 @@ class CLIPEncoder(nn.Module):
     or ``clip_model`` = a ready ClipVisualPrefix, else seeded random weights (synthetic runs)."""
 
     def __init__(self, need_ref=False, ref_path=None, clip_path=None, clip_model=None, device=None,
-                 dtype=torch.float16, seed=0, backend=None):
+                 dtype=torch.float16, seed=0):
         super().__init__()
-        self._backend = backend          # "hip" (default on a GPU device, no fallback) or "torch"
         self._h = None
         self._ws = None
         self._gram_ref_native = None
@@ -175,7 +167,6 @@ class CLIPEncoder(nn.Module):
         # images arrive in [-1, 1]: Normalize(mean*2-1, std*2) of base_clip.py:38-41
         self.register_buffer("_mean", torch.tensor([m * 2 - 1 for m in CLIP_MEAN]).view(1, 3, 1, 1))
         self.register_buffer("_std", torch.tensor([s * 2 for s in CLIP_STD]).view(1, 3, 1, 1))
-        self._gram_ref = None
         if device is not None:
             self.to(device)
         if need_ref:
@@ -191,15 +182,13 @@ class CLIPEncoder(nn.Module):
             self.ref = ref
         else:
             self.register_buffer("ref", ref, persistent=False)
-        self._gram_ref = None
         self._gram_ref_native = None
 
     # ------------------------------------------------------------------ native executor (csrc/vit.hip)
-    def _use_hip(self, x):
-        b = self._backend or ("hip" if x.is_cuda else "torch")
-        if b == "hip" and not x.is_cuda:
-            raise RuntimeError("CLIPEncoder backend 'hip' needs CUDA tensors (there is no CPU fallback)")
-        return b == "hip"
+    @staticmethod
+    def _require_gpu(x):
+        if not x.is_cuda:
+            raise RuntimeError("CLIPEncoder runs on the HIP executor only: pass CUDA tensors (there is no CPU / torch path)")
 
     def _native(self, device):
         import ctypes as C
@@ -228,17 +217,56 @@ class CLIPEncoder(nn.Module):
         return h
 
     def __del__(self):
-        if getattr(self, "_h", None) is not None:
+        if getattr(self, "_h", None) is not None and getattr(self, "_owns_handle", True):
             try:
                 self._lib.hedit_vit_destroy(self._h)
             except Exception:
                 pass
 
+    def sibling(self, ref):
+        """Another style reference on the SAME weights: shares this encoder's parameter container, native handle and
+        workspace (a lock-step batch keeps one reference per image, not one copy of the network per image).
+        ref: (1,3,S,S) CLIP-normalised tensor, or the path of a style image."""
+        if isinstance(ref, str):
+            ref = load_style_reference(ref, self.size)
+        dev = self._mean.device
+        if dev.type == "cuda":
+            self._native(dev)
+        sib = CLIPEncoder(clip_model=self.clip_model)
+        sib.to(dev)
+        sib.set_reference(ref.to(dev))
+        if self._h is not None:
+            sib._h, sib._lib, sib._width, sib._owns_handle, sib._parent = self._h, self._lib, self._width, False, self
+        return sib
+
+    @staticmethod
+    def gram_residual_norms_each(encs, ims):
+        """(N,3,H,W) -> (N,): image i against the style reference of encs[i], differentiable w.r.t. ``ims``.  Encoders
+        that share one native handle (``sibling``) take ONE native call with one reference Gram matrix per image."""
+        first = encs[0]
+        first._require_gpu(ims)
+        first._native(ims.device)
+        if any(getattr(e, "_h", None) is None for e in encs[1:]) or any(e._h.value != first._h.value for e in encs[1:]):
+            return torch.cat([e.gram_residual_norms(ims[i:i + 1]) for i, e in enumerate(encs)])
+        x = first.preprocess(F.interpolate(ims, size=(first.size, first.size), mode="bicubic"))
+        refs = torch.stack([e._native_ref(ims.device) for e in encs]).contiguous()
+        return _NativeGramNorm.apply(x, first, refs)
+
     def _workspace(self, B, device):
+        o = getattr(self, "_parent", None) or self          # siblings use their parent's workspace
         need = self._lib.hedit_vit_workspace_bytes(self._h, B)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
-        return self._ws
+        if o._ws is None or o._ws.numel() < need or o._ws.device != device:
+            o._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return o._ws
+
+    def __deepcopy__(self, memo):
+        """a copy owns its own parameters and (lazily) its own native handle -- never a second reference to this one's"""
+        import copy
+        twin = CLIPEncoder(clip_model=copy.deepcopy(self.clip_model, memo))
+        twin.to(self._mean.device)
+        if "ref" in self._buffers:
+            twin.set_reference(self.ref.detach().clone())
+        return twin
 
     def _native_gram(self, x):
         """x (B,3,S,S) CLIP-normalised -> Gram matrices (B,D,D)"""
@@ -256,60 +284,44 @@ class CLIPEncoder(nn.Module):
             self._gram_ref_native = self._native_gram(self.ref.to(device))[0].contiguous()
         return self._gram_ref_native
 
-    def _native_loss_and_grad(self, x):
-        """(loss [B] = |Gram(x_b) - Gram_ref|_F, d sum(loss) / d x) for x (B,3,S,S), CLIP-normalised"""
+    def _native_loss_and_grad(self, x, ref=None):
+        """(loss [B] = |Gram(x_b) - Gram_ref|_F, d sum(loss) / d x) for x (B,3,S,S), CLIP-normalised; ``ref``: one
+        reference Gram matrix per image (B,D,D) instead of this encoder's style reference"""
         from .. import _lib
         x = x.float().contiguous()
         B = x.shape[0]
         h = self._native(x.device)
-        ref = self._native_ref(x.device)
+        per_image = ref is not None
+        if ref is None:
+            ref = self._native_ref(x.device)
         ws = self._workspace(B, x.device)
         loss = torch.empty(B, device=x.device)
         grad = torch.empty_like(x)
         with torch.cuda.device(x.device):
-            _lib.check(self._lib.hedit_vit_gram_fwd_bwd(h, _lib.ptr(x), _lib.ptr(ref), 0, B, 1.0, _lib.ptr(loss), _lib.ptr(grad),
-                                                        _lib.ptr(ws), ws.numel(), _lib.cur_stream()))
+            _lib.check(self._lib.hedit_vit_gram_fwd_bwd(h, _lib.ptr(x), _lib.ptr(ref), int(per_image), B, 1.0, _lib.ptr(loss),
+                                                        _lib.ptr(grad), _lib.ptr(ws), ws.numel(), _lib.cur_stream()))
         return loss, grad
 
     def gram_residual_norms(self, ims):
         """(N,3,H,W) in [-1, 1] -> (N,) = |get_gram_matrix_residual(ims[i:i+1])|_F, differentiable w.r.t. ``ims``: what the
-        style closure needs (torch.linalg.norm of the residual, inversion/h_edit.py:172-175).  On the GPU one native call
-        evaluates norm and gradient; resize + normalisation stay torch ops in front of it."""
+        style closure needs (torch.linalg.norm of the residual, inversion/h_edit.py:172-175).  One native call evaluates
+        norm and gradient; resize + normalisation stay torch ops in front of it."""
+        self._require_gpu(ims)
         x = self.preprocess(F.interpolate(ims, size=(self.size, self.size), mode="bicubic"))
-        if self._use_hip(x):
-            return _NativeGramNorm.apply(x, self)
-        return torch.linalg.norm(self.gram_residuals(ims), dim=(1, 2))
-
-    def _tokens(self, im):
-        # batch item 0, class token dropped.  The Gram matrices and their norm are accumulated in fp32: with
-        # fp16 tokens (the reference's dtype) sums over 196 tokens x 768^2 entries leave the fp16 range easily
-        return self.clip_model.block_features(im)[0, 1:, :].float()
+        return _NativeGramNorm.apply(x, self)
 
     def get_gram_matrix_residual(self, im1):
-        """Gram matrix (D x D) of the block-3 patch tokens of ``im1`` minus that of the style reference
-        (base_clip.py:55-66).  The reference's Gram matrix does not depend on ``im1``; it is computed
-        on first use and kept (the reference recomputes it every call with the same result)."""
-        im1 = F.interpolate(im1, size=(self.size, self.size), mode="bicubic")
-        if self._use_hip(im1) and not im1.requires_grad:
-            return self._native_gram(self.preprocess(im1[:1]))[0] - self._native_ref(im1.device)
-        feat1 = self._tokens(self.preprocess(im1))
-        if self._gram_ref is None or self._gram_ref.device != feat1.device:
-            with torch.no_grad():
-                feat2 = self._tokens(self.ref)
-                self._gram_ref = torch.mm(feat2.t(), feat2)
-        return torch.mm(feat1.t(), feat1) - self._gram_ref
-
+        """Gram matrix (D x D) of the block-3 patch tokens of ``im1`` (batch item 0, as the reference) minus that of the
+        style reference (base_clip.py:55-66), differentiable w.r.t. ``im1``.  The reference's Gram matrix does not depend
+        on ``im1``; it is computed on first use and kept (the reference recomputes it every call with the same result)."""
+        return self.gram_residuals(im1[:1])[0]
 
     def gram_residuals(self, ims):
         """Batched form for images that share this style reference: (N, 3, H, W) -> (N, D, D), row i equal to
         get_gram_matrix_residual(ims[i:i+1]) (one encoder pass for the N images of a lock-step batch)."""
-        ims = F.interpolate(ims, size=(self.size, self.size), mode="bicubic")
-        f = self.clip_model.block_features(self.preprocess(ims))[:, 1:, :].float()
-        if self._gram_ref is None or self._gram_ref.device != f.device:
-            with torch.no_grad():
-                feat2 = self._tokens(self.ref)
-                self._gram_ref = torch.mm(feat2.t(), feat2)
-        return f.transpose(1, 2) @ f - self._gram_ref
+        self._require_gpu(ims)
+        x = self.preprocess(F.interpolate(ims, size=(self.size, self.size), mode="bicubic"))
+        return _NativeGramResidual.apply(x, self)
 
 
 def load_style_reference(path, size=224):

@@ -125,8 +125,8 @@ class HEditEngine:
                 img = vae.decode(zc).sample
                 if shared and hasattr(image_encoder, "gram_residual_norms"):
                     loss = image_encoder.gram_residual_norms(img).sum()          # native on the GPU (csrc/vit.hip)
-                elif (not shared) and all(hasattr(e, "gram_residual_norms") for e in encs[lo:hi]):
-                    loss = sum(encs[i].gram_residual_norms(img[i - lo:i - lo + 1]).sum() for i in range(lo, hi))
+                elif (not shared) and all(hasattr(e, "gram_residual_norms_each") for e in encs[lo:hi]):
+                    loss = encs[lo].gram_residual_norms_each(encs[lo:hi], img).sum()     # one call, one reference per image
                 elif shared and hasattr(image_encoder, "gram_residuals"):
                     loss = torch.linalg.norm(image_encoder.gram_residuals(img), dim=(1, 2)).sum()
                 else:

@@ -77,9 +77,9 @@ def load_style_encoder(args, ref_path, device):
 
 
 def edit_group(args, model, entries, scale, size, device):
-    """--batch N: n entries in lock-step on the batched engine; every image keeps its own style encoder / reference
-    (CLIPEncoder.get_gram_matrix_residual reads batch item 0 only, clip_guidance/base_clip.py:60-65).
-    entries: [(item, image_path, save_path)]."""
+    """--batch N: n entries in lock-step on the batched engine; every image keeps its own style reference
+    (CLIPEncoder.get_gram_matrix_residual reads batch item 0 only, clip_guidance/base_clip.py:60-65) on ONE copy of the
+    encoder (CLIPEncoder.sibling).  entries: [(item, image_path, save_path)]."""
     from hedit.engine import HEditEngine
     from hedit.p2p.ptp_classes import ControllerBatch
     eng = HEditEngine(model)
@@ -91,7 +91,7 @@ def edit_group(args, model, entries, scale, size, device):
         original_prompt = item["original_prompt"].replace("[", "").replace("]", "")
         editing_prompt = item["editing_prompt"].replace("[", "").replace("]", "")
         blended_word = item["blended_word"].split(" ") if item["blended_word"] != "" else []
-        encs.append(load_style_encoder(args, args.dataset + item['style'], device))
+        encs.append(encs[0].sibling(args.dataset + item['style']) if encs else load_style_encoder(args, args.dataset + item['style'], device))
         x0 = load_512(image_path, 0, 0, 0, 0, device)
         if x0.shape[-1] != size:
             x0 = torch.nn.functional.interpolate(x0, size=(size, size), mode="bilinear", align_corners=False)

@@ -1,7 +1,7 @@
 """-m gpu: the native style encoder (hedit_vit_gram / hedit_vit_gram_fwd_bwd, csrc/vit.hip -- SURVEY.md section 8 row
 a19) against (1) vectors produced by RUNNING the reference's CLIPEncoder.get_gram_matrix_residual and CLIP ViT
 (text-guided-n-style/clip_guidance/base_clip.py, clip/model.py) at toy width, tests/golden/g10_clip.npz, and (2) the
-torch fp32 mirror at ViT-B/16 shape.  Tolerances: fp32 token stream with 16 mantissa bits per GEMM operand and fp32
+oracle's fp32 restatement (oracle/reward_nets.py, pinned on the same vectors, run on the CPU) at ViT-B/16 shape.  Tolerances: fp32 token stream with 16 mantissa bits per GEMM operand and fp32
 accumulation -> Gram residual / loss to 1e-4 relative, image gradient to 2e-3 relative L2 (the reference itself runs
 this encoder in fp16, model.py:414-435)."""
 import os
@@ -14,7 +14,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from helpers import gpu as G  # noqa: E402
+from oracle import reward_nets as RN  # noqa: E402
 from helpers.tiny import hash_normal  # noqa: E402
 from test_host_clip import G10, toy_prefix  # noqa: E402
 from hedit.clip_guidance import CLIPEncoder  # noqa: E402
@@ -29,7 +31,7 @@ def enc(tmp_path_factory):
     g = np.load(G10)
     path = str(tmp_path_factory.mktemp("style") / "ref.png")
     Image.fromarray(g["ref_rgb"]).save(path)
-    return CLIPEncoder(need_ref=True, ref_path=path, clip_model=toy_prefix(), device=G.dev(), backend="hip"), g
+    return CLIPEncoder(need_ref=True, ref_path=path, clip_model=toy_prefix(), device=G.dev()), g
 
 
 @pytest.mark.parametrize("i,hw", [(0, (64, 64)), (1, (96, 80))])
@@ -45,31 +47,52 @@ def test_native_gram_residual_and_gradient_match_reference_vectors(enc, i, hw):
     G.sync()
     assert abs(loss.item() - g[f"loss{i}"][0]) < 1e-4 * g[f"loss{i}"][0]
     assert G.rel_err(grad, torch.from_numpy(g[f"grad{i}"])) < 2e-3
+    # the reference's own call pattern: the residual MATRIX under autograd, then torch.linalg.norm (h_edit.py:172-175)
+    im2 = im.detach().clone().requires_grad_(True)
+    (grad2,) = torch.autograd.grad(torch.linalg.norm(e.get_gram_matrix_residual(im2)), im2)
+    G.sync()
+    assert G.rel_err(grad2, torch.from_numpy(g[f"grad{i}"])) < 2e-3
+    # ... and an arbitrary linear functional of it (upstream gradient that is not the norm's)
+    u = G.f32(hash_normal((64, 64), 5 + i))
+    im3 = im.detach().clone().requires_grad_(True)
+    (grad3,) = torch.autograd.grad((e.get_gram_matrix_residual(im3) * u).sum(), im3)
+    imc = im.detach().cpu().clone().requires_grad_(True)
+    ec = _cpu_twin(e)
+    (want3,) = torch.autograd.grad((RN.clip_gram_residual(ec, imc) * u.cpu()).sum(), imc)
+    G.sync()
+    assert G.rel_err(grad3, want3) < 2e-3
 
 
-def test_native_matches_torch_mirror_at_vit_b16_shape_and_is_batch_invariant():
+def _cpu_twin(e):
+    """the same parameters and style reference on the CPU, for the oracle"""
+    import copy
+    twin = CLIPEncoder(clip_model=copy.deepcopy(e.clip_model).cpu().float())
+    twin.set_reference(e.ref.detach().cpu().float())
+    return twin
+
+
+def test_native_matches_oracle_at_vit_b16_shape_and_is_batch_invariant():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     m = ClipVisualPrefix().init_random(13)
     ref = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(17))
-    nat = CLIPEncoder(clip_model=m.float(), device=G.dev(), backend="hip")
-    tor = CLIPEncoder(clip_model=m.float(), device=G.dev(), backend="torch")
+    nat = CLIPEncoder(clip_model=m.float(), device=G.dev())
     nat.set_reference(ref.to(G.dev()))
-    tor.set_reference(ref.to(G.dev()))
-    ims = G.f32(torch.randn(4, 3, 512, 512, generator=torch.Generator().manual_seed(3)) * 0.5)
-    xs = [ims.clone().requires_grad_(True) for _ in range(2)]
-    ln, lt = nat.gram_residual_norms(xs[0]), tor.gram_residual_norms(xs[1])
-    gn, gt = torch.autograd.grad(ln.sum(), xs[0])[0], torch.autograd.grad(lt.sum(), xs[1])[0]
+    tor = _cpu_twin(nat)
+    ims = torch.randn(4, 3, 512, 512, generator=torch.Generator().manual_seed(3)) * 0.5
+    xn, xt = G.f32(ims).requires_grad_(True), ims.clone().requires_grad_(True)
+    ln, lt = nat.gram_residual_norms(xn), RN.clip_gram_residual_norms(tor, xt)
+    gn, gt = torch.autograd.grad(ln.sum(), xn)[0], torch.autograd.grad(lt.sum(), xt)[0]
     G.sync()
     assert G.rel_err(ln, lt) < 1e-4
     assert G.rel_err(gn, gt) < 2e-3
-    one = nat.gram_residual_norms(ims[2:3])
+    one = nat.gram_residual_norms(G.f32(ims[2:3]))
     G.sync()
     assert torch.equal(one, ln[2:3].detach())
 
 
-def test_backend_hip_has_no_cpu_fallback():
-    e = CLIPEncoder(clip_model=toy_prefix(), backend="hip")
+def test_there_is_no_cpu_path():
+    e = CLIPEncoder(clip_model=toy_prefix())
     e.set_reference(torch.zeros(1, 3, 224, 224))
     with pytest.raises(RuntimeError):
         e.gram_residual_norms(torch.zeros(1, 3, 64, 64))

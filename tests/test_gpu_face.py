@@ -81,18 +81,28 @@ def test_unet_rejects_mixed_timesteps(tiny):
         hip(torch.zeros(2, 3, 32, 32, device=G.dev()), torch.tensor([1.0, 2.0]))
 
 
-def test_celeba_shape_runs_and_is_deterministic():
+def test_celeba_shape_matches_oracle_and_is_batch_invariant():
+    """CelebA-HQ 256 configuration (113.7 M parameters, random weights): eps against the oracle that is pinned on the
+    reference's own Model (face-swapping/diffusion/diffusion.py:301-341), repeatable, and a row's eps is a function of
+    the row alone -- bit for bit, whatever else shares the batch."""
     from hedit.diffusion import Model
+    from oracle import ddpm_unet
     hip = Model(device=G.dev())
-    hip.init_random(1)
-    x = (hash_normal((2, 3, 256, 256), 5) * 0.8).to(G.dev())
-    a = hip(x, 501.0)
-    b = hip(x, 501.0)
+    sd = hip.init_random(1)
+    x = hash_normal((3, 3, 256, 256), 5) * 0.8
+    xg = x.to(G.dev())
+    a = hip(xg, 501.0)
+    b = hip(xg, 501.0)
     G.sync()
-    assert a.shape == (2, 3, 256, 256) and torch.isfinite(a).all()
+    assert a.shape == (3, 3, 256, 256) and torch.isfinite(a).all()
     assert torch.equal(a, b)
-    # batch-size dependent split-K / GroupNorm slab partitions: bf16 rounding-level difference (measured 8e-3)
-    assert G.rel_err(hip(x[:1], 501.0), a[:1]) < 2e-2
+    assert torch.equal(hip(xg[:1], 501.0), a[:1])
+    assert torch.equal(hip(xg[1:], 501.0), a[1:])
+    om = ddpm_unet.Model(**ddpm_unet.CELEBA_HQ).eval()
+    om.load_state_dict(sd)
+    with torch.no_grad():
+        want = om(x[:1], torch.ones(1) * 501.0)
+    assert G.rel_err(a[:1], want) < 2.5e-2          # bf16 activations, fp32 accumulation
 
 
 def linear_betas():
@@ -135,20 +145,21 @@ def test_sde_inversion_and_face_loop_match_oracle():
 
 def test_unet_batch_grouping_of_the_attention_is_transparent(tiny):
     """the block-diagonal attention stacks up to 4096 / T images per pass: a batch of 20 at T = 256 runs as groups of
-    16 + 4; every image must come out as in a batch of its own (up to the bf16 rounding of batch-dependent partitions)"""
+    16 + 4; every image must come out exactly as in a batch of its own"""
     hip, _ = tiny
     x = (hash_normal((20, 3, 32, 32), 71) * 0.8).to(G.dev())
     big = hip(x, 401.0)
     parts = torch.cat([hip(x[i:i + 5], 401.0) for i in range(0, 20, 5)])
     G.sync()
     assert torch.isfinite(big).all()
-    for i in (0, 7, 15, 16, 19):
-        assert G.rel_err(big[i:i + 1], parts[i:i + 1]) < 2e-2, i
+    assert torch.equal(big, parts)
 
 
 def test_lockstep_faces_equal_single_runs():
     """h_Edit_R(per_image=True) on two faces at once (xT (2,3,S,S), zs (T,2,3,S,S)) == two single-face runs: the batch-mean
-    losses are rescaled so that every face receives its own full gradient"""
+    losses are rescaled so that every face receives its own full gradient.  The eps-network is batch-invariant bit for
+    bit (asserted first); the toy reward networks of this test are torch modules (MIOpen convolutions, batch-mean losses
+    rescaled by the batch size), so the loop results agree to their fp32 rounding, not bitwise."""
     from hedit.diffusion import TINY_DDPM_CONFIG
     from hedit.inversion.h_edit_R import h_Edit_R
     hip, _ = make_pair(TINY_DDPM_CONFIG, seed=2, out_scale=0.3)
@@ -161,9 +172,12 @@ def test_lockstep_faces_equal_single_runs():
     import copy
     idl, lp = copy.deepcopy(TinyIdLoss()).to(dev), copy.deepcopy(TinyLpips()).to(dev)
     kw = dict(eta=1.0, weight_edit_face=4.0, optimization_steps=2, after_skip_steps=T, num_inference_steps=T)
+    e2 = hip(xT, 501.0)
+    assert torch.equal(e2[:1], hip(xT[:1], 501.0)) and torch.equal(e2[1:], hip(xT[1:], 501.0))
     both = h_Edit_R(hip, lp, idl, xT, betas, seq, zs=zs, per_image=True, **kw)
     for i in range(2):
         one = h_Edit_R(hip, lp, idl, xT[i:i + 1], betas, seq, zs=zs[:, i:i + 1], **kw)
         G.sync()
-        assert G.rel_err(both[i:i + 1], one) < 3e-2, i
+        print("lockstep face", i, G.rel_err(both[i:i + 1], one))
+        assert G.rel_err(both[i:i + 1], one) < 2e-3, i
     assert G.rel_err(both[0], both[1]) > 1e-1

@@ -1,23 +1,28 @@
 """-m gpu: the native perceptual reward (hedit_lpips_source / hedit_lpips_fwd_bwd, csrc/lpips.hip -- SURVEY.md section 8
-row a24) against the torch fp32 restatement of lpips.LPIPS(net='vgg') (hedit/arcface/lpips_loss.py::LPIPSNet) on the
+row a24) against the oracle's fp32 restatement of lpips.LPIPS(net='vgg') (oracle/reward_nets.py, run on the CPU) on the
 same seeded weights.  PARITY UNPINNED: the third-party lpips package is neither in the reference tree nor in this
 image and the reference holds no vector for it; what is checked is the native executor against the restatement.
 Tolerances: the loss agrees to 1e-5 relative (16 mantissa bits per operand, fp32 accumulation); the image gradient to
 6e-3 relative L2 -- ReLU masks / pooling winners of values within 1e-5 of a tie flip between the two arithmetics."""
+import os
+import sys
+
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from helpers import gpu as G  # noqa: E402
+from oracle import reward_nets as RN  # noqa: E402
 from hedit.arcface.lpips_loss import LPIPS_Loss  # noqa: E402
 
 
 def _pair(src, seed=1):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    return (LPIPS_Loss(src=src, device=G.dev(), seed=seed, backend="hip"),
-            LPIPS_Loss(src=src, device=G.dev(), seed=seed, backend="torch"))
+    return (LPIPS_Loss(src=src, device=G.dev(), seed=seed),
+            LPIPS_Loss(src=src, seed=seed))          # the same parameters on the CPU, for the oracle
 
 
 @pytest.mark.parametrize("B,S,per_image", [(2, 64, False), (3, 96, True), (4, 256, False)])
@@ -25,16 +30,17 @@ def test_native_lpips_matches_restatement(B, S, per_image):
     g = torch.Generator().manual_seed(B * 100 + S)
     src = torch.randn(B if per_image else 1, 3, S, S, generator=g) * 0.4
     nat, tor = _pair(src)
-    x = G.f32(torch.randn(B, 3, S, S, generator=g) * 0.4)
-    xs = [x.clone().requires_grad_(True) for _ in range(2)]
-    ln, lt = nat.get_lpips_loss(xs[0]), tor.get_lpips_loss(xs[1])
+    xc = torch.randn(B, 3, S, S, generator=g) * 0.4
+    x = G.f32(xc)
+    xs = [x.clone().requires_grad_(True), xc.clone().requires_grad_(True)]
+    ln, lt = nat.get_lpips_loss(xs[0]), RN.lpips_loss(tor, xs[1])
     gn, gt = torch.autograd.grad(ln, xs[0])[0], torch.autograd.grad(lt, xs[1])[0]
     G.sync()
     assert abs(ln.item() - lt.item()) < 1e-5 * abs(lt.item()) + 1e-9
     assert G.rel_err(gn, gt) < 6e-3
     # per-image losses: batch-invariant bits
     l_all, _ = nat._native_loss_and_grad(x)
-    nat1 = LPIPS_Loss(src=src[1:2] if per_image else src, device=G.dev(), seed=1, backend="hip")
+    nat1 = LPIPS_Loss(src=src[1:2] if per_image else src, device=G.dev(), seed=1)
     l_one, _ = nat1._native_loss_and_grad(x[1:2])
     G.sync()
     assert torch.equal(l_all[1:2], l_one)
@@ -51,7 +57,7 @@ def test_identical_images_have_zero_distance_and_zero_gradient():
     assert loss.item() == 0.0 and float(grad.abs().max()) == 0.0
 
 
-def test_backend_hip_has_no_cpu_fallback():
-    m = LPIPS_Loss(src=torch.zeros(1, 3, 32, 32), seed=0, backend="hip")
+def test_there_is_no_cpu_path():
+    m = LPIPS_Loss(src=torch.zeros(1, 3, 32, 32), seed=0)
     with pytest.raises(RuntimeError):
         m.get_lpips_loss(torch.zeros(1, 3, 32, 32))

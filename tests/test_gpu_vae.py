@@ -78,6 +78,15 @@ def test_batch_rows_are_independent_and_deterministic(tiny):
     G.sync()
     assert torch.equal(a, b)
     assert torch.equal(a[0], a[1]) and torch.equal(a[0], a[2])
+    # different rows: each decoded image (and its encoding) is a function of its own latent alone, bit for bit
+    z5 = torch.randn(5, 4, 16, 16, generator=g).to(G.dev())
+    d5 = hip.decode(z5).sample.clone()
+    for i in (0, 3, 4):
+        assert torch.equal(hip.decode(z5[i:i + 1]).sample, d5[i:i + 1]), i
+    assert torch.equal(hip.decode(z5[1:4]).sample, d5[1:4])
+    x5 = (torch.rand(4, 3, 32, 32, generator=g) * 2 - 1).to(G.dev())
+    m5 = hip.encode(x5).latent_dist.mode().clone()
+    assert torch.equal(hip.encode(x5[2:3]).latent_dist.mode(), m5[2:3])
 
 
 def test_sd15_decode_512():

@@ -1,7 +1,8 @@
-"""hedit.arcface.IDLoss (the identity reward) against vectors produced by RUNNING
-the reference's IDLoss and IR-SE50 backbone (face-swapping/arcface/arcface_model.py:11-67,
-facial_recognition/model_irse.py, helpers.py) with hash-seeded weights -- tests/golden/g12_idloss.npz,
-generator tests/golden/make_golden.py::gen_idloss."""
+"""The oracle of the identity reward -- oracle/reward_nets.py evaluated on the product's
+parameter container hedit.arcface.IDLoss -- against vectors produced by RUNNING the reference's IDLoss and IR-SE50
+backbone (face-swapping/arcface/arcface_model.py:11-67, facial_recognition/model_irse.py, helpers.py) with hash-seeded
+weights: tests/golden/g12_idloss.npz, generator tests/golden/make_golden.py::gen_idloss.  The product itself has no
+CPU path (asserted here); the native executor is compared with the same vectors in tests/test_gpu_arcface.py."""
 import os
 import sys
 import zlib
@@ -12,8 +13,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from helpers.tiny import hash_normal  # noqa: E402
+from oracle import reward_nets as RN  # noqa: E402
 from hedit.arcface import Backbone, IDLoss  # noqa: E402
 
 G12 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g12_idloss.npz")
@@ -68,12 +71,21 @@ def test_features_loss_and_gradient_match_reference(idl, i, b, hw):
     m, g = idl
     x = (hash_normal((b, 3, hw, hw), 40 + i) * 0.4).requires_grad_(True)
     with torch.no_grad():
-        feat = m.extract_feats(x.detach())
-        sim = m.get_cosine_sim(x.detach())
+        feat = RN.idloss_extract_feats(m, x.detach())
+        sim = RN.idloss_cosine_sim(m, x.detach())
     assert np.allclose(feat.numpy(), g[f"feat{i}"], atol=2e-5)
     assert np.allclose(sim.numpy(), g[f"sim{i}"], atol=2e-5)
-    loss = m.get_cosine_loss(x)
+    loss = RN.idloss_cosine_loss(m, x)
     (grad,) = torch.autograd.grad(loss, x)
     assert abs(loss.item() - g[f"loss{i}"][0]) < 2e-5
     want = g[f"grad_sub{i}"]
     assert np.allclose(grad[:, :, ::4, ::4].numpy(), want, atol=2e-3 * np.abs(want).max(), rtol=1e-3)
+
+
+def test_product_has_no_cpu_path(idl):
+    m, _ = idl
+    x = hash_normal((1, 3, 256, 256), 3) * 0.4
+    for call in (m.extract_feats, m.get_cosine_sim, m.get_cosine_loss):
+        with pytest.raises(RuntimeError, match="HIP executor only"):
+            call(x)
+    assert type(m.facenet).forward is torch.nn.Module.forward

@@ -1,7 +1,8 @@
-"""hedit.clip_guidance.CLIPEncoder (the style image encoder) against
-vectors produced by RUNNING the reference's CLIPEncoder.get_gram_matrix_residual and CLIP ViT
-(text-guided-n-style/clip_guidance/base_clip.py, clip/model.py) at toy width -- tests/golden/g10_clip.npz,
-generator tests/golden/make_golden.py::gen_clip.  fp32 on CPU here; the GPU runs use fp16 weights."""
+"""The oracle of the style image encoder -- oracle/reward_nets.py evaluated on the
+product's parameter container hedit.clip_guidance.CLIPEncoder -- against vectors produced by RUNNING the reference's
+CLIPEncoder.get_gram_matrix_residual and CLIP ViT (text-guided-n-style/clip_guidance/base_clip.py, clip/model.py)
+at toy width: tests/golden/g10_clip.npz, generator tests/golden/make_golden.py::gen_clip.  The product itself has no
+CPU path (asserted here); the native executor is compared with the same vectors in tests/test_gpu_clip.py."""
 import os
 import sys
 import zlib
@@ -12,8 +13,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from helpers.tiny import hash_normal  # noqa: E402
+from oracle import reward_nets as RN  # noqa: E402
 from hedit.clip_guidance import CLIPEncoder  # noqa: E402
 from hedit.clip_guidance.base_clip import ClipVisualPrefix, load_style_reference  # noqa: E402
 
@@ -55,9 +58,9 @@ def test_gram_residual_and_gradient_match_reference(enc, i, hw):
     e, g = enc
     im = (hash_normal((1, 3) + hw, 900 + i) * 0.6).requires_grad_(True)
     x = torch.nn.functional.interpolate(im.detach(), size=(224, 224), mode="bicubic")
-    feat = e.clip_model.block_features(e.preprocess(x))[0]
+    feat = RN.vit_block_features(e.clip_model, e.preprocess(x))[0]
     assert np.allclose(feat.detach().numpy(), g[f"feat{i}"], atol=2e-5, rtol=1e-5)     # feats[2][:, 0, :]
-    res = e.get_gram_matrix_residual(im)
+    res = RN.clip_gram_residual(e, im)
     loss = torch.linalg.norm(res)
     (grad,) = torch.autograd.grad(loss, im)
     assert res.shape == (64, 64)
@@ -75,7 +78,7 @@ def test_reads_full_clip_state_dict_names():
     sd["token_embedding.weight"] = torch.zeros(16, 64)
     m2 = ClipVisualPrefix(width=64, layers=3, heads=1, patch_size=32, input_resolution=224).load_clip_state_dict(sd)
     x = hash_normal((1, 3, 224, 224), 5)
-    assert torch.equal(m.block_features(x), m2.block_features(x))
+    assert torch.equal(RN.vit_block_features(m, x), RN.vit_block_features(m2, x))
     del sd["visual.ln_pre.bias"]
     with pytest.raises(KeyError):
         ClipVisualPrefix(width=64, layers=3, heads=1, patch_size=32, input_resolution=224).load_clip_state_dict(sd)
@@ -93,6 +96,15 @@ def test_vit_b16_shape():
 def test_batched_residuals_equal_per_image(enc):
     e, _ = enc
     ims = hash_normal((3, 3, 48, 40), 77) * 0.5
-    got = e.gram_residuals(ims)
+    got = RN.clip_gram_residuals(e, ims)
     for i in range(3):
-        assert torch.allclose(got[i], e.get_gram_matrix_residual(ims[i:i + 1]), atol=1e-4, rtol=1e-5)
+        assert torch.allclose(got[i], RN.clip_gram_residual(e, ims[i:i + 1]), atol=1e-4, rtol=1e-5)
+
+
+def test_product_has_no_cpu_path(enc):
+    e, _ = enc
+    ims = hash_normal((1, 3, 48, 40), 7) * 0.5
+    for call in (e.get_gram_matrix_residual, e.gram_residuals, e.gram_residual_norms):
+        with pytest.raises(RuntimeError, match="HIP executor only"):
+            call(ims)
+    assert not hasattr(e.clip_model, "block_features") and type(e.clip_model).forward is torch.nn.Module.forward
