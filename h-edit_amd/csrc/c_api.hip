@@ -82,6 +82,12 @@ int hedit_local_blend(float* const* h_maps, int n_maps, int heads, const float* 
   return local_blend_launch(const_cast<const float* const*>(h_maps), n_maps, heads, alpha_layers, enabled, xt, n_img, C, H, W, th, S(stream));
 } catch (...) { return hedit_abi_catch(); }
 
+int hedit_axis_mix(const float* in, float* out, const int32_t* idx, const float* val, int nnz, int64_t outer, int n_in, int n_out, int inner,
+                   void* stream) try {
+  ARG_CHECK(in && out && idx && val, "axis_mix args");
+  return axis_mix_launch(in, out, idx, val, nnz, (long)outer, n_in, n_out, inner, S(stream));
+} catch (...) { return hedit_abi_catch(); }
+
 size_t hedit_k_gemm_ws_bytes(int M, int N, int K, int splits) try {
   const int s = gemm_pick_splits(M, N, K, splits);
   return gemm_partial_bytes(M, N, s);

@@ -174,6 +174,9 @@ int step_tweedie_launch(const float* e_u_tar, const float* e_c_tar, long stride_
 int step_style_launch(const float* e_u_src, const float* e_c_src, const float* e_u_tar, const float* e_c_tar,
                       long stride_img, const float* x, const float* g_z, float* x_out, int n_img, int elems, float w_hat,
                       float w_tar, float chain, float weight, hipStream_t st);
+// out[o][i][x] = sum_j val[i][j] in[o][idx[i][j]][x] over a [outer][n_in][inner] fp32 tensor (tables [n_out][nnz])
+int axis_mix_launch(const float* in, float* out, const int* idx, const float* val, int nnz, long outer, int n_in, int n_out, int inner,
+                    hipStream_t st);
 int local_blend_launch(const float* const* maps, int n_maps, int heads, const float* alpha_layers,
                        const int* enabled, float* xt, int n_img, int C, int H, int W, float th, hipStream_t st);
 

@@ -276,3 +276,32 @@ int local_blend_launch(const float* const* maps, int n_maps, int heads, const fl
   LAUNCH_CHECK();
   return HEDIT_OK;
 }
+
+// ------------------------------------------------------------------ axis mix (bicubic resize of the style closure)
+// out[o][i][x] = sum_j val[i][j] * in[o][idx[i][j]][x],  j < nnz in table order: a sparse linear map along one axis of
+// a [outer][n][inner] fp32 tensor.  With the bicubic weights of F.interpolate as the table it is the resize in front
+// of the style encoder (clip_guidance/base_clip.py:57-58), with the transposed table its backward -- one thread per
+// output element and a fixed summation order, so forward and backward are repeatable and batch-invariant bit for bit
+// (torch's bicubic backward accumulates with atomics).
+__global__ __launch_bounds__(256) void axis_mix_kernel(const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ idx,
+                                                       const float* __restrict__ val, int nnz, long outer, int n_in, int n_out, int inner) {
+  const long total = outer * n_out * inner;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int x = (int)(e % inner);
+    const long r = e / inner;
+    const int i = (int)(r % n_out);
+    const long o = r / n_out;
+    const float* src = in + o * n_in * inner + x;
+    float acc = 0.f;
+    for (int j = 0; j < nnz; ++j) acc += val[i * nnz + j] * src[(long)idx[i * nnz + j] * inner];
+    out[e] = acc;
+  }
+}
+
+int axis_mix_launch(const float* in, float* out, const int* idx, const float* val, int nnz, long outer, int n_in, int n_out, int inner,
+                    hipStream_t st) {
+  ARG_CHECK(nnz >= 1 && outer >= 1 && n_in >= 1 && n_out >= 1 && inner >= 1, "axis_mix: shape");
+  hipLaunchKernelGGL(axis_mix_kernel, dim3(ew_grid(outer * n_out * inner)), dim3(256), 0, st, in, out, idx, val, nnz, outer, n_in, n_out, inner);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}

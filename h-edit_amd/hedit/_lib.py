@@ -149,6 +149,8 @@ _SIGS = {
     "hedit_vae_decode_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hedit_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p]),
+    "hedit_axis_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p]),
     "hedit_k_gemm_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "hedit_k_gemm_canonical_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "hedit_k_gemm_plan_splits": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -99,6 +99,68 @@ def read_clip_checkpoint(path):
         return sd.get("state_dict", sd) if isinstance(sd, dict) else sd.state_dict()
 
 
+_RESIZE_TABLES = {}
+
+
+def _resize_tables(n_in, n_out, device):
+    """torch's own bicubic weights (align_corners=False, A = -0.75, border clamping) as sparse tables: forward
+    [n_out][4+] and transposed [n_in][*].  The axis map is extracted from F.interpolate on the identity, so the resize
+    computes what the reference's F.interpolate(..., mode="bicubic") computes, tap for tap."""
+    key = (n_in, n_out, str(device))
+    if key not in _RESIZE_TABLES:
+        w = F.interpolate(torch.eye(n_in, dtype=torch.float64)[None, None], size=(n_out, n_in), mode="bicubic")[0, 0]      # [n_out][n_in]
+
+        def table(m):
+            nnz = int((m != 0).sum(1).max())
+            idx = torch.zeros(m.shape[0], nnz, dtype=torch.int32)
+            val = torch.zeros(m.shape[0], nnz, dtype=torch.float32)
+            for i in range(m.shape[0]):
+                j = torch.nonzero(m[i]).flatten()
+                idx[i, :len(j)] = j.int()
+                val[i, :len(j)] = m[i, j].float()
+            return idx.contiguous().to(device), val.contiguous().to(device), nnz
+        _RESIZE_TABLES[key] = (table(w), table(w.t().contiguous()))
+    return _RESIZE_TABLES[key]
+
+
+def _axis_mix(x, tab, axis):
+    from .. import _lib
+    idx, val, nnz = tab
+    x = x.float().contiguous()
+    shape = list(x.shape)
+    outer = 1
+    for d in shape[:axis]:
+        outer *= d
+    inner = 1
+    for d in shape[axis + 1:]:
+        inner *= d
+    n_out = idx.shape[0]
+    out = torch.empty(shape[:axis] + [n_out] + shape[axis + 1:], device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().hedit_axis_mix(_lib.ptr(x), _lib.ptr(out), _lib.ptr(idx), _lib.ptr(val), nnz, outer, shape[axis], n_out, inner,
+                                             _lib.cur_stream()))
+    return out
+
+
+class _BicubicResize(torch.autograd.Function):
+    """F.interpolate(im, size=(S, S), mode="bicubic") with a deterministic, batch-invariant backward (hedit_axis_mix)"""
+
+    @staticmethod
+    def forward(ctx, im, size):
+        H, W = im.shape[2], im.shape[3]
+        ctx.dims = (H, W, size)
+        fy, _ = _resize_tables(H, size, im.device)
+        fx, _ = _resize_tables(W, size, im.device)
+        return _axis_mix(_axis_mix(im.detach(), fy, 2), fx, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W, size = ctx.dims
+        _, by = _resize_tables(H, size, g.device)
+        _, bx = _resize_tables(W, size, g.device)
+        return _axis_mix(_axis_mix(g, bx, 3), by, 2), None
+
+
 class _NativeGramNorm(torch.autograd.Function):
     """sum_b |Gram(x_b) - Gram_ref|_F with the gradient w.r.t. x from the same native call"""
 
@@ -117,9 +179,9 @@ class _NativeGramNorm(torch.autograd.Function):
 class _NativeGramResidual(torch.autograd.Function):
     """Gram(x_b) - Gram_ref as a differentiable (B, D, D) tensor, for callers that take the residual itself (the
     reference's closure: torch.linalg.norm(get_gram_matrix_residual(img)), h_edit.py:172-175).  Backward for an
-    arbitrary upstream gradient U_b through the executor's norm-gradient entry: with the per-image reference
-    R_b = Gram_b - U_b that entry back-propagates (Gram_b - R_b) / |Gram_b - R_b| = U_b / |U_b|, so |U_b| times its
-    result is exactly J^T U_b."""
+    arbitrary upstream gradient U_b through the executor's norm-gradient entry: a Gram matrix is symmetric, so only the
+    symmetric part of U_b acts on it; with the per-image reference R_b = Gram_b - sym(U_b) that entry back-propagates
+    (Gram_b - R_b) / |Gram_b - R_b| = sym(U_b) / |sym(U_b)|, so |sym(U_b)| times its result is exactly J^T U_b."""
 
     @staticmethod
     def forward(ctx, x, owner):
@@ -132,7 +194,7 @@ class _NativeGramResidual(torch.autograd.Function):
     @staticmethod
     def backward(ctx, up):
         xd, gram = ctx.saved_tensors
-        up = up.float()
+        up = 0.5 * (up.float() + up.float().transpose(1, 2))
         nrm = up.flatten(1).norm(dim=1)
         live = nrm > 0
         ref = torch.where(live.view(-1, 1, 1), gram - up, gram - 1.0).contiguous()      # (a dead row must not divide by 0)
@@ -248,7 +310,7 @@ class CLIPEncoder(nn.Module):
         first._native(ims.device)
         if any(getattr(e, "_h", None) is None for e in encs[1:]) or any(e._h.value != first._h.value for e in encs[1:]):
             return torch.cat([e.gram_residual_norms(ims[i:i + 1]) for i, e in enumerate(encs)])
-        x = first.preprocess(F.interpolate(ims, size=(first.size, first.size), mode="bicubic"))
+        x = first.preprocess(_BicubicResize.apply(ims, first.size))
         refs = torch.stack([e._native_ref(ims.device) for e in encs]).contiguous()
         return _NativeGramNorm.apply(x, first, refs)
 
@@ -307,7 +369,7 @@ class CLIPEncoder(nn.Module):
         style closure needs (torch.linalg.norm of the residual, inversion/h_edit.py:172-175).  One native call evaluates
         norm and gradient; resize + normalisation stay torch ops in front of it."""
         self._require_gpu(ims)
-        x = self.preprocess(F.interpolate(ims, size=(self.size, self.size), mode="bicubic"))
+        x = self.preprocess(_BicubicResize.apply(ims, self.size))
         return _NativeGramNorm.apply(x, self)
 
     def get_gram_matrix_residual(self, im1):
@@ -320,7 +382,7 @@ class CLIPEncoder(nn.Module):
         """Batched form for images that share this style reference: (N, 3, H, W) -> (N, D, D), row i equal to
         get_gram_matrix_residual(ims[i:i+1]) (one encoder pass for the N images of a lock-step batch)."""
         self._require_gpu(ims)
-        x = self.preprocess(F.interpolate(ims, size=(self.size, self.size), mode="bicubic"))
+        x = self.preprocess(_BicubicResize.apply(ims, self.size))
         return _NativeGramResidual.apply(x, self)
 
 

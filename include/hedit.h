@@ -179,6 +179,12 @@ int hedit_step_tweedie(const float* e_u_tar, const float* e_c_tar, int64_t strid
 int hedit_step_style(const float* e_u_src, const float* e_c_src, const float* e_u_tar, const float* e_c_tar,
                      int64_t stride_img, const float* x, const float* g_z, float* x_out, int n_img, int elems,
                      float w_hat, float w_tar, float chain, float weight, void* stream);
+/* A sparse linear map along one axis of a [outer][n_in][inner] fp32 tensor: out[o][i][x] = sum_j val[i][j] in[o][idx[i][j]][x]
+ * (tables [n_out][nnz], fixed summation order).  With torch's bicubic weights it replaces F.interpolate(im, (224, 224),
+ * mode="bicubic") in front of the style encoder (text-guided-n-style/clip_guidance/base_clip.py:57-58) and, with the
+ * transposed table, its backward -- repeatable and batch-invariant, where torch's bicubic backward uses atomics. */
+int hedit_axis_mix(const float* in, float* out, const int32_t* idx, const float* val, int nnz, int64_t outer, int n_in, int n_out,
+                   int inner, void* stream);
 int hedit_local_blend(float* const* h_maps, int n_maps, int heads, const float* alpha_layers,
                       const int32_t* enabled, float* xt, int n_img, int C, int H, int W, float th,
                       void* stream);
