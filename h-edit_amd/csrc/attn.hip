@@ -125,11 +125,23 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
+  // XCD-aware block order.  Workgroup i is observed to run on XCD i % 8 (speed only, never correctness): give every XCD
+  // one contiguous chunk of the (row, head, query block) sequence, query blocks innermost, so that the blocks which
+  // stream the same K / V^T of one (row, head) share one 4 MB L2 instead of all eight fetching their own copy
+  // (measured before: 3.6x the algorithmic HBM traffic).
+  const int qblocks = (p.N + 128 * QG - 1) / (128 * QG);
+  int v;
+  {
+    const int nb = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int xcd = bid & 7, seq = bid >> 3, q8 = nb >> 3, r8 = nb & 7;
+    v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + seq;
+  }
+  const int qblk = v % qblocks;
+  const int h = (v / qblocks) % p.heads, b = v / (qblocks * p.heads);
   const int bqk = p.qk_src ? p.qk_src[b] : b;                       // P2P self-replace: q and k of another row
   const int bk = p.kv_src ? p.kv_src[b] : bqk;                      // mutual self-attention: k and v of another row
   const int bv = p.kv_src ? p.kv_src[b] : b;
-  const int q_base = blockIdx.x * (128 * QG) + wave * (32 * QG) + ql;
+  const int q_base = qblk * (128 * QG) + wave * (32 * QG) + ql;
 
   // zero LDS once (pad rows of V^T must be finite zeros), then the row of ones
   for (int i = tid; i < C::TOTAL / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
@@ -568,7 +580,7 @@ int launch_self(const SelfAttnParams& p, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL));
     attr_set = true;
   }
-  dim3 grid(cdiv(p.N, 128 * QG), p.heads, p.B);
+  dim3 grid(cdiv(p.N, 128 * QG) * p.heads * p.B);
   hipLaunchKernelGGL((self_attn_kernel<D, QG, NS>), grid, dim3(256), C::TOTAL, st, p);
   LAUNCH_CHECK();
   return HEDIT_OK;

@@ -779,6 +779,14 @@ int hedit_unet_param_shape(const hedit_unet* h, int i, int* ndim, int* dims4) tr
   return HEDIT_OK;
 } catch (...) { return hedit_abi_catch(); }
 
+/* 1: the executor keeps this parameter as an unscaled bf16 copy (matrices, convolutions), so handing it over rounded to
+   bf16 loses nothing -- what the start-up weight broadcast uses to halve its blob; 0: kept in fp32 or scaled while packed */
+int hedit_unet_param_bf16_exact(const hedit_unet* h, int i) try {
+  if (!h || i < 0 || i >= (int)h->slots.size()) return 0;
+  const Slot& s = h->slots[i];
+  return ((s.kind == 1 && s.scale == 1.f) || s.kind == 2 || s.kind == 3 || s.kind == 5 || s.kind == 7) ? 1 : 0;
+} catch (...) { (void)hedit_abi_catch(); return 0; }
+
 int hedit_unet_load(hedit_unet* h, const char* name, const float* w, size_t numel, void* stream) try {
   ARG_CHECK(h && name && w, "null");
   auto it = h->index.find(name);

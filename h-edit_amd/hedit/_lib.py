@@ -57,6 +57,7 @@ _SIGS = {
     "hedit_unet_param_name": (C.c_char_p, [C.c_void_p, C.c_int]),
     "hedit_unet_param_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "hedit_unet_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hedit_unet_param_bf16_exact": (C.c_int, [C.c_void_p, C.c_int]),
     "hedit_unet_missing": (C.c_int, [C.c_void_p]),
     "hedit_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "hedit_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int,

@@ -18,6 +18,11 @@ _WEIGHT_FILES = ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model
                  "diffusion_pytorch_model.fp16.safetensors")
 
 
+def read_config(path):
+    with open(os.path.join(path, "config.json")) as f:
+        return json.load(f)
+
+
 def read_component(path):
     """(config dict, state_dict of CPU tensors) of one sub-folder."""
     with open(os.path.join(path, "config.json")) as f:

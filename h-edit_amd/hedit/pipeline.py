@@ -47,14 +47,31 @@ class HEditPipeline:
         from .vae import AutoencoderKL
         if not os.path.isdir(path):
             raise FileNotFoundError(f"{path}: not a local checkpoint directory (this build never downloads)")
-        ucfg, usd = CK.read_component(os.path.join(path, "unet"))
+        # in a multi-rank job only rank 0 reads the weight files; the others receive them by one broadcast per blob
+        # (RCCL over xGMI, hedit.dist.state_dict_from_rank0).  The small config.json files are read by every rank.
+        from . import dist as HD
+        ucfg = CK.read_config(os.path.join(path, "unet"))
         unet = UNet2DConditionModel(CK.unet_config(ucfg), device=device)
+        usd = HD.state_dict_from_rank0(lambda: CK.read_component(os.path.join(path, "unet"))[1], unet.param_shapes, device=device,
+                                       bf16_names=unet.bf16_exact)
         unet.load_state_dict(usd)
+        del usd
         vae = None
         if os.path.isdir(os.path.join(path, "vae")):
-            vcfg, vsd = CK.read_component(os.path.join(path, "vae"))
+            vcfg = CK.read_config(os.path.join(path, "vae"))
             vae = AutoencoderKL(CK.vae_config(vcfg), device=device)
+            def read_vae():
+                sd = vae.current_names(CK.read_component(os.path.join(path, "vae"))[1])
+                fix = {}
+                for k, shape in vae.param_shapes.items():       # pre-0.18 checkpoints store 1x1 convs as linears and vice versa
+                    w = sd[k]
+                    fix[k] = w[:, :, None, None] if (w.dim() == 2 and len(shape) == 4) else (w[:, :, 0, 0] if (w.dim() == 4 and len(shape) == 2) else w)
+                return fix
+            multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+            vsd = (HD.state_dict_from_rank0(read_vae, vae.param_shapes, device=device) if multi
+                   else CK.read_component(os.path.join(path, "vae"))[1])
             vae.load_state_dict(vsd)
+            del vsd
         if tokenizer is None:
             from transformers import CLIPTokenizer
             tokenizer = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"), local_files_only=True)

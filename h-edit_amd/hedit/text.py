@@ -8,7 +8,6 @@ HEditPipeline instead.
 """
 import math
 import types
-import zlib
 
 import torch
 import torch.nn as nn
@@ -28,17 +27,20 @@ class WordTokenizer:
 
     def _id(self, w):
         # default: ids in order of first sight (what the committed golden vectors were generated with).  stable_ids: a
-        # word's id is a function of the word (CRC-32 into the id range; a collision moves to the next free id), so a
-        # synthetic-weights run gives a prompt the same embedding whether its image is edited alone or inside a
-        # lock-step batch (the drivers' --random_init pipelines)
+        # word's id is a function of the word ALONE (64 bits of SHA-256 into the id range), so a synthetic-weights run
+        # gives a prompt the same embedding whether its image is edited alone or inside a lock-step batch (the drivers'
+        # --random_init pipelines).  Two different words landing on one id would make an id depend on the order of
+        # first sight again: that is refused loudly instead of being probed around.
         if w not in self._ids:
             if len(self._ids) >= self.bos_token_id - 1:
                 raise RuntimeError("WordTokenizer vocabulary exhausted")
             i = 1 + len(self._ids)
             if self.stable_ids:
-                i = 1 + zlib.crc32(w.encode("utf-8")) % (self.bos_token_id - 1)
-                while i in self._words:
-                    i = 1 + i % (self.bos_token_id - 1)
+                import hashlib
+                i = 1 + int.from_bytes(hashlib.sha256(w.encode("utf-8")).digest()[:8], "big") % (self.bos_token_id - 1)
+                if i in self._words:
+                    raise RuntimeError(f"WordTokenizer(stable_ids): {w!r} and {self._words[i]!r} hash to the same id {i}; "
+                                       "word ids would depend on prompt order -- use a real tokenizer for this vocabulary")
             self._ids[w] = i
             self._words[i] = w
         return self._ids[w]

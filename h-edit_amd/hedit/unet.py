@@ -99,11 +99,14 @@ class UNet2DConditionModel:
             _lib.check(self._lib.hedit_unet_create(C.byref(c), C.byref(h)))
         self._h = h
         self.param_shapes = {}
+        self.bf16_exact = set()       # parameters the executor keeps as unscaled bf16 copies (hedit.dist sends those as bf16)
         nd, dims = C.c_int(), (C.c_int * 4)()
         for i in range(self._lib.hedit_unet_num_params(self._h)):
             name = self._lib.hedit_unet_param_name(self._h, i).decode()
             _lib.check(self._lib.hedit_unet_param_shape(self._h, i, C.byref(nd), dims))
             self.param_shapes[name] = tuple(dims[k] for k in range(nd.value))
+            if self._lib.hedit_unet_param_bf16_exact(self._h, i):
+                self.bf16_exact.add(name)
         self._procs = {n: AttnProcessor() for n in self._processor_names()}
         self._ws = None
         self.heads = cfg["attention_head_dim"]

@@ -116,14 +116,19 @@ class AutoencoderKL:
             pass
 
     # ---------------------------------------------------------------- weights
-    def load_state_dict(self, sd, strict=True):
+    @staticmethod
+    def current_names(sd):
+        """pre-0.18 attention parameter names (query / key / value / proj_attn) -> the current ones"""
         ren = {}
         for k, v in sd.items():
             for old, new in _OLD_ATTN_NAMES.items():
                 if old in k and ".attentions." in k:
                     k = k.replace(old, new)
             ren[k] = v
-        sd = ren
+        return ren
+
+    def load_state_dict(self, sd, strict=True):
+        sd = self.current_names(sd)
         missing = [k for k in self.param_shapes if k not in sd]
         extra = [k for k in sd if k not in self.param_shapes]
         if strict and (missing or extra):

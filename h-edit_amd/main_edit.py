@@ -133,6 +133,7 @@ def main(argv=None):
     rank, world, local_rank = D.env_rank_world()
     device = f"cuda:{local_rank if world > 1 else args.device_num}"
     torch.cuda.set_device(device)
+    D.init_from_env(device)      # several ranks: RCCL group; rank 0 reads the checkpoints and broadcasts them
     full_data = dataset_from_json(args.dataset + "demo.json")
     time_stamp = calendar.timegm(time.gmtime())
     xa_sa_string = f'_xa_{args.xa}_sa{args.sa}_'

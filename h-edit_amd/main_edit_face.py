@@ -79,15 +79,19 @@ def main(argv=None):
     rank, world, local_rank = D.env_rank_world()
     device = f"cuda:{local_rank if world > 1 else args.device_num}"
     torch.cuda.set_device(device)
+    D.init_from_env(device)      # several ranks: RCCL group; rank 0 reads the checkpoints and broadcasts them
     if args.random_init:
         model = Model(TINY_DDPM_CONFIG if args.tiny else None, device=device)
         model.init_random(args.seed)
     elif args.ddpm_ckpt:
         model = Model(device=device)
-        states = torch.load(args.ddpm_ckpt, map_location="cpu")
-        if isinstance(states, list):                     # [model, ..., ema]: DataParallel-prefixed first entry
-            states = {k[7:]: v for k, v in states[0].items()}
-        model.load_state_dict(states)
+
+        def read_ddpm():
+            states = torch.load(args.ddpm_ckpt, map_location="cpu")
+            if isinstance(states, list):                     # [model, ..., ema]: DataParallel-prefixed first entry
+                states = {k[7:]: v for k, v in states[0].items()}
+            return states
+        model.load_state_dict(D.state_dict_from_rank0(read_ddpm, model.param_shapes, device=device))
     else:
         raise SystemExit("give --ddpm_ckpt FILE (local CelebA-HQ DDPM checkpoint) or --random_init")
     S = model.resolution

@@ -170,6 +170,7 @@ def main(argv=None):
     rank, world, local_rank = D.env_rank_world()
     device = f"cuda:{local_rank if world > 1 else args.device_num}"
     torch.cuda.set_device(device)
+    D.init_from_env(device)      # several ranks: RCCL group; rank 0 reads the checkpoints and broadcasts them
     data_path, output_path = args.data_path, args.output_path
     with open(os.path.join(data_path, 'mapping_file.json')) as f:
         full_data = json.load(f)

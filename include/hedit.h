@@ -119,6 +119,9 @@ int hedit_unet_param_shape(const hedit_unet* h, int i, int* ndim, int* dims4);
 /* hand one fp32 parameter tensor (torch layout, device memory) to the library, which packs it
  * into its own bf16/fp32 GEMM layout on `stream` */
 int hedit_unet_load(hedit_unet* h, const char* name, const float* w, size_t numel, void* stream);
+/* 1 if parameter i is kept as an unscaled bf16 copy: a bf16-rounded source gives the same packed bits (the weight
+ * broadcast of the multi-GPU start-up sends those tensors as bf16, the rest as fp32) */
+int hedit_unet_param_bf16_exact(const hedit_unet* h, int i);
 /* 0 when every parameter has been loaded, else the count still missing */
 int hedit_unet_missing(const hedit_unet* h);
 size_t hedit_unet_workspace_bytes(hedit_unet* h, int B, int height, int width);

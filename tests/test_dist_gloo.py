@@ -56,6 +56,56 @@ def test_two_rank_gloo():
     assert n0 == n1 == 11.0
 
 
+def _driver_worker(rank, world, port, q, ckpt_dir):
+    """the product drivers' start-up: only rank 0 may touch the checkpoint, the others receive it (bf16 blob for the
+    tensors named bf16-exact, fp32 blob for the rest)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    rk, w = HD.init_from_env("cpu")
+    try:
+        from hedit import checkpoint as CK
+        shapes = {"m.weight": (6, 5), "m.bias": (6,), "conv.weight": (3, 2, 3, 3), "q.weight": (4, 4), "n.weight": (7,)}
+        reads = []
+
+        def read():
+            if rank != 0:
+                raise AssertionError("a non-zero rank read the checkpoint")
+            reads.append(1)
+            return CK.read_component(ckpt_dir)[1]
+        got = HD.state_dict_from_rank0(read, shapes, device="cpu", bf16_names={"m.weight", "conv.weight"})
+        q.put((rank, {k: (str(v.dtype), v.float().clone(), v.data_ptr() % 16) for k, v in got.items()}, len(reads), (rk, w)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_driver_reads_on_rank0_and_broadcasts(tmp_path):
+    from hedit import checkpoint as CK
+    g = torch.Generator().manual_seed(1)
+    shapes = {"m.weight": (6, 5), "m.bias": (6,), "conv.weight": (3, 2, 3, 3), "q.weight": (4, 4), "n.weight": (7,)}
+    sd = {k: torch.randn(v, generator=g) for k, v in shapes.items()}
+    sd["unused.extra"] = torch.zeros(3)
+    CK.write_component(str(tmp_path), {"x": 1}, sd)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_driver_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, a, reads0, rw0), (_, b, reads1, rw1) = res
+    assert reads0 == 1 and reads1 == 0 and rw0 == (0, 2) and rw1 == (1, 2)
+    assert list(a) == list(shapes) == list(b)
+    for k in shapes:
+        assert a[k][0] == b[k][0] == ("torch.bfloat16" if k in ("m.weight", "conv.weight") else "torch.float32")
+        assert torch.equal(a[k][1], b[k][1])                       # every rank holds the same bits
+        want = sd[k].to(torch.bfloat16).float() if k in ("m.weight", "conv.weight") else sd[k]
+        assert torch.equal(a[k][1], want)                          # bf16 only where it was asked for; fp32 tensors exact
+        assert a[k][2] == 0 and b[k][2] == 0                       # 16-byte aligned views
+
+
 def test_shard_properties():
     for n in (0, 1, 7, 8, 128):
         for world in (1, 2, 3, 8):

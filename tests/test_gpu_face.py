@@ -140,6 +140,7 @@ def test_sde_inversion_and_face_loop_match_oracle():
                        weight_edit_face=w, optimization_steps=K, after_skip_steps=after, num_inference_steps=T)
         G.sync()
         assert got.shape == (1, 3, 32, 32) and torch.isfinite(got).all()
+        print("face loop", skip, K, G.rel_err(got, want))
         assert G.rel_err(got, want) < (6e-2 if after <= 4 else 1.5e-1), (skip, K)
 
 
@@ -157,9 +158,8 @@ def test_unet_batch_grouping_of_the_attention_is_transparent(tiny):
 
 def test_lockstep_faces_equal_single_runs():
     """h_Edit_R(per_image=True) on two faces at once (xT (2,3,S,S), zs (T,2,3,S,S)) == two single-face runs: the batch-mean
-    losses are rescaled so that every face receives its own full gradient.  The eps-network is batch-invariant bit for
-    bit (asserted first); the toy reward networks of this test are torch modules (MIOpen convolutions, batch-mean losses
-    rescaled by the batch size), so the loop results agree to their fp32 rounding, not bitwise."""
+    losses are rescaled so that every face receives its own full gradient.  Bit for bit: the eps-network is
+    batch-invariant (asserted first) and so is everything between its evaluations."""
     from hedit.diffusion import TINY_DDPM_CONFIG
     from hedit.inversion.h_edit_R import h_Edit_R
     hip, _ = make_pair(TINY_DDPM_CONFIG, seed=2, out_scale=0.3)
@@ -178,6 +178,5 @@ def test_lockstep_faces_equal_single_runs():
     for i in range(2):
         one = h_Edit_R(hip, lp, idl, xT[i:i + 1], betas, seq, zs=zs[:, i:i + 1], **kw)
         G.sync()
-        print("lockstep face", i, G.rel_err(both[i:i + 1], one))
-        assert G.rel_err(both[i:i + 1], one) < 2e-3, i
+        assert torch.equal(both[i:i + 1], one), i
     assert G.rel_err(both[0], both[1]) > 1e-1

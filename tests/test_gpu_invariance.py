@@ -221,7 +221,7 @@ def test_sd15_loops_match_oracle(sd15, fn, T, after, K, ddim):
     """loop-level parity at SD-1.5 shape against oracle/loops.py (fp32 CPU) on the same weights and the same inversion
     outputs, two sampler steps each (timesteps 501, 1 / 334, 1 after the skip): Replace + Reweight + LocalBlend for the
     P2P cases.  Tolerance: one bf16 eps evaluation is < 3e-2 off the fp32 oracle (test_gpu_unet.py); two chained steps
-    at full output gain stay within 6e-2 on the edited latent and 2e-2 on the reconstruction."""
+    at full output gain stay within 8e-2 on the edited latent and 2.5e-2 / 4.5e-2 on the reconstruction."""
     from oracle import loops as OL
     from oracle import p2p as OP
     from hedit.inversion import p2p_h_edit as HE
@@ -284,8 +284,9 @@ def test_sd15_loops_match_oracle(sd15, fn, T, after, K, ddim):
     assert hc.cur_step == oc.cur_step
     print("sd15 loop", fn, T, after, K, ddim, "recon", G.rel_err(r_h, r_o), "edit", G.rel_err(e_h, e_o))
     assert torch.isfinite(e_h).all()
-    assert G.rel_err(r_h, r_o) < (2e-2 if p2p and not ddim else 6e-2), G.rel_err(r_h, r_o)
-    assert G.rel_err(e_h, e_o) < 6e-2, G.rel_err(e_h, e_o)
+    # measured on MI355X: edited 4.9e-2 / 5.8e-2 (K = 3) / 5.0e-2 (skip) / 5.1e-2 (h-Edit-D); reconstruction 1.5e-2, 2.7e-2 (no P2P)
+    assert G.rel_err(r_h, r_o) < (2.5e-2 if p2p else 4.5e-2), G.rel_err(r_h, r_o)
+    assert G.rel_err(e_h, e_o) < 8e-2, G.rel_err(e_h, e_o)
 
 
 def test_reusing_the_source_rows_of_the_p2p_pass_is_bit_identical(tiny):

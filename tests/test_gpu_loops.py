@@ -104,6 +104,7 @@ def test_loops_match_oracle(setup, fn, pi, skip, K, ddim, p2p):
     assert e_h.shape == (1, 4, 32, 32) and r_h.shape == (1, 4, 32, 32)
     assert torch.isfinite(e_h).all()
     tol_edit, tol_recon = tol(after)
+    print("loop", fn, pi, skip, K, ddim, p2p, "edit", G.rel_err(e_h, e_o), "recon", G.rel_err(r_h, r_o))
     assert G.rel_err(r_h, r_o) < (tol_recon if p2p and not ddim else tol_edit)
     assert G.rel_err(e_h, e_o) < tol_edit
     assert hc.cur_step == oc.cur_step

@@ -106,6 +106,7 @@ def test_style_loop_matches_oracle(setup, pi, skip, K, weight, with_enc):
     G.sync()
     assert e_h.shape == (1, 4, 32, 32) and torch.isfinite(e_h).all()
     tol_edit, tol_recon = (8e-2 if K == 1 else 2.5e-1, 1e-2) if after <= 4 else (1.8e-1, 5e-2)
+    print("style loop", pi, skip, K, with_enc, "edit", G.rel_err(e_h, e_o), "recon", G.rel_err(r_h, r_o))
     assert G.rel_err(r_h, r_o) < tol_recon
     assert G.rel_err(e_h, e_o) < tol_edit
     assert hc.cur_step == oc.cur_step
