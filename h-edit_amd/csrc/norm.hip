@@ -139,10 +139,38 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 // stage 3, row form: a thread keeps ONE group of 8 channels (its 8 scale / shift pairs in registers) and walks the pixels
 // of its slab, so an iteration is one 16-byte load and one 16-byte store; the form above re-reads 64 bytes of the
 // coefficient table per 16 bytes of data.  Same arithmetic per element.
+// The statistics' second stage is folded into this kernel's prologue (no gn_finalize launch on this path): every block
+// folds the slab partials of its image into mean / rstd per group -- the same lanes, the same order and the same formulas
+// as gn_finalize_kernel, hence the same bits -- and each thread derives the scale / shift pairs of its 8 channels.
 __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
-                                                            const float* __restrict__ ss, int HW, int C, int silu, int nslab) {
+                                                            const float* __restrict__ part, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int HW, int C, int G, int nstat, float eps,
+                                                            int silu, int nslab) {
+  __shared__ float mean[64], rstd[64];
   const int CV = C / 8;
   const int slab = blockIdx.x, b = blockIdx.y;
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int g = wave; g < G; g += 4) {
+      float s = 0.f, q = 0.f;
+      for (int sl = lane; sl < nstat; sl += 64) {
+        const float2 v = *reinterpret_cast<const float2*>(part + (((long)b * nstat + sl) * G + g) * 2);
+        s += v.x;
+        q += v.y;
+      }
+      s = wave_sum(s);
+      q = wave_sum(q);
+      if (lane == 0) {
+        const float n = (float)HW * (float)(C / G);
+        const float m = s / n;
+        float var = q / n - m * m;
+        var = var < 0.f ? 0.f : var;
+        mean[g] = m;
+        rstd[g] = rsqrtf(var + eps);
+      }
+    }
+    __syncthreads();
+  }
   const int pix_per = (HW + nslab - 1) / nslab;
   const int p0 = slab * pix_per;
   int p1 = p0 + pix_per;
@@ -151,8 +179,18 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const bf16_t* __rest
   const int r = threadIdx.x / CV;
   const int cv = threadIdx.x - r * CV;
   if (r >= R) return;
-  const float4* t = reinterpret_cast<const float4*>(ss + ((long)b * C + cv * 8) * 2);
-  const float4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+  float sc[8], sh[8];
+  {
+    const int cpg = C / G;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cv * 8 + j, g = c / cpg;
+      sc[j] = rstd[g] * gamma[c];
+      sh[j] = beta[c] - mean[g] * sc[j];
+    }
+  }
+  const float4 t0 = {sc[0], sh[0], sc[1], sh[1]}, t1 = {sc[2], sh[2], sc[3], sh[3]};
+  const float4 t2 = {sc[4], sh[4], sc[5], sh[5]}, t3 = {sc[6], sh[6], sc[7], sh[7]};
   const bf16_t* xb = x + (long)b * HW * C + cv * 8;
   bf16_t* yb = y + (long)b * HW * C + cv * 8;
   for (int p = p0 + r; p < p1; p += R) {
@@ -535,15 +573,18 @@ int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, B), dim3(256), lds, st, x, part, HW, C, G, nslab);
   LAUNCH_CHECK();
   // partial buffer is indexed with stride G (<=64 reserved)
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, gamma, beta, ss, HW, C, G, nslab, eps, stats);
-  LAUNCH_CHECK();
   const long total_v = (long)B * HW * CV;
-  if (CV <= 256 && HW >= 1024) {      // (smaller images: too few pixels per thread row to pay for the set-up)
+  const bool rows_form = CV <= 256 && HW >= 1024;      // (smaller images: too few pixels per thread row to pay for the set-up)
+  if (!rows_form || stats) {       // the row-form apply folds the slabs itself; the backward pass wants (mean, rstd) written out
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, gamma, beta, ss, HW, C, G, nslab, eps, stats);
+    LAUNCH_CHECK();
+  }
+  if (rows_form) {
     // enough slabs for >= ~4096 workgroups over the batch, at least 8 pixels per thread row
     int ns = (int)(4096 / (B > 0 ? B : 1)) + 1;
     const int max_ns = HW / (R * 8) > 0 ? HW / (R * 8) : 1;
     if (ns > max_ns) ns = max_ns;
-    hipLaunchKernelGGL(gn_apply_rows_kernel, dim3(ns, B), dim3(256), 0, st, x, y, ss, HW, C, silu, ns);
+    hipLaunchKernelGGL(gn_apply_rows_kernel, dim3(ns, B), dim3(256), 0, st, x, y, part, gamma, beta, HW, C, G, nslab, eps, silu, ns);
     LAUNCH_CHECK();
     return HEDIT_OK;
   }

@@ -140,8 +140,8 @@ def test_sde_inversion_and_face_loop_match_oracle():
                        weight_edit_face=w, optimization_steps=K, after_skip_steps=after, num_inference_steps=T)
         G.sync()
         assert got.shape == (1, 3, 32, 32) and torch.isfinite(got).all()
-        print("face loop", skip, K, G.rel_err(got, want))
-        assert G.rel_err(got, want) < (6e-2 if after <= 4 else 1.5e-1), (skip, K)
+        # measured 3.6e-3 (4 steps, K = 1 / 2) and 3.1e-2 (8 steps): limits = 2x
+        assert G.rel_err(got, want) < (8e-3 if after <= 4 else 6.5e-2), (skip, K)
 
 
 def test_unet_batch_grouping_of_the_attention_is_transparent(tiny):

@@ -16,9 +16,10 @@ T = 8
 # with this synthetic network (tests/diag/diag_loops.py, output scale 0.3): one eps evaluation 1.4e-2;
 # 1-step chain 5e-4 (K=1) / 9e-3 (K=2); 4-step chain 2.1e-2 / 3.2e-2 edited, 3e-3 recon;
 # 8-step chain 7e-2 edited, 1.9e-2 recon.  Error grows with chain length because every step
-# re-injects the bf16 rounding of the eps evaluations; limits below are ~2.5x the measurements.
+# re-injects the bf16 rounding of the eps evaluations.  Round 3, the eight cases below: 4 / 5-step chains 1.9e-3 ...
+# 3.5e-2 edited, 1.6e-4 ... 7.2e-3 recon; the 8-step chain 4.7e-2 edited, 2.1e-2 recon.  Limits = 2x the largest.
 def tol(after):
-    return (8e-2, 1e-2) if after <= 4 else (1.8e-1, 5e-2)
+    return (7e-2, 1.5e-2) if after <= 5 else (1e-1, 4.2e-2)
 
 
 @pytest.fixture(scope="module")
@@ -104,7 +105,6 @@ def test_loops_match_oracle(setup, fn, pi, skip, K, ddim, p2p):
     assert e_h.shape == (1, 4, 32, 32) and r_h.shape == (1, 4, 32, 32)
     assert torch.isfinite(e_h).all()
     tol_edit, tol_recon = tol(after)
-    print("loop", fn, pi, skip, K, ddim, p2p, "edit", G.rel_err(e_h, e_o), "recon", G.rel_err(r_h, r_o))
     assert G.rel_err(r_h, r_o) < (tol_recon if p2p and not ddim else tol_edit)
     assert G.rel_err(e_h, e_o) < tol_edit
     assert hc.cur_step == oc.cur_step

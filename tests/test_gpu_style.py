@@ -105,8 +105,9 @@ def test_style_loop_matches_oracle(setup, pi, skip, K, weight, with_enc):
                                       controller=hc, prog_bar=False, **kw)
     G.sync()
     assert e_h.shape == (1, 4, 32, 32) and torch.isfinite(e_h).all()
-    tol_edit, tol_recon = (8e-2 if K == 1 else 2.5e-1, 1e-2) if after <= 4 else (1.8e-1, 5e-2)
-    print("style loop", pi, skip, K, with_enc, "edit", G.rel_err(e_h, e_o), "recon", G.rel_err(r_h, r_o))
+    # round 3 (deterministic resize, batch-invariant decoder): 4 steps K=1 3.6e-2 (text only 2.2e-2), K=2 6.0e-2, 8 steps
+    # 6.0e-2; recon 3.0e-3 / 2.1e-2.  Limits = 2x.
+    tol_edit, tol_recon = (7.5e-2 if K == 1 else 1.2e-1, 6.5e-3) if after <= 4 else (1.2e-1, 4.2e-2)
     assert G.rel_err(r_h, r_o) < tol_recon
     assert G.rel_err(e_h, e_o) < tol_edit
     assert hc.cur_step == oc.cur_step
