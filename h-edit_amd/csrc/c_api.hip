@@ -146,14 +146,18 @@ int hedit_k_gemm_geglu(const void* A, const void* w_packed, const float* bias_pa
 } catch (...) { return hedit_abi_catch(); }
 
 int hedit_k_ffn_channels(void) { return ffn_fused_channels(); }
-size_t hedit_k_ffn_stream_bytes(void) { return ffn_stream_bytes(); }
+size_t hedit_k_ffn_stream_bytes(int with_outer_layers) { return ffn_stream_bytes(with_outer_layers, with_outer_layers); }
 size_t hedit_k_ffn_bias_bytes(void) { return ffn_bias_bytes(); }
 
-int hedit_k_ffn_pack(const float* w1, const float* b1, const float* w2, void* stream_out, float* bias1_out, void* stream) try {
-  ARG_CHECK(w1 && b1 && w2 && stream_out && bias1_out, "ffn_pack args");
-  int rc = ffn_pack_launch(w1, nullptr, reinterpret_cast<bf16_t*>(stream_out), S(stream));
-  if (rc != HEDIT_OK) return rc;
-  rc = ffn_pack_launch(nullptr, w2, reinterpret_cast<bf16_t*>(stream_out), S(stream));
+int hedit_k_ffn_pack(const float* w1, const float* b1, const float* w2, const float* w_pre, const float* w_post, void* stream_out,
+                     float* bias1_out, void* stream) try {
+  ARG_CHECK(w1 && b1 && w2 && stream_out && bias1_out && ((w_pre == nullptr) == (w_post == nullptr)), "ffn_pack args");
+  const int outer = w_pre != nullptr;
+  bf16_t* so = reinterpret_cast<bf16_t*>(stream_out);
+  int rc = ffn_pack_launch(w1, 1, outer, outer, so, S(stream));
+  if (rc == HEDIT_OK) rc = ffn_pack_launch(w2, 2, outer, outer, so, S(stream));
+  if (rc == HEDIT_OK && outer) rc = ffn_pack_launch(w_pre, 0, 1, 1, so, S(stream));
+  if (rc == HEDIT_OK && outer) rc = ffn_pack_launch(w_post, 3, 1, 1, so, S(stream));
   if (rc != HEDIT_OK) return rc;
   return ffn_pack_bias_launch(b1, bias1_out, S(stream));
 } catch (...) { return hedit_abi_catch(); }
@@ -162,6 +166,21 @@ int hedit_k_ffn_fused(const void* x, int64_t ldx, const float* gamma, const floa
                       const float* bias1_packed, const float* bias2, void* out, int64_t ldo, int M, int C, void* stream) try {
   FfnParams f{};
   f.x = reinterpret_cast<const bf16_t*>(x); f.ldx = (long)ldx; f.gamma = gamma; f.beta = beta; f.eps = eps;
+  f.stream = reinterpret_cast<const bf16_t*>(w_stream); f.bias1p = bias1_packed; f.bias2 = bias2;
+  f.out = reinterpret_cast<bf16_t*>(out); f.ldo = (long)ldo; f.M = M; f.C = C;
+  return ffn_fused_launch(f, S(stream));
+} catch (...) { return hedit_abi_catch(); }
+
+int hedit_k_ffn_chain(const void* a, int64_t lda, const void* t1, int64_t ldt1, const void* x, int64_t ldx, const float* bias_pre,
+                      const float* gamma, const float* beta, float eps, const void* w_stream, const float* bias1_packed, const float* bias2,
+                      const float* bias_post, void* out, int64_t ldo, int M, int C, void* stream) try {
+  ARG_CHECK(a && t1 && x, "ffn_chain args");
+  FfnParams f{};
+  f.a = reinterpret_cast<const bf16_t*>(a); f.lda = (long)lda;
+  f.x = reinterpret_cast<const bf16_t*>(t1); f.ldx = (long)ldt1;
+  f.r2 = reinterpret_cast<const bf16_t*>(x); f.ldr2 = (long)ldx;
+  f.bias_pre = bias_pre; f.bias_post = bias_post;
+  f.gamma = gamma; f.beta = beta; f.eps = eps;
   f.stream = reinterpret_cast<const bf16_t*>(w_stream); f.bias1p = bias1_packed; f.bias2 = bias2;
   f.out = reinterpret_cast<bf16_t*>(out); f.ldo = (long)ldo; f.M = M; f.C = C;
   return ffn_fused_launch(f, S(stream));

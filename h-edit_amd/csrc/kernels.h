@@ -36,22 +36,29 @@ size_t gemm_partial_bytes(int M, int N, int splits);
 int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st);
 
 // ---------------------------------------------------------------- ffn.hip
-// out = x + FF2(GEGLU(FF1(LayerNorm(x)))) in one kernel (C = ffn_fused_channels() only): the weights come as a
-// pre-packed stream (ffn_pack_launch: call once with w1 = ff.net.0.proj.weight [8C][C], once with w2 = ff.net.2.weight
-// [C][4C], either order) and the FF1 bias in packed order (ffn_pack_bias_launch)
+// The token-local tail of a transformer block in one kernel (C = ffn_fused_channels() only):
+//     t2 = a W_pre^T + bias_pre + x          (only if a != nullptr: attn2.to_out + residual)
+//     t3 = t2 + FF2(GEGLU(FF1(LayerNorm(t2))))          (t2 = x without the leading layer)
+//     out = t3 W_post^T + bias_post + r2     (only with the leading layer: proj_out + residual)
+// The weights come as a pre-packed stream (ffn_pack_launch, one call per layer: which = 0 leading linear [C][C],
+// 1 ff.net.0.proj.weight [8C][C] -- call it first or alone, it also zeroes the padding --, 2 ff.net.2.weight [C][4C],
+// 3 trailing linear [C][C]) and the FF1 bias in packed order (ffn_pack_bias_launch).
 struct FfnParams {
-  const bf16_t* x; long ldx;     // [M][ldx]: LayerNorm input AND residual
+  const bf16_t* x; long ldx;     // [M][ldx]: residual of the leading layer, or LayerNorm input AND residual without it
   const float* gamma; const float* beta; float eps;
-  const bf16_t* stream;          // ffn_stream_bytes()
+  const bf16_t* stream;          // ffn_stream_bytes(pre, post)
   const float* bias1p;           // ffn_bias_bytes()
   const float* bias2;            // [C]
   bf16_t* out; long ldo;
   int M, C;
+  const bf16_t* a; long lda;     // leading layer input [M][lda] or nullptr
+  const bf16_t* r2; long ldr2;   // residual of the trailing layer [M][ldr2] (with the leading layer only)
+  const float* bias_pre; const float* bias_post;
 };
 int ffn_fused_channels();
-size_t ffn_stream_bytes();
+size_t ffn_stream_bytes(int pre, int post);
 size_t ffn_bias_bytes();
-int ffn_pack_launch(const float* w1, const float* w2, bf16_t* stream, hipStream_t st);
+int ffn_pack_launch(const float* w, int which, int pre, int post, bf16_t* stream, hipStream_t st);
 int ffn_pack_bias_launch(const float* b1, float* out, hipStream_t st);
 int ffn_fused_launch(const FfnParams& f, hipStream_t st);
 

@@ -26,7 +26,8 @@ struct Slot {
   std::string name;
   int kind;        // 0 fp32 copy, 1 linear -> bf16 (scaled), 2 conv3x3 OIHW -> bf16 [O][9][I],
                    // 3 / 4: FF1 weight / bias with GEGLU (value16|gate16) row interleave,
-                   // 5 / 6 / 7: FF1 weight / FF1 bias / FF2 weight of the one-kernel feed-forward (ffn.hip)
+                   // 5 / 6 / 7 / 8 / 9: FF1 weight / FF1 bias / FF2 weight / attn2.to_out weight / proj_out weight of the
+                   // one-kernel block tail (ffn.hip)
   void* dst;
   size_t numel;
   int O, I;
@@ -167,14 +168,22 @@ Attn make_attn(hedit_unet* h, const std::string& pre, int C) {
   a.w_q2 = linp(h, tb + ".attn2.to_q.weight", C, C, nullptr, qscale);
   a.w_k2 = linp(h, tb + ".attn2.to_k.weight", C, ctx);
   a.w_v2 = linp(h, tb + ".attn2.to_v.weight", C, ctx);
-  a.w_o2 = linp(h, tb + ".attn2.to_out.0.weight", C, C);
+  const bool chain = C == ffn_fused_channels();
+  if (chain) {
+    // the token-local tail of the block (attn2.to_out + residual, norm3, feed-forward, proj_out + residual) runs as one
+    // kernel (ffn.hip): the four weights go into its stream (slot kinds 5 / 7 / 8 / 9), the FF1 bias into its packed
+    // form (kind 6); none of them is kept as a GEMM operand
+    a.ffs = dalloc<bf16_t>(h, ffn_stream_bytes(1, 1) / sizeof(bf16_t));
+    a.ff1_bp = dalloc<float>(h, ffn_bias_bytes() / sizeof(float));
+    add_slot(h, tb + ".attn2.to_out.0.weight", 8, a.ffs, (size_t)C * C, C, C);
+    h->slots.back().ndim = 2; h->slots.back().dims[0] = C; h->slots.back().dims[1] = C;
+  } else {
+    a.w_o2 = linp(h, tb + ".attn2.to_out.0.weight", C, C);
+  }
   a.o2_b = f32p(h, tb + ".attn2.to_out.0.bias", C);
   a.ln3g = f32p(h, tb + ".norm3.weight", C);
   a.ln3b = f32p(h, tb + ".norm3.bias", C);
-  if (C == ffn_fused_channels()) {
-    // one-kernel feed-forward: both weights go into the stream, the FF1 bias into its packed form (kinds 5 / 6 / 7)
-    a.ffs = dalloc<bf16_t>(h, ffn_stream_bytes() / sizeof(bf16_t));
-    a.ff1_bp = dalloc<float>(h, ffn_bias_bytes() / sizeof(float));
+  if (chain) {
     add_slot(h, tb + ".ff.net.0.proj.weight", 5, a.ffs, (size_t)8 * C * C, 8 * C, C);
     h->slots.back().ndim = 2; h->slots.back().dims[0] = 8 * C; h->slots.back().dims[1] = C;
     add_slot(h, tb + ".ff.net.0.proj.bias", 6, a.ff1_bp, (size_t)8 * C);
@@ -188,7 +197,12 @@ Attn make_attn(hedit_unet* h, const std::string& pre, int C) {
     a.ff2 = linp(h, tb + ".ff.net.2.weight", C, 4 * C);
   }
   a.ff2_b = f32p(h, tb + ".ff.net.2.bias", C);
-  a.pout = linp(h, pre + ".proj_out.weight", C, C);
+  if (chain) {
+    add_slot(h, pre + ".proj_out.weight", 9, a.ffs, (size_t)C * C, C, C);
+    h->slots.back().ndim = 4; h->slots.back().dims[0] = C; h->slots.back().dims[1] = C; h->slots.back().dims[2] = 1; h->slots.back().dims[3] = 1;
+  } else {
+    a.pout = linp(h, pre + ".proj_out.weight", C, C);
+  }
   a.pout_b = f32p(h, pre + ".proj_out.bias", C);
   return a;
 }
@@ -420,28 +434,38 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   f.ar.free(q2);
   f.ar.free(k2);
   f.ar.free(vt2);
+  if (a.ffs) {
+    // attn2.to_out + residual -> LayerNorm -> FF1 -> GEGLU -> FF2 + residual -> proj_out + residual in ONE kernel: rows in
+    // registers, weights streamed (ffn.hip).  The result goes where proj_out's would (dst / ldd: the next concatenation).
+    if (dst) {
+      y = dst;
+    } else {
+      TRY(aalloc(f, &y, M * C));
+    }
+    FfnParams fp{};
+    fp.a = ao; fp.lda = C; fp.x = t1; fp.ldx = C; fp.r2 = x; fp.ldr2 = C;
+    fp.bias_pre = a.o2_b; fp.bias_post = a.pout_b;
+    fp.gamma = a.ln3g; fp.beta = a.ln3b; fp.eps = 1e-5f;
+    fp.stream = a.ffs; fp.bias1p = a.ff1_bp; fp.bias2 = a.ff2_b; fp.out = y; fp.ldo = dst ? ldd : C; fp.M = (int)M; fp.C = C;
+    {
+      ProfScope ps(f, PK_LINEAR, 2.0 * M * 14.0 * C * C, 8.0 * M * C + 28.0 * C * C);      // a, t1, x read, out written; weights once
+      if (ps.rec >= 0) {
+        auto& r = f.h->prof_recs[ps.rec];
+        r.m = (int)M; r.n = C; r.k = 14 * C; r.tag = 128;     // tag 128: the fused block tail
+      }
+      RUN(f, ffn_fused_launch(fp, f.st));
+    }
+    f.ar.free(ao);
+    f.ar.free(t1);
+    *out = y;
+    return HEDIT_OK;
+  }
   TRY(aalloc(f, &t2, M * C));
   TRY(linear(f, ao, (int)M, C, a.w_o2, C, a.o2_b, t1, t2, C));
   f.ar.free(ao);
   f.ar.free(t1);
 
   // ---- GEGLU feed-forward
-  if (a.ffs) {
-    // LayerNorm -> FF1 -> GEGLU -> FF2 -> + residual in one kernel: rows in registers, weights streamed (ffn.hip)
-    TRY(aalloc(f, &t3, M * C));
-    FfnParams fp{};
-    fp.x = t2; fp.ldx = C; fp.gamma = a.ln3g; fp.beta = a.ln3b; fp.eps = 1e-5f;
-    fp.stream = a.ffs; fp.bias1p = a.ff1_bp; fp.bias2 = a.ff2_b; fp.out = t3; fp.ldo = C; fp.M = (int)M; fp.C = C;
-    {
-      ProfScope ps(f, PK_LINEAR, 2.0 * M * 12.0 * C * C, 4.0 * M * C + 24.0 * C * C);
-      if (ps.rec >= 0) {
-        auto& r = f.h->prof_recs[ps.rec];
-        r.m = (int)M; r.n = C; r.k = 12 * C; r.tag = 128;     // tag 128: fused feed-forward
-      }
-      RUN(f, ffn_fused_launch(fp, f.st));
-    }
-    f.ar.free(t2);
-  } else {
   TRY(aalloc(f, &tn, M * C));
   { ProfScope ps(f, PK_NORM, 0.0, 4.0 * M * C); RUN(f, layernorm_launch(t2, tn, a.ln3g, a.ln3b, (long)M, C, 1e-5f, f.st)); }
   TRY(aalloc(f, &gf, M * 4 * C));
@@ -457,7 +481,6 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   TRY(linear(f, gf, (int)M, 4 * C, a.ff2, C, a.ff2_b, t2, t3, C));
   f.ar.free(gf);
   f.ar.free(t2);
-  }
 
   if (dst) {
     y = dst;
@@ -784,7 +807,7 @@ int hedit_unet_param_shape(const hedit_unet* h, int i, int* ndim, int* dims4) tr
 int hedit_unet_param_bf16_exact(const hedit_unet* h, int i) try {
   if (!h || i < 0 || i >= (int)h->slots.size()) return 0;
   const Slot& s = h->slots[i];
-  return ((s.kind == 1 && s.scale == 1.f) || s.kind == 2 || s.kind == 3 || s.kind == 5 || s.kind == 7) ? 1 : 0;
+  return ((s.kind == 1 && s.scale == 1.f) || s.kind == 2 || s.kind == 3 || s.kind == 5 || s.kind >= 7) ? 1 : 0;
 } catch (...) { (void)hedit_abi_catch(); return 0; }
 
 int hedit_unet_load(hedit_unet* h, const char* name, const float* w, size_t numel, void* stream) try {
@@ -809,11 +832,15 @@ int hedit_unet_load(hedit_unet* h, const char* name, const float* w, size_t nume
   } else if (s.kind == 4) {
     TRY(pack_geglu_rows_launch(w, nullptr, reinterpret_cast<float*>(s.dst), (int)numel, 1, st));
   } else if (s.kind == 5) {
-    TRY(ffn_pack_launch(w, nullptr, reinterpret_cast<bf16_t*>(s.dst), st));
+    TRY(ffn_pack_launch(w, 1, 1, 1, reinterpret_cast<bf16_t*>(s.dst), st));
   } else if (s.kind == 6) {
     TRY(ffn_pack_bias_launch(w, reinterpret_cast<float*>(s.dst), st));
   } else if (s.kind == 7) {
-    TRY(ffn_pack_launch(nullptr, w, reinterpret_cast<bf16_t*>(s.dst), st));
+    TRY(ffn_pack_launch(w, 2, 1, 1, reinterpret_cast<bf16_t*>(s.dst), st));
+  } else if (s.kind == 8) {
+    TRY(ffn_pack_launch(w, 0, 1, 1, reinterpret_cast<bf16_t*>(s.dst), st));
+  } else if (s.kind == 9) {
+    TRY(ffn_pack_launch(w, 3, 1, 1, reinterpret_cast<bf16_t*>(s.dst), st));
   } else {
     TRY(pack_conv3x3_launch(w, reinterpret_cast<bf16_t*>(s.dst), s.O, s.I, st));
   }

@@ -266,18 +266,27 @@ int hedit_k_pack_geglu(const float* w, const float* bias, void* w_packed_bf16, f
                        int inner, int K, void* stream);
 int hedit_k_gemm_geglu(const void* A, const void* w_packed, const float* bias_packed, void* C, int M,
                        int inner, int K, int lda, int ldc, void* stream);
-/* The whole GEGLU feed-forward of a BasicTransformerBlock in one launch (csrc/ffn.hip; replaces diffusers'
- * `hidden_states = self.ff(self.norm3(hidden_states)) + hidden_states`, oracle/sd_unet.py transformer block):
- * out[M][C] = x + ff.net.2( GEGLU( ff.net.0.proj( LayerNorm(x) ) ) ), x / out bf16 with row strides ldx / ldo
- * (multiples of 8).  Exists for C == hedit_k_ffn_channels() (320).  hedit_k_ffn_pack turns the checkpoint tensors
- * w1 = ff.net.0.proj.weight [8C][C], b1 = ff.net.0.proj.bias [8C], w2 = ff.net.2.weight [C][4C] (fp32, device) into the
- * weight stream (hedit_k_ffn_stream_bytes) and the packed FF1 bias (hedit_k_ffn_bias_bytes). */
+/* The token-local tail of a BasicTransformerBlock in one launch (csrc/ffn.hip), for C == hedit_k_ffn_channels() (320).
+ * hedit_k_ffn_fused: out[M][C] = x + ff.net.2( GEGLU( ff.net.0.proj( LayerNorm(x) ) ) )  -- replaces diffusers'
+ *   `hidden_states = self.ff(self.norm3(hidden_states)) + hidden_states` (oracle/sd_unet.py transformer block).
+ * hedit_k_ffn_chain: the same with the linear layers either side of it,
+ *   t2 = attn2.to_out.0(a) + t1;  t3 = t2 + ff(norm3(t2));  out = proj_out(t3) + x
+ *   (oracle/sd_unet.py: the cross-attention output projection + residual in front, Transformer2DModel.proj_out +
+ *   residual behind), x / t1 / a / out bf16 with row strides that are multiples of 8.
+ * hedit_k_ffn_pack turns the checkpoint tensors w1 = ff.net.0.proj.weight [8C][C], b1 = ff.net.0.proj.bias [8C],
+ * w2 = ff.net.2.weight [C][4C] (and w_pre = attn2.to_out.0.weight [C][C], w_post = proj_out.weight [C][C], both or
+ * neither; fp32, device) into the weight stream (hedit_k_ffn_stream_bytes(with_outer_layers)) and the packed FF1 bias
+ * (hedit_k_ffn_bias_bytes). */
 int hedit_k_ffn_channels(void);
-size_t hedit_k_ffn_stream_bytes(void);
+size_t hedit_k_ffn_stream_bytes(int with_outer_layers);
 size_t hedit_k_ffn_bias_bytes(void);
-int hedit_k_ffn_pack(const float* w1, const float* b1, const float* w2, void* stream_out, float* bias1_out, void* stream);
+int hedit_k_ffn_pack(const float* w1, const float* b1, const float* w2, const float* w_pre, const float* w_post, void* stream_out,
+                     float* bias1_out, void* stream);
 int hedit_k_ffn_fused(const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* w_stream,
                       const float* bias1_packed, const float* bias2, void* out, int64_t ldo, int M, int C, void* stream);
+int hedit_k_ffn_chain(const void* a, int64_t lda, const void* t1, int64_t ldt1, const void* x, int64_t ldx, const float* bias_pre,
+                      const float* gamma, const float* beta, float eps, const void* w_stream, const float* bias1_packed,
+                      const float* bias2, const float* bias_post, void* out, int64_t ldo, int M, int C, void* stream);
 size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C);
 int hedit_k_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW,
                       int C, int G, float eps, int silu, void* ws, void* stream);

@@ -184,9 +184,9 @@ def _ffn_setup(lib, M, seed):
     b1 = G.f32(torch.randn(8 * Cc, generator=g) * 0.5)
     w2 = G.f32(torch.randn(Cc, 4 * Cc, generator=g) / math.sqrt(4 * Cc))
     b2 = G.f32(torch.randn(Cc, generator=g) * 0.5)
-    ws = torch.empty(lib.hedit_k_ffn_stream_bytes(), dtype=torch.uint8, device=G.dev())
+    ws = torch.empty(lib.hedit_k_ffn_stream_bytes(0), dtype=torch.uint8, device=G.dev())
     bp = torch.empty(lib.hedit_k_ffn_bias_bytes(), dtype=torch.uint8, device=G.dev())
-    _lib.check(lib.hedit_k_ffn_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(ws), _lib.ptr(bp), None))
+    _lib.check(lib.hedit_k_ffn_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), None, None, _lib.ptr(ws), _lib.ptr(bp), None))
     return Cc, x, gamma, beta, w1, b1, w2, b2, ws, bp
 
 
@@ -240,6 +240,68 @@ def test_ffn_fused_rows_are_independent_and_repeatable(lib):
     assert torch.equal(full[4096 + 77:4096 + 77 + 300], part)
     one = _ffn_run(lib, x[-1:].contiguous(), gamma, beta, ws, bp, b2, Cc)
     assert torch.equal(full[-1:], one)
+
+
+@pytest.mark.parametrize("M", [128, 4096 + 77, 3 * 4096])
+def test_ffn_chain(lib, M):
+    """The token-local tail of a transformer block in one kernel (csrc/ffn.hip): attn2.to_out + residual -> norm3 ->
+    GEGLU feed-forward + residual -> proj_out + residual == the same five layers in fp32 on the bf16-rounded operands
+    (diffusers BasicTransformerBlock / Transformer2DModel order, oracle/sd_unet.py) and == the chain of single kernels
+    of this library (GEMM + residual, fused feed-forward, GEMM + residual); rows are independent bit for bit."""
+    Cc, _, gamma, beta, w1, b1, w2, b2, _, _ = _ffn_setup(lib, 8, 23)
+    g = torch.Generator().manual_seed(5 + M)
+    a = G.bf(torch.randn(M, Cc, generator=g))
+    t1 = G.bf(torch.randn(M, Cc, generator=g) * 1.5 + 0.2)
+    ld_x = Cc + 64                                                  # the block input may sit in a wider buffer
+    xw = G.bf(torch.randn(M, ld_x, generator=g))
+    x = xw[:, :Cc]
+    wo = G.f32(torch.randn(Cc, Cc, generator=g) / math.sqrt(Cc))
+    bo = G.f32(torch.randn(Cc, generator=g) * 0.3)
+    wp = G.f32(torch.randn(Cc, Cc, generator=g) / math.sqrt(Cc))
+    bpo = G.f32(torch.randn(Cc, generator=g) * 0.3)
+    ws = torch.empty(lib.hedit_k_ffn_stream_bytes(1), dtype=torch.uint8, device=G.dev())
+    bp = torch.empty(lib.hedit_k_ffn_bias_bytes(), dtype=torch.uint8, device=G.dev())
+    _lib.check(lib.hedit_k_ffn_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(wo), _lib.ptr(wp), _lib.ptr(ws), _lib.ptr(bp), None))
+    ld_o = Cc + 320                                                 # ... and the result goes into a concatenation buffer
+    outw = torch.zeros(M, ld_o, dtype=torch.bfloat16, device=G.dev())
+
+    def run(a_, t1_, xw_, outw_):
+        _lib.check(lib.hedit_k_ffn_chain(_lib.ptr(a_), Cc, _lib.ptr(t1_), Cc, _lib.ptr(xw_), ld_x, _lib.ptr(bo), _lib.ptr(gamma), _lib.ptr(beta),
+                                         1e-5, _lib.ptr(ws), _lib.ptr(bp), _lib.ptr(b2), _lib.ptr(bpo), _lib.ptr(outw_), ld_o, a_.shape[0], Cc, None))
+        G.sync()
+    run(a, t1, xw, outw)
+    out = outw[:, :Cc]
+    assert float(outw[:, Cc:].abs().max()) == 0.0
+    bfr = lambda t: t.to(torch.bfloat16).float()
+    t2 = a.float() @ bfr(wo).t() + bo + t1.float()
+    xn = bfr(F.layer_norm(t2, (Cc,), gamma, beta, 1e-5))
+    proj = xn @ bfr(w1).t() + b1
+    h, gate = proj.chunk(2, dim=-1)
+    t3 = t2 + bfr(h * F.gelu(gate)) @ bfr(w2).t() + b2
+    want = bfr(t3) @ bfr(wp).t() + bpo + x.float()
+    assert torch.isfinite(out.float()).all()
+    assert G.rel_err(out.float(), want) < 6e-3
+    # the chain of single kernels (t2 and t3 rounded to bf16 in between, as they were in HBM)
+    t2_k = torch.empty(M, Cc, dtype=torch.bfloat16, device=G.dev())
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(a), _lib.ptr(wo.to(torch.bfloat16).contiguous()), _lib.ptr(bo), _lib.ptr(t1), _lib.ptr(t2_k), M, Cc, Cc,
+                                Cc, Cc, Cc, 0, 0, 0, 0, 0, 0, 1, None, None))
+    ws0 = torch.empty(lib.hedit_k_ffn_stream_bytes(0), dtype=torch.uint8, device=G.dev())
+    _lib.check(lib.hedit_k_ffn_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), None, None, _lib.ptr(ws0), _lib.ptr(bp), None))
+    t3_k = _ffn_run(lib, t2_k, gamma, beta, ws0, bp, b2, Cc)
+    out_k = torch.empty(M, Cc, dtype=torch.bfloat16, device=G.dev())
+    xc = x.contiguous()
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(t3_k), _lib.ptr(wp.to(torch.bfloat16).contiguous()), _lib.ptr(bpo), _lib.ptr(xc), _lib.ptr(out_k), M, Cc, Cc,
+                                Cc, Cc, Cc, 0, 0, 0, 0, 0, 0, 1, None, None))
+    G.sync()
+    assert G.rel_err(out.float(), out_k.float()) < 6e-3
+    # a row is a function of itself alone, run to run and batch to batch
+    again = torch.zeros_like(outw)
+    run(a, t1, xw, again)
+    assert torch.equal(again, outw)
+    lo = min(M - 1, 100)
+    part = torch.zeros(M - lo, ld_o, dtype=torch.bfloat16, device=G.dev())
+    run(a[lo:].contiguous(), t1[lo:].contiguous(), xw[lo:].contiguous(), part)
+    assert torch.equal(part, outw[lo:])
 
 
 def attn_ref(q, k, v, heads):

@@ -19,9 +19,9 @@ for blk in range(4):
     w2 = torch.zeros(C, 4 * C, device=dev)
     idx = torch.arange(C, device=dev)
     w2[idx, blk * C + idx] = 1.0
-    ws = torch.empty(lib.hedit_k_ffn_stream_bytes(), dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.hedit_k_ffn_stream_bytes(0), dtype=torch.uint8, device=dev)
     bp = torch.empty(lib.hedit_k_ffn_bias_bytes(), dtype=torch.uint8, device=dev)
-    _lib.check(lib.hedit_k_ffn_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(ws), _lib.ptr(bp), None))
+    _lib.check(lib.hedit_k_ffn_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), None, None, _lib.ptr(ws), _lib.ptr(bp), None))
     out = torch.zeros_like(x)
     _lib.check(lib.hedit_k_ffn_fused(_lib.ptr(x), C, _lib.ptr(gamma), _lib.ptr(beta), 1e-5, _lib.ptr(ws), _lib.ptr(bp),
                                      _lib.ptr(b2), _lib.ptr(out), C, M, C, None))

@@ -22,9 +22,9 @@ w1 = (torch.randn(8 * C, C, generator=g) / math.sqrt(C)).to(dev)
 b1 = torch.zeros(8 * C, device=dev)
 w2 = (torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)).to(dev)
 b2 = torch.zeros(C, device=dev)
-ws = torch.empty(lib.hedit_k_ffn_stream_bytes(), dtype=torch.uint8, device=dev)
+ws = torch.empty(lib.hedit_k_ffn_stream_bytes(0), dtype=torch.uint8, device=dev)
 bp = torch.empty(lib.hedit_k_ffn_bias_bytes(), dtype=torch.uint8, device=dev)
-_lib.check(lib.hedit_k_ffn_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(ws), _lib.ptr(bp), None))
+_lib.check(lib.hedit_k_ffn_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), None, None, _lib.ptr(ws), _lib.ptr(bp), None))
 out = torch.empty_like(x)
 xn = torch.empty_like(x)
 wp = torch.empty(8 * C, C, dtype=torch.bfloat16, device=dev)
@@ -59,7 +59,36 @@ def timeit(fn):
     return e0.elapsed_time(e1) / reps
 
 
+# ---- the whole block tail: attn2.to_out + residual, feed-forward, proj_out + residual
+a_in = (torch.randn(M, C, generator=g)).to(torch.bfloat16).to(dev)
+t1 = (torch.randn(M, C, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+wo = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dev); wpo = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dev)
+bo = torch.zeros(C, device=dev)
+wsc = torch.empty(lib.hedit_k_ffn_stream_bytes(1), dtype=torch.uint8, device=dev)
+_lib.check(lib.hedit_k_ffn_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(wo), _lib.ptr(wpo), _lib.ptr(wsc), _lib.ptr(bp), None))
+wob, wpb = wo.to(torch.bfloat16).contiguous(), wpo.to(torch.bfloat16).contiguous()
+t2 = torch.empty_like(x); out_c = torch.empty_like(x); out_ck = torch.empty_like(x)
+
+
+def chain():
+    _lib.check(lib.hedit_k_ffn_chain(_lib.ptr(a_in), C, _lib.ptr(t1), C, _lib.ptr(x), C, _lib.ptr(bo), _lib.ptr(gamma), _lib.ptr(beta), 1e-5,
+                                     _lib.ptr(wsc), _lib.ptr(bp), _lib.ptr(b2), _lib.ptr(bo), _lib.ptr(out_c), C, M, C, None))
+
+
+def chain_unfused():
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(a_in), _lib.ptr(wob), _lib.ptr(bo), _lib.ptr(t1), _lib.ptr(t2), M, C, C, C, C, C, 0, 0, 0, 0, 0, 0, 1, None, None))
+    _lib.check(lib.hedit_k_layernorm(_lib.ptr(t2), _lib.ptr(xn), _lib.ptr(gamma), _lib.ptr(beta), M, C, 1e-5, None))
+    _lib.check(lib.hedit_k_gemm_geglu(_lib.ptr(xn), _lib.ptr(wp), _lib.ptr(b1p), _lib.ptr(hid), M, 4 * C, C, C, 4 * C, None))
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(hid), _lib.ptr(w2b), _lib.ptr(b2), _lib.ptr(t2), _lib.ptr(out_k), M, C, 4 * C,
+                                4 * C, C, C, 0, 0, 0, 0, 0, 0, 1, None, None))
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(out_k), _lib.ptr(wpb), _lib.ptr(bo), _lib.ptr(x), _lib.ptr(out_ck), M, C, C, C, C, C, 0, 0, 0, 0, 0, 0, 1, None, None))
+
+
 flops = 2.0 * M * 12 * C * C
+tc, tcu = timeit(chain), timeit(chain_unfused)
+errc = ((out_c.float() - out_ck.float()).norm() / out_ck.float().norm()).item()
+print(f"rows {rows}: block tail (to_out + ff + proj_out) fused {tc * 1e3:.1f} us = {2.0 * M * 14 * C * C / tc / 1e9:.0f} TF/s | five launches "
+      f"{tcu * 1e3:.1f} us = {2.0 * M * 14 * C * C / tcu / 1e9:.0f} TF/s | speed-up {tcu / tc:.2f} | rel diff {errc:.2e}")
 tf, tu = timeit(fused), timeit(unfused)
 err = ((out.float() - out_k.float()).norm() / out_k.float().norm()).item()
 print(f"rows {rows} (M = {M}): fused {tf * 1e3:.1f} us = {flops / tf / 1e9:.0f} TF/s | unfused chain {tu * 1e3:.1f} us = "
