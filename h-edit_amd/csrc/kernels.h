@@ -55,6 +55,27 @@ struct FfnParams {
   const bf16_t* r2; long ldr2;   // residual of the trailing layer [M][ldr2] (with the leading layer only)
   const float* bias_pre; const float* bias_post;
 };
+// ---------------------------------------------------------------- linchain.hip
+// The projections around an attention of the C = 320 level as one kernel:
+//   mid = a W_pre^T + bias_pre + r1 (written to out_mid);  out = LN(mid) W_0^T           [gn_ss == nullptr]
+//   mid = (a * scale + shift) W_pre^T + bias_pre;  q, k = LN(mid) W_0^T, LN(mid) W_1^T;  out = (LN(mid) W_2^T)^T   [gn_ss set]
+struct LinChainParams {
+  const bf16_t* a; long lda;
+  const bf16_t* r1; long ldr1;
+  const float* bias_pre;
+  const float* gamma; const float* beta; float eps;
+  const bf16_t* stream;          // lin_chain_stream_bytes(2 / 4 layers)
+  bf16_t* out_mid; long ldmid;
+  bf16_t* out; long ldo;         // [M][ldo], or with gn_ss: [C][ldo] (transposed)
+  int M, C;
+  const float* gn_ss; int rows_per_image;      // [images][C][2] (scale, shift) of the GroupNorm in front
+  bf16_t* out_q; long ldq; bf16_t* out_k; long ldk;
+};
+int lin_chain_launch(const LinChainParams& c, hipStream_t st);
+size_t lin_chain_stream_bytes(int layers);        // layers = 2 (to_out, to_q) or 4 (proj_in, to_q, to_k, to_v)
+// w [C][C] fp32 -> layer `layer` of the stream (layer 0 takes its input from HBM: natural k order; the others read an
+// accumulator: register order); the call for layer 0 also zeroes the DMA overrun behind the last layer
+int lin_chain_pack_launch(const float* w, int layer, float scale, int layers, bf16_t* stream, hipStream_t st);
 int ffn_fused_channels();
 size_t ffn_stream_bytes(int pre, int post);
 size_t ffn_bias_bytes();
@@ -72,6 +93,8 @@ size_t groupnorm_ws_bytes(int B, int HW, int C);
 int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B,
                      int HW, int C, int G, float eps, int silu, float* ws, hipStream_t st,
                      float* stats = nullptr);   // stats: optional [B][G][2] (mean, rstd) for the backward pass
+int groupnorm_affine_launch(const bf16_t* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps,
+                            float* ws, hipStream_t st, const float** ss_out);   // *ss_out: [B][C] float2 (scale, shift), inside ws
 int layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, long rows,
                      int C, float eps, hipStream_t st);
 int geglu_launch(const bf16_t* x, bf16_t* y, long rows, int inner, hipStream_t st);

@@ -1,0 +1,545 @@
+// The token-local projections AROUND the two attentions of a BasicTransformerBlock at the C = 320 level of the SD UNet,
+// each group as ONE kernel per 128-row tile (oracle/sd_unet.py: Transformer2DModel.norm / proj_in, BasicTransformerBlock
+// norm1 / attn1.to_q|k|v, attn1.to_out, norm2, attn2.to_q):
+//
+//   two layers:   t1 = attn1.to_out(a) + t0         (written out: the residual stream)
+//                 q2 = attn2.to_q( LayerNorm(t1) )
+//   four layers:  t0 = proj_in( GroupNorm(x) )      (GroupNorm applied on the fly from per-(image, channel) scale / shift)
+//                 q | k = attn1.to_q | to_k ( LayerNorm(t0) ),   v^T = attn1.to_v( LayerNorm(t0) )^T
+//
+// Unfused these are 3 / 6 launches that move five / nine [M][320] activations through HBM at HBM speed (K = 320 GEMMs
+// are memory-bound); here the inputs are read once and only the results the attention kernels need are written.
+//
+// gfx950 mapping -- the scheme of ffn.hip ("rows stay in registers, weights stream") with the tile I/O done the way the
+// memory system wants it:
+//   * a block = 4 waves (one per SIMD), a wave owns 32 rows; v_mfma_f32_32x32x16_bf16 with the weights as the 32-row
+//     operand: Xn = the layer's input fragments (80 AGPR), O = the 320 x 32 fp32 accumulator (160 AGPR).  An accumulator
+//     in MFMA result layout is the next layer's fragment layout once that layer's k is renumbered inside its groups of
+//     16 (lin_unit_of_reg, folded into the weight packing).
+//   * weights: a stream of 10 KB iterations (one 16-deep k-step = ten 1 KB lane-linear fragment images, 20 iterations
+//     per layer) copied global -> LDS by DMA into a ring of seven, six ahead (60 KB in flight = what an LDS-DMA's
+//     ~0.85 us latency needs at the consumption rate of 10 KB per 320 cycles), counted vmcnt, one barrier per iteration.
+//   * tile I/O through a wave-private 20 KB staging area in LDS: a lane of the MFMA layout owns ONE ROW, so direct
+//     global accesses are 64 separate requests per instruction (measured: 60 such loads + 40 such stores cost more than
+//     the arithmetic of the whole chain).  Inputs: DMA of whole rows (lanes fetch consecutive 16-byte chunks) into the
+//     staging area with the chunk index XOR-swizzled by the row, then ds_read of the fragment / accumulator layout.
+//     Outputs: bf16(O) written to the staging area in the same swizzle, read back as row pieces, 16-byte coalesced
+//     stores.  v^T leaves through a block-wide [320][128] transposing stage (the ring is free by then).
+// Every output row depends on its own input row only and the summation order is fixed.
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+constexpr int LC = 320;                  // channels
+constexpr int LKS = LC / 16;             // k-steps = iterations per layer
+constexpr int LNB = LC / 32;             // 32-wide output blocks = MFMAs (and fragments) per iteration
+constexpr int IT_BYTES = LNB * 1024;
+constexpr int RING = 7, AHEAD = 6;
+constexpr int PPW = 3;                   // DMA pieces per wave and iteration (10 pieces; the surplus slots re-load the last)
+constexpr int LEAD = 8;                  // fragment reads run this many MFMAs ahead
+constexpr int ROW_BYTES = LC * 2;
+constexpr int STAGE_OFF = RING * IT_BYTES;
+constexpr int STAGE_BYTES = 32 * ROW_BYTES;            // per wave
+constexpr int PAR_OFF = STAGE_OFF + 4 * STAGE_BYTES;   // gamma | beta | bias of the first layer (fp32)
+constexpr int SS_OFF = PAR_OFF + 3 * LC * 4;           // GroupNorm (scale, shift) pairs of the tile's image, 3 x 1 KB DMA pieces
+constexpr int SS_DMAS = 3;
+constexpr int DUMMY_OFF = SS_OFF + SS_DMAS * 1024;     // target of the place-holder DMA in front of the first tile
+constexpr int LDS_TOTAL = DUMMY_OFF + 1024;
+constexpr int BLOCK_ROWS = 128;
+constexpr int CPR = LC / 8;              // 16-byte chunks per row
+static_assert(LDS_TOTAL <= 160 * 1024, "ring + staging must fit the LDS");
+static_assert(LNB + 2 >= LEAD && LEAD <= LNB, "the read-ahead reaches into the next iteration only");
+
+__host__ __device__ constexpr int stream_iters(int layers) { return layers * LKS; }
+// input feature (inside its group of 16) held by accumulator register r (0..7) of lane half hi
+__host__ __device__ inline int lin_unit_of_reg(int r, int hi) { return (r >> 2) * 8 + hi * 4 + (r & 3); }
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+__global__ __launch_bounds__(256) void lin_pack_kernel(const float* __restrict__ w, int layer, float scale, int layers, bf16_t* __restrict__ stream) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)stream_iters(layers) * (IT_BYTES / 16);
+  if (idx >= total) return;
+  const int it = (int)(idx / (IT_BYTES / 16));
+  const int r = (int)(idx - (long)it * (IT_BYTES / 16));
+  const int nb = r >> 6, l = r & 63, row = l & 31, hi = l >> 5;
+  const int L = it / LKS, ks = it % LKS;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  if (L != layer) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = scale * w[(long)(nb * 32 + row) * LC + ks * 16 + (L == 0 ? hi * 8 + e : lin_unit_of_reg(e, hi))];
+  *reinterpret_cast<uint4*>(reinterpret_cast<char*>(stream) + idx * 16) = pack8(v);
+}
+
+struct LinKernelParams {
+  const bf16_t* a; long lda;
+  const bf16_t* r1; long ldr1;
+  const float* bias_pre;
+  const float* gamma; const float* beta; float eps;
+  const bf16_t* stream;
+  bf16_t* out_mid; long ldmid;
+  bf16_t* out_p[2]; long ldp[2];
+  bf16_t* out; long ldo;
+  const float* gn_ss; int rows_per_image;
+  int M;
+};
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// accumulator and activation fragment in AGPRs, the weight fragment in VGPRs (asm: the register files are ours to choose;
+// what the compiler does not do for an asm MFMA is hazard padding -- see settle / publish below and ffn.hip)
+__device__ __forceinline__ void mfma_l(f32x16& acc, const bf16x8& w, const bf16x8& a) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "a"(a));
+}
+
+// NPOST: layers behind the LayerNorm (1 or 3).  GNIN: the first layer's input is GroupNorm'd on the fly and there is no
+// residual.  VT: the last result is written transposed.
+//
+// PERSISTENT: one block per CU walks over its tiles, so that
+//   * the weight stream never stops -- it is read cyclically, the DMA of the next tile's first iterations is simply the
+//     continuation of the ring (no per-tile prefill, no drain);
+//   * the tile I/O overlaps the arithmetic: the next tile's input rows are DMA'd into the staging area while the last
+//     layer runs, the residual rows while the first layer runs (the residual is added BEHIND the first layer), and the
+//     stores of a result are in flight while the next layer runs.  The staging area is used strictly one thing after
+//     the other: [input rows -> fragments] [final result -> stores] [residual rows -> accumulator] [first result ->
+//     stores] ([q, k -> stores]) [next input rows ...].
+// Everything that enters the vector-memory queue between two layers (row DMA, stores) retires in issue order with the
+// weight DMA (one in-order vmcnt queue on gfx9), so the counted waits of the ring stay exact: the first iterations of
+// a layer that follows E such operations allow E more outstanding ones (template parameter of the layer) -- the burst
+// gets four iterations to complete before anybody waits for it.  The burst sizes are made the same for every tile
+// (dummy DMA in front of the first tile, bounds-checked buffer stores that are issued whether or not the row exists).
+template <int NPOST, bool GNIN, bool VT>
+__global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lm = lane & 31, hi = lane >> 5;
+  constexpr int NL = 1 + NPOST, NIT = NL * LKS;
+  const int ntiles = (p.M + BLOCK_ROWS - 1) / BLOCK_ROWS;
+  float* const par = reinterpret_cast<float*>(smem + PAR_OFF);      // gamma | beta | bias_pre
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.stream), (short)0, (int)(NIT * IT_BYTES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.a), (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(GNIN ? p.a : p.r1), (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GNIN ? p.gn_ss : p.gamma), (short)0,
+                                                                         GNIN ? (int)(((p.M + p.rows_per_image - 1) / (GNIN ? p.rows_per_image : 1)) * LC * 8) : 16, 0x00020000);
+#endif
+  // (the address arithmetic of the tile I/O is redone where it is used -- an opaque copy of the lane id per use -- instead
+  //  of living in ~150 registers across the whole tile loop, where the compiler would hoist it to)
+  auto fresh = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
+  // weight DMA: piece k (0..2) of this wave for stream iteration `sit` -> ring bank `bank`: 1 KB piece q = wave + 4 k of the
+  // iteration's ten (q = 10, 11 re-load piece 9: same bytes, same place)
+  const int q2 = wave + 8 > 9 ? 9 : wave + 8;
+  const unsigned dma_voff = (unsigned)(lane * 16);
+  auto dma_piece = [&](int sit, int bank, int k) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int q = k < 2 ? wave + 4 * k : q2;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(smem + bank * IT_BYTES + q * 1024), 16, dma_voff,
+                                             sit * IT_BYTES + q * 1024, 0, 0);
+#else
+    (void)sit; (void)bank; (void)k;
+#endif
+  };
+  // row DMA: the wave's 32 rows of a tile -> its staging area, 20 instructions of 64 consecutive 16-byte slots; slot s of
+  // row r holds chunk s ^ swz(r) (the XOR stays inside a group of eight chunks = one 128-byte line)
+  char* const stage = smem + STAGE_OFF + wave * STAGE_BYTES;
+  constexpr int ROW_DMAS = 32 * CPR / 64;
+  static_assert(32 * CPR % 64 == 0, "rows must divide evenly over the lanes");
+  auto stage_rows = [&](auto res_c, long ld, int tile) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int m0 = tile * BLOCK_ROWS + wave * 32;
+    const int ln = fresh(lane);
+#pragma unroll
+    for (int i = 0; i < ROW_DMAS; ++i) {
+      const int s = i * 64 + ln;
+      const int r = s / CPR, slot = s - r * CPR;
+      int row = m0 + r;
+      if (row > p.M - 1) row = p.M - 1;
+      const unsigned voff = (unsigned)((long)row * ld * 2 + ((slot ^ swz(r)) * 16));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(decltype(res_c)::value ? rs_r : rs_a, (__attribute__((address_space(3))) void*)(stage + i * 1024), 16, voff, 0, 0, 0);
+    }
+#else
+    (void)ld; (void)tile;
+#endif
+  };
+  // the (scale, shift) pairs of the tile's image -> SS_OFF (every wave fetches the same 2.5 KB: identical bytes)
+  auto stage_ss = [&](int tile) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int img = (tile * BLOCK_ROWS) / p.rows_per_image;
+#pragma unroll
+    for (int k = 0; k < SS_DMAS; ++k)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ss, (__attribute__((address_space(3))) void*)(smem + SS_OFF + k * 1024), 16, dma_voff,
+                                               img * (LC * 8) + k * 1024, 0, 0);
+#else
+    (void)tile;
+#endif
+  };
+  auto dummy_dma = [&](int n) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int k = 0; k < n; ++k)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(smem + DUMMY_OFF), 16, dma_voff, 0, 0, 0);
+#else
+    (void)n;
+#endif
+  };
+
+  // O[nb][4 q + j] of lane (lm, hi) = feature 32 nb + 8 q + 4 hi + j of row lm  (32x32 MFMA result layout)
+  f32x16 O[LNB];
+  bf16x8 Xn[LKS];        // lane (row lm, half hi): activation fragment of k-step ks (8 consecutive k, or 8 registers of O)
+  // (see ffn.hip) accumulators readable by the VALU behind asm MFMAs / VALU-written registers in front of asm MFMAs
+  auto settle = [&]() __attribute__((always_inline)) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#pragma unroll
+    for (int nb = 0; nb < LNB; ++nb) asm volatile("" : "+a"(O[nb]));
+  };
+  auto publish = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int nb = 0; nb < LNB; ++nb) asm volatile("" : "+a"(O[nb]));
+    asm volatile("s_nop 3" ::: "memory");
+  };
+  // the first layer's fragments from the staged input rows (GNIN: x * scale + shift on the way)
+  auto read_xn = [&]() __attribute__((always_inline)) {
+    const int lmf = fresh(lm);
+    const int my_row = lmf * ROW_BYTES, my_swz = swz(lmf);
+#pragma unroll
+    for (int ks = 0; ks < LKS; ++ks) {
+      u32x4 raw = *reinterpret_cast<const u32x4*>(stage + my_row + (((2 * ks + hi) ^ my_swz) * 16));
+      if constexpr (GNIN) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x[2 * e] = __builtin_bit_cast(float, raw[e] << 16);
+          x[2 * e + 1] = __builtin_bit_cast(float, raw[e] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const f32x4 c = *reinterpret_cast<const f32x4*>(smem + SS_OFF + (ks * 16 + hi * 8 + 2 * e2) * 8);       // channels 2 e2, 2 e2 + 1
+          x[2 * e2] = __builtin_fmaf(x[2 * e2], c[0], c[1]);
+          x[2 * e2 + 1] = __builtin_fmaf(x[2 * e2 + 1], c[2], c[3]);
+        }
+        raw = (u32x4){pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])};
+      }
+      Xn[ks] = __builtin_bit_cast(bf16x8, raw);
+      asm volatile("" : "+a"(Xn[ks]));       // home in the AGPR file from here on (every use is an MFMA operand)
+    }
+  };
+  auto bias_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int nb = 0; nb < LNB; ++nb) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(par + 2 * LC + nb * 32 + q * 8 + hi * 4);
+        O[nb][4 * q] = bb[0]; O[nb][4 * q + 1] = bb[1]; O[nb][4 * q + 2] = bb[2]; O[nb][4 * q + 3] = bb[3];
+      }
+      asm volatile("" : "+a"(O[nb]));
+    }
+  };
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int nb = 0; nb < LNB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[nb][r] = 0.f;
+  };
+
+  // ---- one iteration = ten bundles of [MFMA | a fragment read LEAD MFMAs ahead (the last LEAD fetch the first fragments
+  // of the next iteration; not across layers) | three of them a DMA piece], pinned by sched_barrier.  At the iteration
+  // boundary: [my pieces of iteration it + 2 have landed: vmcnt(the newest AHEAD - 2 iterations, + the burst in front of
+  // the layer while it is younger than that)] [my reads of the iteration just finished have returned: lgkmcnt(the LEAD
+  // newest = next iteration's)] barrier; the finished bank is refilled next.
+  int sit = 0, bank = 0;                     // stream iteration being consumed (mod NIT), its ring bank
+  int frag_rd = lane * 16;
+  bf16x8 pre[LEAD];
+  auto linear_layer = [&](auto extra_c) __attribute__((always_inline)) {
+    constexpr int EXTRA = decltype(extra_c)::value;
+    static_assert((AHEAD - 2) * PPW + EXTRA <= 63, "vmcnt is a 6-bit counter");
+#pragma unroll
+    for (int j = 0; j < LEAD; ++j) pre[j] = *reinterpret_cast<const bf16x8*>(smem + frag_rd + j * 1024);
+    static_for<LKS>([&](auto ks_) {
+      constexpr int ks = decltype(ks_)::value;
+      const int base = frag_rd;
+      const int nbank = bank == RING - 1 ? 0 : bank + 1;
+      const int pbank = bank == 0 ? RING - 1 : bank - 1;
+      const int nbase = lane * 16 + nbank * IT_BYTES;
+      int dit = sit + AHEAD;
+      if (dit >= NIT) dit -= NIT;
+      bf16x8 fr[LNB + LEAD];
+#pragma unroll
+      for (int j = 0; j < LEAD; ++j) fr[j] = pre[j];
+      static_for<LNB>([&](auto b_) {
+        constexpr int b = decltype(b_)::value;
+        // lgkmcnt only: fragments b .. b+2 are here when at most the reads of b+3 .. b+LEAD-1 are outstanding (the last
+        // iteration of a layer issues none beyond its own fragments)
+        if constexpr (b % 3 == 0) {
+          constexpr int newer = (ks + 1 < LKS ? b + LEAD - 1 : (b + LEAD - 1 < LNB - 1 ? b + LEAD - 1 : LNB - 1)) - (b + 2);
+          __builtin_amdgcn_s_waitcnt(0xC07F | ((newer > 0 ? newer : 0) << 8));
+        }
+        mfma_l(O[b], fr[b], Xn[ks]);
+        if constexpr (b + LEAD < LNB) fr[b + LEAD] = *reinterpret_cast<const bf16x8*>(smem + base + (b + LEAD) * 1024);
+        else if constexpr (ks + 1 < LKS) pre[b + LEAD - LNB] = *reinterpret_cast<const bf16x8*>(smem + nbase + (b + LEAD - LNB) * 1024);
+        if constexpr (b % 3 == 1) dma_piece(dit, pbank, b / 3);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (ks < 4)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"((AHEAD - 2) * PPW + EXTRA), "n"(LEAD) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"((AHEAD - 2) * PPW), "n"(LEAD) : "memory");
+      sit = sit + 1 == NIT ? 0 : sit + 1;
+      bank = nbank;
+      frag_rd = nbase;
+    });
+  };
+  // bf16(O) -> the wave's staging area (swizzled like the inputs) -> whole-row pieces -> 16-byte coalesced stores:
+  // ROW_DMAS bounds-checked buffer stores, issued for every tile alike (rows beyond M fall outside the buffer)
+  auto store_rows = [&](bf16_t* dst, long ld, int tile) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(dst, (short)0, (int)((((long)p.M - 1) * ld + LC) * 2), 0x00020000);
+#endif
+    const int lmf = fresh(lm), ln = fresh(lane);
+    const int my_row = lmf * ROW_BYTES, my_swz = swz(lmf);
+#pragma unroll
+    for (int nb = 0; nb < LNB; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u32x2 o;
+        o[0] = pack_bf16x2(O[nb][4 * q], O[nb][4 * q + 1]);
+        o[1] = pack_bf16x2(O[nb][4 * q + 2], O[nb][4 * q + 3]);
+        *reinterpret_cast<u32x2*>(stage + my_row + (((nb * 4 + q) ^ my_swz) * 16) + hi * 8) = o;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (a wave reads back only what it wrote itself)
+    const int m0 = tile * BLOCK_ROWS + wave * 32;
+    constexpr int GRP = 5;
+#pragma unroll
+    for (int i0 = 0; i0 < ROW_DMAS; i0 += GRP) {
+      u32x4 ov[GRP];
+#pragma unroll
+      for (int i = 0; i < GRP; ++i) ov[i] = *reinterpret_cast<const u32x4*>(stage + ((i0 + i) * 64 + ln) * 16);
+#pragma unroll
+      for (int i = 0; i < GRP; ++i) {
+        const int s = (i0 + i) * 64 + ln;
+        const int r = s / CPR, slot = s - r * CPR;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_o, (unsigned)(((long)(m0 + r) * ld + (slot ^ swz(r)) * 8) * 2), 0, 0);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the staging area may be overwritten from here on
+  };
+  // the same for the transposed result: [320 features][32 rows] per wave (64 bytes per feature; features permuted inside
+  // their groups of eight so that the two lane halves, four features apart, write different bank halves), then per
+  // feature 64 contiguous bytes of the [C][M] result as four 16-byte stores
+  auto store_rows_t = [&](bf16_t* dst, long ld, int tile) __attribute__((always_inline)) {
+    const int lmf = fresh(lm), ln = fresh(lane);
+#pragma unroll
+    for (int nb = 0; nb < LNB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = nb * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+        const int x = f & 7;
+        const int slot = (f & ~7) + (x < 4 ? x : 4 + ((x + 1) & 3));
+        *reinterpret_cast<bf16_t*>(stage + slot * 64 + lmf * 2) = (bf16_t)(pack_bf16x2(O[nb][r], 0.f) & 0xffffu);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int m0 = tile * BLOCK_ROWS + wave * 32;
+    constexpr int GRP = 5;
+#pragma unroll
+    for (int i0 = 0; i0 < ROW_DMAS; i0 += GRP) {
+      u32x4 ov[GRP];
+#pragma unroll
+      for (int i = 0; i < GRP; ++i) ov[i] = *reinterpret_cast<const u32x4*>(stage + ((i0 + i) * 64 + ln) * 16);
+#pragma unroll
+      for (int i = 0; i < GRP; ++i) {
+        const int s = (i0 + i) * 64 + ln;
+        const int slot = s >> 2, part = s & 3;
+        const int y = slot & 7;
+        const int f = (slot & ~7) + (y < 4 ? y : 4 + ((y + 3) & 3));
+        *reinterpret_cast<u32x4*>(dst + (long)f * ld + m0 + part * 8) = ov[i];          // (M % 128 == 0: every row exists)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  // ---- once: the LayerNorm parameters and the first bias into LDS; the first tile's input rows; the stream's head
+  for (int i = tid; i < 3 * LC; i += 256) par[i] = i < LC ? p.gamma[i] : (i < 2 * LC ? p.beta[i - LC] : p.bias_pre[i - 2 * LC]);
+  int tile = blockIdx.x;
+  stage_rows(std::false_type{}, p.lda, tile);
+  if constexpr (GNIN) stage_ss(tile);
+#pragma unroll
+  for (int it = 0; it < AHEAD; ++it)
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) dma_piece(it, it, k);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * PPW) : "memory");        // my input rows (and the scale / shift pairs) are in LDS
+  read_xn();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  constexpr int E_FIRST = ROW_DMAS + (GNIN ? 0 : ROW_DMAS);                  // in front of a first layer: the final stores (+ the residual DMA)
+  constexpr int E_MID = ROW_DMAS;                                            // in front of a middle layer: the stores of the previous result
+  constexpr int E_LAST = ROW_DMAS + ROW_DMAS + (GNIN ? SS_DMAS : 0);         // in front of the last layer: stores + the next tile's input
+  dummy_dma(ROW_DMAS);                                                       // (stands in for the previous tile's final stores)
+  if constexpr (!GNIN) stage_rows(std::true_type{}, p.ldr1, tile);
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(E_FIRST) : "memory");     // par[] and iterations 0 .. AHEAD-1 are in LDS
+  bias_acc();
+  publish();
+
+  while (true) {
+    // ================================================================ first layer (+ residual), written out
+    linear_layer(std::integral_constant<int, E_FIRST>{});
+    settle();
+    if constexpr (!GNIN) {
+      const int lmf = fresh(lm);
+      const int my_row = lmf * ROW_BYTES, my_swz = swz(lmf);
+#pragma unroll
+      for (int nb = 0; nb < LNB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const u32x2 u = *reinterpret_cast<const u32x2*>(stage + my_row + (((nb * 4 + q) ^ my_swz) * 16) + hi * 8);
+          O[nb][4 * q] += __builtin_bit_cast(float, u[0] << 16);
+          O[nb][4 * q + 1] += __builtin_bit_cast(float, u[0] & 0xffff0000u);
+          O[nb][4 * q + 2] += __builtin_bit_cast(float, u[1] << 16);
+          O[nb][4 * q + 3] += __builtin_bit_cast(float, u[1] & 0xffff0000u);
+          if (q == 3) asm volatile("" : "+a"(O[nb]));
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    store_rows(p.out_mid, p.ldmid, tile);
+
+    // ================================================================ LayerNorm of the accumulator -> fragments
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < LNB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += O[nb][r];
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s / (float)LC;
+#pragma unroll
+      for (int nb = 0; nb < LNB; ++nb) asm volatile("" : "+a"(O[nb]));      // (each pass re-reads the AGPRs: no 160-register copy kept alive)
+      float q = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < LNB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = O[nb][r] - mean; q += d * d; }
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = rsqrtf(q / (float)LC + p.eps);
+#pragma unroll
+      for (int nb = 0; nb < LNB; ++nb) asm volatile("" : "+a"(O[nb]));
+#pragma unroll
+      for (int ks = 0; ks < LKS; ++ks) {
+        float o[8];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int qq = 2 * (ks % 2) + h2;
+          const f32x4 gg = *reinterpret_cast<const f32x4*>(par + (ks / 2) * 32 + qq * 8 + hi * 4);
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(par + LC + (ks / 2) * 32 + qq * 8 + hi * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[4 * h2 + j] = (O[ks / 2][4 * qq + j] - mean) * rstd * gg[j] + bb[j];
+        }
+        const u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        Xn[ks] = __builtin_bit_cast(bf16x8, pk);
+        asm volatile("" : "+a"(Xn[ks]));
+      }
+    }
+
+    // ================================================================ the layers behind the LayerNorm
+    zero_acc();
+    publish();
+#pragma unroll 1
+    for (int j = 0; j < NPOST - 1; ++j) {
+      linear_layer(std::integral_constant<int, E_MID>{});
+      settle();
+      store_rows(p.out_p[j], p.ldp[j], tile);
+      zero_acc();
+      publish();
+    }
+    // the next tile's input rows travel while the last layer runs (behind the last tile: the same rows once more, so that
+    // every tile puts the same number of operations into the queue)
+    const int ntile = tile + (int)gridDim.x;
+    const int ltile = ntile < ntiles ? ntile : tile;
+    stage_rows(std::false_type{}, p.lda, ltile);
+    if constexpr (GNIN) stage_ss(ltile);
+    linear_layer(std::integral_constant<int, E_LAST>{});
+    settle();
+    read_xn();                                             // the fragments of the NEXT tile's first layer (Xn is free now)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (VT) store_rows_t(p.out, p.ldo, tile);
+    else store_rows(p.out, p.ldo, tile);
+    if constexpr (!GNIN) stage_rows(std::true_type{}, p.ldr1, ltile);
+    if (ntile >= ntiles) break;
+    tile = ntile;
+    bias_acc();
+    publish();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (DMA still in flight lands in LDS that must still be this block's)
+}
+
+template <int NPOST, bool GNIN, bool VT>
+int launch(const LinKernelParams& k, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_chain_kernel<NPOST, GNIN, VT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    attr_set = true;
+  }
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const int ntiles = cdiv(k.M, BLOCK_ROWS);
+  hipLaunchKernelGGL((lin_chain_kernel<NPOST, GNIN, VT>), dim3(ntiles < cus ? ntiles : cus), dim3(256), LDS_TOTAL, st, k);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+}  // namespace
+
+size_t lin_chain_stream_bytes(int layers) { return (size_t)stream_iters(layers) * IT_BYTES; }
+
+int lin_chain_pack_launch(const float* w, int layer, float scale, int layers, bf16_t* stream, hipStream_t st) {
+  ARG_CHECK(w && stream && (layers == 2 || layers == 4) && layer >= 0 && layer < layers, "lin_chain_pack: args");
+  const long total = (long)stream_iters(layers) * (IT_BYTES / 16);
+  hipLaunchKernelGGL(lin_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, layer, scale, layers, stream);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int lin_chain_launch(const LinChainParams& c, hipStream_t st) {
+  ARG_CHECK(c.C == LC, "lin_chain: exists for C = 320");
+  ARG_CHECK(c.M > 0 && c.a && c.stream && c.gamma && c.beta && c.bias_pre && c.out_mid && c.out, "lin_chain: null");
+  ARG_CHECK(c.lda % 8 == 0 && c.ldmid % 8 == 0 && c.ldo % 8 == 0, "lin_chain: rows must be 16-byte aligned");
+  ARG_CHECK((long)c.M * c.lda * 2 < (1L << 31) && (long)c.M * c.ldmid * 2 < (1L << 31) && (c.gn_ss || (long)c.M * c.ldo * 2 < (1L << 31)),
+            "lin_chain: tensor beyond the 2 GB buffer window");
+  LinKernelParams k{};
+  k.a = c.a; k.lda = c.lda; k.bias_pre = c.bias_pre; k.gamma = c.gamma; k.beta = c.beta; k.eps = c.eps;
+  k.stream = c.stream; k.M = c.M; k.out_mid = c.out_mid; k.ldmid = c.ldmid; k.out = c.out; k.ldo = c.ldo;
+  if (!c.gn_ss) {
+    ARG_CHECK(c.r1 && c.ldr1 % 8 == 0 && (long)c.M * c.ldr1 * 2 < (1L << 31), "lin_chain: residual rows");
+    k.r1 = c.r1; k.ldr1 = c.ldr1;
+    return launch<1, false, false>(k, st);
+  }
+  ARG_CHECK(c.rows_per_image > 0 && c.rows_per_image % BLOCK_ROWS == 0 && c.M % c.rows_per_image == 0 && c.out_q && c.out_k &&
+                c.ldq % 8 == 0 && c.ldk % 8 == 0,
+            "lin_chain: GroupNorm'd input form (whole images of a multiple of 128 rows; q, k, v^T outputs)");
+  ARG_CHECK((long)c.M * c.ldq * 2 < (1L << 31) && (long)c.M * c.ldk * 2 < (1L << 31), "lin_chain: output beyond the 2 GB buffer window");
+  k.gn_ss = c.gn_ss; k.rows_per_image = c.rows_per_image;
+  k.out_p[0] = c.out_q; k.ldp[0] = c.ldq; k.out_p[1] = c.out_k; k.ldp[1] = c.ldk;
+  return launch<3, true, true>(k, st);
+}

@@ -593,6 +593,27 @@ int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float
   return HEDIT_OK;
 }
 
+// statistics only: the per (image, channel) scale and shift (float2, [B][C]) a consumer applies itself (ffn.hip's
+// GroupNorm'd-input chain); same partial sums and summation order as groupnorm_launch
+int groupnorm_affine_launch(const bf16_t* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps,
+                            float* ws, hipStream_t st, const float** ss_out) {
+  ARG_CHECK(C % 8 == 0 && C % G == 0 && G <= 64, "groupnorm: C % 8, C % G, G <= 64");
+  ARG_CHECK(C / 8 <= 256 * GN_MAXV, "groupnorm: C too large");
+  const int nslab = gn_nslab(B, HW, C);
+  float* part = ws;
+  float* ss = ws + (size_t)B * nslab * 64 * 2;
+  const int CV = C / 8;
+  const int R = CV <= 256 ? 256 / CV : 1;
+  const size_t lds = (size_t)R * C * 2 * sizeof(float);
+  ARG_CHECK(lds <= 64 * 1024, "groupnorm: LDS");
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, B), dim3(256), lds, st, x, part, HW, C, G, nslab);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, gamma, beta, ss, HW, C, G, nslab, eps, (float*)nullptr);
+  LAUNCH_CHECK();
+  *ss_out = ss;
+  return HEDIT_OK;
+}
+
 int layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, long rows, int C,
                      float eps, hipStream_t st) {
   ARG_CHECK(C % 8 == 0 && C / 8 <= 64 * LN_MAXV, "layernorm: C");

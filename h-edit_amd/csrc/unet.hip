@@ -26,8 +26,8 @@ struct Slot {
   std::string name;
   int kind;        // 0 fp32 copy, 1 linear -> bf16 (scaled), 2 conv3x3 OIHW -> bf16 [O][9][I],
                    // 3 / 4: FF1 weight / bias with GEGLU (value16|gate16) row interleave,
-                   // 5 / 6 / 7 / 8 / 9: FF1 weight / FF1 bias / FF2 weight / attn2.to_out weight / proj_out weight of the
-                   // one-kernel block tail (ffn.hip)
+                   // 5: layer `which` of the block-tail weight stream (ffn.hip), 6: the FF1 bias in that kernel's packed
+                   // order, 7: layer `which` of a projection-chain weight stream of `lay` layers (linchain.hip)
   void* dst;
   size_t numel;
   int O, I;
@@ -35,6 +35,7 @@ struct Slot {
   bool loaded;
   int ndim;
   int dims[4];
+  int which = 0, lay = 0;
 };
 
 struct Res {
@@ -47,8 +48,10 @@ struct Attn {
   int C;
   float *gn_g, *gn_b, *pin_b, *ln1g, *ln1b, *ln2g, *ln2b, *ln3g, *ln3b, *o1_b, *o2_b, *ff1_b, *ff2_b, *pout_b;
   bf16_t *pin, *w_qk, *w_v1, *w_o1, *w_q2, *w_k2, *w_v2, *w_o2, *ff1, *ff2, *pout;
-  bf16_t* ffs = nullptr;     // C == ffn_fused_channels(): the feed-forward runs as one kernel (ffn.hip) on this weight
-  float* ff1_bp = nullptr;   // stream + packed FF1 bias; ff1 / ff2 / ff1_b are then not materialised
+  // C == ffn_fused_channels(): the token-local layers run as three chain kernels (ffn.hip) on these weight streams
+  // (+ the packed FF1 bias); pin / w_qk / w_v1 / w_o1 / w_q2 / w_o2 / ff1 / ff2 / ff1_b / pout are then not materialised
+  bf16_t *frs = nullptr, *k1s = nullptr, *ffs = nullptr;
+  float* ff1_bp = nullptr;
 };
 
 struct Block {
@@ -152,31 +155,51 @@ Attn make_attn(hedit_unet* h, const std::string& pre, int C) {
   const float qscale = 1.0f / sqrtf((float)d) * 1.4426950408889634f;   // softmax scale * log2(e)
   a.gn_g = f32p(h, pre + ".norm.weight", C);
   a.gn_b = f32p(h, pre + ".norm.bias", C);
-  a.pin = linp(h, pre + ".proj_in.weight", C, C);
-  a.pin_b = f32p(h, pre + ".proj_in.bias", C);
+  // At the level ffn.hip exists for, the token-local layers of the block run as three kernels -- GroupNorm apply +
+  // proj_in + norm1 + q | k | v^T;  attn1.to_out + residual + norm2 + attn2.to_q;  attn2.to_out + residual + norm3 +
+  // feed-forward + proj_out + residual -- and their weights go into those kernels' streams (slot kind 5), the FF1 bias
+  // into its packed form (kind 6); none of them is kept as a GEMM operand.
+  const bool chain = C == ffn_fused_channels();
+  auto stream_slot = [&](const std::string& name, bf16_t* stream, int lay, int which, int O, int I, float scale, int ndim) {
+    add_slot(h, name, lay ? 7 : 5, stream, (size_t)O * I, O, I, scale);
+    Slot& sl = h->slots.back();
+    sl.which = which; sl.lay = lay; sl.ndim = ndim;
+    sl.dims[0] = O; sl.dims[1] = I; sl.dims[2] = 1; sl.dims[3] = 1;
+  };
   const std::string tb = pre + ".transformer_blocks.0";
+  if (chain) {
+    a.frs = dalloc<bf16_t>(h, lin_chain_stream_bytes(4) / sizeof(bf16_t));
+    a.k1s = dalloc<bf16_t>(h, lin_chain_stream_bytes(2) / sizeof(bf16_t));
+    a.ffs = dalloc<bf16_t>(h, ffn_stream_bytes(1, 1) / sizeof(bf16_t));
+    a.ff1_bp = dalloc<float>(h, ffn_bias_bytes() / sizeof(float));
+    stream_slot(pre + ".proj_in.weight", a.frs, 4, 0, C, C, 1.f, 4);
+  } else {
+    a.pin = linp(h, pre + ".proj_in.weight", C, C);
+  }
+  a.pin_b = f32p(h, pre + ".proj_in.bias", C);
   a.ln1g = f32p(h, tb + ".norm1.weight", C);
   a.ln1b = f32p(h, tb + ".norm1.bias", C);
-  a.w_qk = dalloc<bf16_t>(h, (size_t)2 * C * C);
-  linp(h, tb + ".attn1.to_q.weight", C, C, a.w_qk, qscale);
-  linp(h, tb + ".attn1.to_k.weight", C, C, a.w_qk + (size_t)C * C);
-  a.w_v1 = linp(h, tb + ".attn1.to_v.weight", C, C);
-  a.w_o1 = linp(h, tb + ".attn1.to_out.0.weight", C, C);
+  if (chain) {
+    stream_slot(tb + ".attn1.to_q.weight", a.frs, 4, 1, C, C, qscale, 2);
+    stream_slot(tb + ".attn1.to_k.weight", a.frs, 4, 2, C, C, 1.f, 2);
+    stream_slot(tb + ".attn1.to_v.weight", a.frs, 4, 3, C, C, 1.f, 2);
+    stream_slot(tb + ".attn1.to_out.0.weight", a.k1s, 2, 0, C, C, 1.f, 2);
+  } else {
+    a.w_qk = dalloc<bf16_t>(h, (size_t)2 * C * C);
+    linp(h, tb + ".attn1.to_q.weight", C, C, a.w_qk, qscale);
+    linp(h, tb + ".attn1.to_k.weight", C, C, a.w_qk + (size_t)C * C);
+    a.w_v1 = linp(h, tb + ".attn1.to_v.weight", C, C);
+    a.w_o1 = linp(h, tb + ".attn1.to_out.0.weight", C, C);
+  }
   a.o1_b = f32p(h, tb + ".attn1.to_out.0.bias", C);
   a.ln2g = f32p(h, tb + ".norm2.weight", C);
   a.ln2b = f32p(h, tb + ".norm2.bias", C);
-  a.w_q2 = linp(h, tb + ".attn2.to_q.weight", C, C, nullptr, qscale);
+  if (chain) stream_slot(tb + ".attn2.to_q.weight", a.k1s, 2, 1, C, C, qscale, 2);
+  else a.w_q2 = linp(h, tb + ".attn2.to_q.weight", C, C, nullptr, qscale);
   a.w_k2 = linp(h, tb + ".attn2.to_k.weight", C, ctx);
   a.w_v2 = linp(h, tb + ".attn2.to_v.weight", C, ctx);
-  const bool chain = C == ffn_fused_channels();
   if (chain) {
-    // the token-local tail of the block (attn2.to_out + residual, norm3, feed-forward, proj_out + residual) runs as one
-    // kernel (ffn.hip): the four weights go into its stream (slot kinds 5 / 7 / 8 / 9), the FF1 bias into its packed
-    // form (kind 6); none of them is kept as a GEMM operand
-    a.ffs = dalloc<bf16_t>(h, ffn_stream_bytes(1, 1) / sizeof(bf16_t));
-    a.ff1_bp = dalloc<float>(h, ffn_bias_bytes() / sizeof(float));
-    add_slot(h, tb + ".attn2.to_out.0.weight", 8, a.ffs, (size_t)C * C, C, C);
-    h->slots.back().ndim = 2; h->slots.back().dims[0] = C; h->slots.back().dims[1] = C;
+    stream_slot(tb + ".attn2.to_out.0.weight", a.ffs, 0, 0, C, C, 1.f, 2);
   } else {
     a.w_o2 = linp(h, tb + ".attn2.to_out.0.weight", C, C);
   }
@@ -184,11 +207,9 @@ Attn make_attn(hedit_unet* h, const std::string& pre, int C) {
   a.ln3g = f32p(h, tb + ".norm3.weight", C);
   a.ln3b = f32p(h, tb + ".norm3.bias", C);
   if (chain) {
-    add_slot(h, tb + ".ff.net.0.proj.weight", 5, a.ffs, (size_t)8 * C * C, 8 * C, C);
-    h->slots.back().ndim = 2; h->slots.back().dims[0] = 8 * C; h->slots.back().dims[1] = C;
+    stream_slot(tb + ".ff.net.0.proj.weight", a.ffs, 0, 1, 8 * C, C, 1.f, 2);
     add_slot(h, tb + ".ff.net.0.proj.bias", 6, a.ff1_bp, (size_t)8 * C);
-    add_slot(h, tb + ".ff.net.2.weight", 7, a.ffs, (size_t)4 * C * C, C, 4 * C);
-    h->slots.back().ndim = 2; h->slots.back().dims[0] = C; h->slots.back().dims[1] = 4 * C;
+    stream_slot(tb + ".ff.net.2.weight", a.ffs, 0, 2, C, 4 * C, 1.f, 2);
   } else {
     a.ff1 = linp(h, tb + ".ff.net.0.proj.weight", 8 * C, C);
     h->slots.back().kind = 3;
@@ -198,8 +219,7 @@ Attn make_attn(hedit_unet* h, const std::string& pre, int C) {
   }
   a.ff2_b = f32p(h, tb + ".ff.net.2.bias", C);
   if (chain) {
-    add_slot(h, pre + ".proj_out.weight", 9, a.ffs, (size_t)C * C, C, C);
-    h->slots.back().ndim = 4; h->slots.back().dims[0] = C; h->slots.back().dims[1] = C; h->slots.back().dims[2] = 1; h->slots.back().dims[3] = 1;
+    stream_slot(pre + ".proj_out.weight", a.ffs, 0, 3, C, C, 1.f, 4);
   } else {
     a.pout = linp(h, pre + ".proj_out.weight", C, C);
   }
@@ -369,20 +389,46 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   const hedit_p2p_plan* pl = (f.plan && f.plan->mode > 0) ? f.plan : nullptr;
   bf16_t *xn, *t0, *tn, *qk, *vt, *ao, *t1, *q2, *k2, *vt2, *t2, *gf, *t3, *y;
 
-  TRY(aalloc(f, &xn, M * C));
-  TRY(groupnorm(f, x, xn, a.gn_g, a.gn_b, N, C, 1e-6f, 0));
+  const bool chain = a.ffs != nullptr;
+  auto chain_prof = [&](ProfScope& ps, int layers, int tag) {
+    if (ps.rec >= 0) {
+      auto& r = f.h->prof_recs[ps.rec];
+      r.m = (int)M; r.n = C; r.k = layers * C; r.tag = tag;
+    }
+  };
   TRY(aalloc(f, &t0, M * C));
-  TRY(linear(f, xn, (int)M, C, a.pin, C, a.pin_b, nullptr, t0, C));
-  f.ar.free(xn);
-
-  // ---- self-attention
-  TRY(aalloc(f, &tn, M * C));
-  { ProfScope ps(f, PK_NORM, 0.0, 4.0 * M * C); RUN(f, layernorm_launch(t0, tn, a.ln1g, a.ln1b, (long)M, C, 1e-5f, f.st)); }
   TRY(aalloc(f, &qk, M * 2 * C));
-  TRY(linear(f, tn, (int)M, C, a.w_qk, 2 * C, nullptr, nullptr, qk, 2 * C));
   TRY(aalloc(f, &vt, M * C));
-  TRY(linear(f, a.w_v1, C, C, tn, (int)M, nullptr, nullptr, vt, (int)M, 2));   // V^T = W_v . X^T
-  f.ar.free(tn);
+  if (chain) {
+    // GroupNorm statistics, then normalisation + proj_in -> norm1 -> q | k | v^T in ONE kernel (ffn.hip): x is read once,
+    // t0 (the residual stream), q, k and v^T are written, nothing else touches HBM
+    float* ws;
+    const float* ss = nullptr;
+    TRY(aalloc(f, &ws, groupnorm_ws_bytes(B, N, C) / sizeof(float)));
+    { ProfScope ps(f, PK_NORM, 0.0, 2.0 * M * C); RUN(f, groupnorm_affine_launch(x, a.gn_g, a.gn_b, B, N, C, f.h->cfg.norm_num_groups, 1e-6f, ws, f.st, &ss)); }
+    LinChainParams lc{};
+    lc.a = x; lc.lda = C; lc.gn_ss = ss; lc.rows_per_image = N; lc.bias_pre = a.pin_b;
+    lc.gamma = a.ln1g; lc.beta = a.ln1b; lc.eps = 1e-5f; lc.stream = a.frs;
+    lc.out_mid = t0; lc.ldmid = C; lc.out_q = qk; lc.ldq = 2 * C; lc.out_k = qk + C; lc.ldk = 2 * C; lc.out = vt; lc.ldo = (long)M;
+    lc.M = (int)M; lc.C = C;
+    {
+      ProfScope ps(f, PK_LINEAR, 2.0 * M * 4.0 * C * C, 10.0 * M * C + 8.0 * C * C);      // x read; t0, q, k, v^T written; weights once
+      chain_prof(ps, 4, 129);                                                               // tag 129: GroupNorm .. q | k | v^T
+      RUN(f, lin_chain_launch(lc, f.st));
+    }
+    f.ar.free(ws);
+  } else {
+    TRY(aalloc(f, &xn, M * C));
+    TRY(groupnorm(f, x, xn, a.gn_g, a.gn_b, N, C, 1e-6f, 0));
+    TRY(linear(f, xn, (int)M, C, a.pin, C, a.pin_b, nullptr, t0, C));
+    f.ar.free(xn);
+    // ---- self-attention projections
+    TRY(aalloc(f, &tn, M * C));
+    { ProfScope ps(f, PK_NORM, 0.0, 4.0 * M * C); RUN(f, layernorm_launch(t0, tn, a.ln1g, a.ln1b, (long)M, C, 1e-5f, f.st)); }
+    TRY(linear(f, tn, (int)M, C, a.w_qk, 2 * C, nullptr, nullptr, qk, 2 * C));
+    TRY(linear(f, a.w_v1, C, C, tn, (int)M, nullptr, nullptr, vt, (int)M, 2));   // V^T = W_v . X^T
+    f.ar.free(tn);
+  }
   TRY(aalloc(f, &ao, M * C));
   {
     SelfAttnParams sp{};
@@ -398,16 +444,26 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   f.ar.free(qk);
   f.ar.free(vt);
   TRY(aalloc(f, &t1, M * C));
-  TRY(linear(f, ao, (int)M, C, a.w_o1, C, a.o1_b, t0, t1, C));
+  TRY(aalloc(f, &q2, M * C));
+  if (chain) {
+    // attn1.to_out + residual -> norm2 -> attn2.to_q in ONE kernel: t1 (the residual stream) and the query are written
+    LinChainParams lc{};
+    lc.a = ao; lc.lda = C; lc.r1 = t0; lc.ldr1 = C; lc.bias_pre = a.o1_b;
+    lc.gamma = a.ln2g; lc.beta = a.ln2b; lc.eps = 1e-5f; lc.stream = a.k1s;
+    lc.out_mid = t1; lc.ldmid = C; lc.out = q2; lc.ldo = C; lc.M = (int)M; lc.C = C;
+    ProfScope ps(f, PK_LINEAR, 2.0 * M * 2.0 * C * C, 8.0 * M * C + 4.0 * C * C);          // ao, t0 read; t1, q written
+    chain_prof(ps, 2, 130);                                                                 // tag 130: attn1.to_out .. attn2.to_q
+    RUN(f, lin_chain_launch(lc, f.st));
+  } else {
+    TRY(linear(f, ao, (int)M, C, a.w_o1, C, a.o1_b, t0, t1, C));
+    // ---- cross-attention (P2P edits + store happen inside the kernel)
+    TRY(aalloc(f, &tn, M * C));
+    { ProfScope ps(f, PK_NORM, 0.0, 4.0 * M * C); RUN(f, layernorm_launch(t1, tn, a.ln2g, a.ln2b, (long)M, C, 1e-5f, f.st)); }
+    TRY(linear(f, tn, (int)M, C, a.w_q2, C, nullptr, nullptr, q2, C));
+    f.ar.free(tn);
+  }
   f.ar.free(ao);
   f.ar.free(t0);
-
-  // ---- cross-attention (P2P edits + store happen inside the kernel)
-  TRY(aalloc(f, &tn, M * C));
-  { ProfScope ps(f, PK_NORM, 0.0, 4.0 * M * C); RUN(f, layernorm_launch(t1, tn, a.ln2g, a.ln2b, (long)M, C, 1e-5f, f.st)); }
-  TRY(aalloc(f, &q2, M * C));
-  TRY(linear(f, tn, (int)M, C, a.w_q2, C, nullptr, nullptr, q2, C));
-  f.ar.free(tn);
   const int MC = B * HEDIT_CTXP;
   TRY(aalloc(f, &k2, (size_t)MC * C));
   TRY(linear(f, f.ctxb, MC, ctx_dim, a.w_k2, C, nullptr, nullptr, k2, C));
@@ -434,7 +490,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   f.ar.free(q2);
   f.ar.free(k2);
   f.ar.free(vt2);
-  if (a.ffs) {
+  if (chain) {
     // attn2.to_out + residual -> LayerNorm -> FF1 -> GEGLU -> FF2 + residual -> proj_out + residual in ONE kernel: rows in
     // registers, weights streamed (ffn.hip).  The result goes where proj_out's would (dst / ldd: the next concatenation).
     if (dst) {
@@ -449,10 +505,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
     fp.stream = a.ffs; fp.bias1p = a.ff1_bp; fp.bias2 = a.ff2_b; fp.out = y; fp.ldo = dst ? ldd : C; fp.M = (int)M; fp.C = C;
     {
       ProfScope ps(f, PK_LINEAR, 2.0 * M * 14.0 * C * C, 8.0 * M * C + 28.0 * C * C);      // a, t1, x read, out written; weights once
-      if (ps.rec >= 0) {
-        auto& r = f.h->prof_recs[ps.rec];
-        r.m = (int)M; r.n = C; r.k = 14 * C; r.tag = 128;     // tag 128: the fused block tail
-      }
+      chain_prof(ps, 14, 128);                                                              // tag 128: the fused block tail
       RUN(f, ffn_fused_launch(fp, f.st));
     }
     f.ar.free(ao);
@@ -807,7 +860,7 @@ int hedit_unet_param_shape(const hedit_unet* h, int i, int* ndim, int* dims4) tr
 int hedit_unet_param_bf16_exact(const hedit_unet* h, int i) try {
   if (!h || i < 0 || i >= (int)h->slots.size()) return 0;
   const Slot& s = h->slots[i];
-  return ((s.kind == 1 && s.scale == 1.f) || s.kind == 2 || s.kind == 3 || s.kind == 5 || s.kind >= 7) ? 1 : 0;
+  return (((s.kind == 1 || s.kind == 7) && s.scale == 1.f) || s.kind == 2 || s.kind == 3 || s.kind == 5) ? 1 : 0;
 } catch (...) { (void)hedit_abi_catch(); return 0; }
 
 int hedit_unet_load(hedit_unet* h, const char* name, const float* w, size_t numel, void* stream) try {
@@ -832,15 +885,11 @@ int hedit_unet_load(hedit_unet* h, const char* name, const float* w, size_t nume
   } else if (s.kind == 4) {
     TRY(pack_geglu_rows_launch(w, nullptr, reinterpret_cast<float*>(s.dst), (int)numel, 1, st));
   } else if (s.kind == 5) {
-    TRY(ffn_pack_launch(w, 1, 1, 1, reinterpret_cast<bf16_t*>(s.dst), st));
+    TRY(ffn_pack_launch(w, s.which, 1, 1, reinterpret_cast<bf16_t*>(s.dst), st));
   } else if (s.kind == 6) {
     TRY(ffn_pack_bias_launch(w, reinterpret_cast<float*>(s.dst), st));
   } else if (s.kind == 7) {
-    TRY(ffn_pack_launch(w, 2, 1, 1, reinterpret_cast<bf16_t*>(s.dst), st));
-  } else if (s.kind == 8) {
-    TRY(ffn_pack_launch(w, 0, 1, 1, reinterpret_cast<bf16_t*>(s.dst), st));
-  } else if (s.kind == 9) {
-    TRY(ffn_pack_launch(w, 3, 1, 1, reinterpret_cast<bf16_t*>(s.dst), st));
+    TRY(lin_chain_pack_launch(w, s.which, s.scale, s.lay, reinterpret_cast<bf16_t*>(s.dst), st));
   } else {
     TRY(pack_conv3x3_launch(w, reinterpret_cast<bf16_t*>(s.dst), s.O, s.I, st));
   }

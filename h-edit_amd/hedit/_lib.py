@@ -160,6 +160,13 @@ _SIGS = {
     "hedit_k_pack_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "hedit_k_gemm_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p]),
+    "hedit_k_lin_chain_stream_bytes": (C.c_size_t, [C.c_int]),
+    "hedit_k_lin_chain_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "hedit_k_lin_chain": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "hedit_k_groupnorm_affine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
     "hedit_k_ffn_channels": (C.c_int, []),
     "hedit_k_ffn_stream_bytes": (C.c_size_t, [C.c_int]),
     "hedit_k_ffn_bias_bytes": (C.c_size_t, []),

@@ -287,7 +287,24 @@ int hedit_k_ffn_fused(const void* x, int64_t ldx, const float* gamma, const floa
 int hedit_k_ffn_chain(const void* a, int64_t lda, const void* t1, int64_t ldt1, const void* x, int64_t ldx, const float* bias_pre,
                       const float* gamma, const float* beta, float eps, const void* w_stream, const float* bias1_packed,
                       const float* bias2, const float* bias_post, void* out, int64_t ldo, int M, int C, void* stream);
+/* The projections around an attention of the same level in one launch (csrc/ffn.hip), two forms:
+ *   n_out = 1 (gn_ss == NULL):  mid = attn1.to_out.0(a) + r1 (written to out_mid);  out[M][C] = attn2.to_q( norm2(mid) )
+ *   n_out = 3 (gn_ss set):      mid = proj_in( a * scale + shift ) (GroupNorm applied on the fly; written to out_mid);
+ *                               q, k = attn1.to_q / to_k ( norm1(mid) ) -> out_q, out_k;  out[C][ldo] = attn1.to_v(norm1(mid))^T
+ *   (oracle/sd_unet.py: Transformer2DModel.norm / proj_in and BasicTransformerBlock attn1 / attn2 projections).
+ * hedit_k_lin_chain_pack: checkpoint tensors [C][C] (fp32, device) -> weight stream; scale0 multiplies w0 (the softmax
+ * scale folded into the query projection); w1, w2: both (n_out = 3) or neither.
+ * hedit_k_groupnorm_affine: ss_out [B][C][2] = (scale, shift) per image and channel of GroupNorm(x). */
+size_t hedit_k_lin_chain_stream_bytes(int n_out);
+int hedit_k_lin_chain_pack(const float* w_pre, const float* w0, const float* w1, const float* w2, float scale0, void* stream_out,
+                           void* stream);
+int hedit_k_lin_chain(const void* a, int64_t lda, const void* r1, int64_t ldr1, const float* gn_ss, int rows_per_image,
+                      const float* bias_pre, const float* gamma, const float* beta, float eps, const void* w_stream, void* out_mid,
+                      int64_t ldmid, void* out_q, int64_t ldq, void* out_k, int64_t ldk, void* out, int64_t ldo, int M, int C,
+                      void* stream);
 size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C);
+int hedit_k_groupnorm_affine(const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, void* ws,
+                             float* ss_out, void* stream);
 int hedit_k_groupnorm(const void* x, void* y, const float* gamma, const float* beta, int B, int HW,
                       int C, int G, float eps, int silu, void* ws, void* stream);
 int hedit_k_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows,

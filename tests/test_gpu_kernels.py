@@ -242,6 +242,94 @@ def test_ffn_fused_rows_are_independent_and_repeatable(lib):
     assert torch.equal(full[-1:], one)
 
 
+@pytest.mark.parametrize("M", [128, 4096 + 77, 3 * 4096, 11 * 4096 + 5])     # (the last: more tiles than CUs, several per block)
+def test_lin_chain_out_then_query(lib, M):
+    """attn1.to_out + residual -> norm2 -> attn2.to_q in one kernel (csrc/ffn.hip, hedit_k_lin_chain, one output) == the
+    three layers in fp32 on the bf16-rounded operands (diffusers BasicTransformerBlock, oracle/sd_unet.py); both results
+    (the residual stream and the query) are functions of their own row alone, bit for bit."""
+    Cc = lib.hedit_k_ffn_channels()
+    g = torch.Generator().manual_seed(31 + M)
+    a = G.bf(torch.randn(M, Cc, generator=g))
+    r1 = G.bf(torch.randn(M, Cc, generator=g) * 1.5 + 0.2)
+    gamma, beta = G.f32(1 + 0.1 * torch.randn(Cc, generator=g)), G.f32(0.1 * torch.randn(Cc, generator=g))
+    wo = G.f32(torch.randn(Cc, Cc, generator=g) / math.sqrt(Cc))
+    bo = G.f32(torch.randn(Cc, generator=g) * 0.3)
+    wq = G.f32(torch.randn(Cc, Cc, generator=g) / math.sqrt(Cc))
+    scale = 0.2281
+    ws = torch.empty(lib.hedit_k_lin_chain_stream_bytes(1), dtype=torch.uint8, device=G.dev())
+    _lib.check(lib.hedit_k_lin_chain_pack(_lib.ptr(wo), _lib.ptr(wq), None, None, scale, _lib.ptr(ws), None))
+
+    def run(a_, r1_):
+        m = a_.shape[0]
+        mid = torch.zeros(m, Cc, dtype=torch.bfloat16, device=G.dev())
+        q = torch.zeros(m, Cc, dtype=torch.bfloat16, device=G.dev())
+        _lib.check(lib.hedit_k_lin_chain(_lib.ptr(a_), Cc, _lib.ptr(r1_), Cc, None, 0, _lib.ptr(bo), _lib.ptr(gamma), _lib.ptr(beta), 1e-5,
+                                         _lib.ptr(ws), _lib.ptr(mid), Cc, None, 0, None, 0, _lib.ptr(q), Cc, m, Cc, None))
+        G.sync()
+        return mid, q
+    mid, q = run(a, r1)
+    bfr = lambda t: t.to(torch.bfloat16).float()
+    t1 = a.float() @ bfr(wo).t() + bo + r1.float()
+    want_q = bfr(F.layer_norm(t1, (Cc,), gamma, beta, 1e-5)) @ bfr(wq * scale).t()
+    assert torch.isfinite(q.float()).all()
+    assert G.rel_err(mid.float(), t1) < 3e-3
+    assert G.rel_err(q.float(), want_q) < 6e-3
+    mid2, q2 = run(a, r1)
+    assert torch.equal(mid, mid2) and torch.equal(q, q2)
+    lo = min(M - 1, 100)
+    mid3, q3 = run(a[lo:].contiguous(), r1[lo:].contiguous())
+    assert torch.equal(mid3, mid[lo:]) and torch.equal(q3, q[lo:])
+
+
+@pytest.mark.parametrize("B,N", [(1, 128), (3, 1024), (2, 4096), (11, 4096)])
+def test_lin_chain_groupnorm_to_qkv(lib, B, N):
+    """GroupNorm (applied on the fly) -> proj_in -> norm1 -> attn1.to_q | to_k | to_v^T in one kernel (hedit_k_lin_chain,
+    three outputs; Transformer2DModel.norm / proj_in and the self-attention projections, oracle/sd_unet.py) == the layers
+    in fp32 on the bf16-rounded operands; q and k go into one [M][2C] buffer, v comes out transposed ([C][M])."""
+    Cc = lib.hedit_k_ffn_channels()
+    M = B * N
+    g = torch.Generator().manual_seed(41 + M)
+    x = G.bf(torch.randn(B, N, Cc, generator=g) * 1.3 + 0.4 * torch.randn(1, 1, Cc, generator=g))
+    gn_g, gn_b = G.f32(1 + 0.1 * torch.randn(Cc, generator=g)), G.f32(0.1 * torch.randn(Cc, generator=g))
+    gamma, beta = G.f32(1 + 0.1 * torch.randn(Cc, generator=g)), G.f32(0.1 * torch.randn(Cc, generator=g))
+    w_in = G.f32(torch.randn(Cc, Cc, generator=g) / math.sqrt(Cc))
+    b_in = G.f32(torch.randn(Cc, generator=g) * 0.3)
+    wq, wk, wv = (G.f32(torch.randn(Cc, Cc, generator=g) / math.sqrt(Cc)) for _ in range(3))
+    scale = 0.2281
+    ws = torch.empty(lib.hedit_k_lin_chain_stream_bytes(3), dtype=torch.uint8, device=G.dev())
+    _lib.check(lib.hedit_k_lin_chain_pack(_lib.ptr(w_in), _lib.ptr(wq), _lib.ptr(wk), _lib.ptr(wv), scale, _lib.ptr(ws), None))
+    gws = torch.empty(lib.hedit_k_groupnorm_ws_bytes(B, N, Cc), dtype=torch.uint8, device=G.dev())
+
+    def run(x_):
+        b = x_.shape[0]
+        m = b * N
+        ss = torch.empty(b, Cc, 2, dtype=torch.float32, device=G.dev())
+        _lib.check(lib.hedit_k_groupnorm_affine(_lib.ptr(x_), _lib.ptr(gn_g), _lib.ptr(gn_b), b, N, Cc, 32, 1e-6, _lib.ptr(gws), _lib.ptr(ss), None))
+        mid = torch.zeros(m, Cc, dtype=torch.bfloat16, device=G.dev())
+        qk = torch.zeros(m, 2 * Cc, dtype=torch.bfloat16, device=G.dev())
+        vt = torch.zeros(Cc, m, dtype=torch.bfloat16, device=G.dev())
+        _lib.check(lib.hedit_k_lin_chain(_lib.ptr(x_), Cc, None, 0, _lib.ptr(ss), N, _lib.ptr(b_in), _lib.ptr(gamma), _lib.ptr(beta), 1e-5,
+                                         _lib.ptr(ws), _lib.ptr(mid), Cc, _lib.ptr(qk), 2 * Cc, qk.data_ptr() + 2 * Cc, 2 * Cc,
+                                         _lib.ptr(vt), m, m, Cc, None))
+        G.sync()
+        return mid, qk, vt
+    mid, qk, vt = run(x)
+    bfr = lambda t: t.to(torch.bfloat16).float()
+    xf = x.float()
+    xg = F.group_norm(xf.transpose(1, 2), 32, gn_g, gn_b, 1e-6).transpose(1, 2).reshape(M, Cc)
+    t0 = bfr(xg) @ bfr(w_in).t() + b_in
+    tn = bfr(F.layer_norm(t0, (Cc,), gamma, beta, 1e-5))
+    assert G.rel_err(mid.float(), t0) < 6e-3
+    assert G.rel_err(qk[:, :Cc].float(), tn @ bfr(wq * scale).t()) < 8e-3
+    assert G.rel_err(qk[:, Cc:].float(), tn @ bfr(wk).t()) < 8e-3
+    assert G.rel_err(vt.float().t(), tn @ bfr(wv).t()) < 8e-3
+    again = run(x)
+    assert all(torch.equal(u, v) for u, v in zip((mid, qk, vt), again))
+    if B > 1:                      # an image alone == the image inside the batch
+        m1, qk1, vt1 = run(x[1:2].contiguous())
+        assert torch.equal(m1, mid[N:2 * N]) and torch.equal(qk1, qk[N:2 * N]) and torch.equal(vt1, vt[:, N:2 * N])
+
+
 @pytest.mark.parametrize("M", [128, 4096 + 77, 3 * 4096])
 def test_ffn_chain(lib, M):
     """The token-local tail of a transformer block in one kernel (csrc/ffn.hip): attn2.to_out + residual -> norm3 ->

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Kernel trace of the face workload (configs[3]) restricted to the loop: per-kernel table, busy / span, and where the
+# idle time between dispatches sits.  tools/face_trace.sh [faces]   -> gpurun_out/r03/face_*  (run on the GPU box)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r03
+N=${1:-32}
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/p_face -o trace -- python $R/bench.py --workload face --images $N --steps 1 --warmup 1 --diffusion-steps 20 > $O/bench_face_n${N}_under_rocprof.json 2> $O/rocprof_face.err
+db=$(find /tmp/p_face -name "*.db" | head -1)
+if [ -n "$db" ]; then
+  python $R/tools/rocpd_stats.py $db --loop > $O/face_n${N}_kernel_stats.txt
+  python $R/tools/rocpd_stats.py $db --loop --gaps > $O/face_n${N}_gaps.txt
+  head -12 $O/face_n${N}_kernel_stats.txt; head -45 $O/face_n${N}_gaps.txt
+fi
+rm -rf /tmp/p_face

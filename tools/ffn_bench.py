@@ -84,6 +84,55 @@ def chain_unfused():
     _lib.check(lib.hedit_k_gemm(_lib.ptr(out_k), _lib.ptr(wpb), _lib.ptr(bo), _lib.ptr(x), _lib.ptr(out_ck), M, C, C, C, C, C, 0, 0, 0, 0, 0, 0, 1, None, None))
 
 
+# ---- the projection chains around the two attentions
+wq, wk, wv = ((torch.randn(C, C, generator=g) / math.sqrt(C)).to(dev) for _ in range(3))
+wqb, wvb = wq.to(torch.bfloat16).contiguous(), wv.to(torch.bfloat16).contiguous()
+wqkb = torch.cat([wq, wk], 0).to(torch.bfloat16).contiguous()
+ws2 = torch.empty(lib.hedit_k_lin_chain_stream_bytes(1), dtype=torch.uint8, device=dev)
+_lib.check(lib.hedit_k_lin_chain_pack(_lib.ptr(wo), _lib.ptr(wq), None, None, 1.0, _lib.ptr(ws2), None))
+ws4 = torch.empty(lib.hedit_k_lin_chain_stream_bytes(3), dtype=torch.uint8, device=dev)
+_lib.check(lib.hedit_k_lin_chain_pack(_lib.ptr(wo), _lib.ptr(wq), _lib.ptr(wk), _lib.ptr(wv), 1.0, _lib.ptr(ws4), None))
+mid = torch.empty_like(x); q_c = torch.empty_like(x); q_k = torch.empty_like(x)
+qk_c = torch.empty(M, 2 * C, dtype=torch.bfloat16, device=dev); qk_k = torch.empty_like(qk_c)
+vt_c = torch.empty(C, M, dtype=torch.bfloat16, device=dev); vt_k = torch.empty_like(vt_c)
+gws = torch.empty(lib.hedit_k_groupnorm_ws_bytes(rows, 4096, C), dtype=torch.uint8, device=dev)
+ss = torch.empty(rows, C, 2, dtype=torch.float32, device=dev)
+
+
+def lin2():
+    _lib.check(lib.hedit_k_lin_chain(_lib.ptr(a_in), C, _lib.ptr(t1), C, None, 0, _lib.ptr(bo), _lib.ptr(gamma), _lib.ptr(beta), 1e-5,
+                                     _lib.ptr(ws2), _lib.ptr(mid), C, None, 0, None, 0, _lib.ptr(q_c), C, M, C, None))
+
+
+def lin2_unfused():
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(a_in), _lib.ptr(wob), _lib.ptr(bo), _lib.ptr(t1), _lib.ptr(t2), M, C, C, C, C, C, 0, 0, 0, 0, 0, 0, 1, None, None))
+    _lib.check(lib.hedit_k_layernorm(_lib.ptr(t2), _lib.ptr(xn), _lib.ptr(gamma), _lib.ptr(beta), M, C, 1e-5, None))
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(xn), _lib.ptr(wqb), None, None, _lib.ptr(q_k), M, C, C, C, C, 0, 0, 0, 0, 0, 0, 0, 1, None, None))
+
+
+def lin4():
+    _lib.check(lib.hedit_k_groupnorm_affine(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), rows, 4096, C, 32, 1e-6, _lib.ptr(gws), _lib.ptr(ss), None))
+    _lib.check(lib.hedit_k_lin_chain(_lib.ptr(x), C, None, 0, _lib.ptr(ss), 4096, _lib.ptr(bo), _lib.ptr(gamma), _lib.ptr(beta), 1e-5,
+                                     _lib.ptr(ws4), _lib.ptr(mid), C, _lib.ptr(qk_c), 2 * C, qk_c.data_ptr() + 2 * C, 2 * C,
+                                     _lib.ptr(vt_c), M, M, C, None))
+
+
+def lin4_unfused():
+    _lib.check(lib.hedit_k_groupnorm(_lib.ptr(x), _lib.ptr(out_k), _lib.ptr(gamma), _lib.ptr(beta), rows, 4096, C, 32, 1e-6, 0, _lib.ptr(gws), None))
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(out_k), _lib.ptr(wob), _lib.ptr(bo), None, _lib.ptr(t2), M, C, C, C, C, 0, 0, 0, 0, 0, 0, 0, 1, None, None))
+    _lib.check(lib.hedit_k_layernorm(_lib.ptr(t2), _lib.ptr(xn), _lib.ptr(gamma), _lib.ptr(beta), M, C, 1e-5, None))
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(xn), _lib.ptr(wqkb), None, None, _lib.ptr(qk_k), M, 2 * C, C, C, 2 * C, 0, 0, 0, 0, 0, 0, 0, 1, None, None))
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(wvb), _lib.ptr(xn), None, None, _lib.ptr(vt_k), C, M, C, C, M, 0, 0, 0, 0, 0, 0, 0, 1, None, None))
+
+
+rel = lambda u, v: ((u.float() - v.float()).norm() / v.float().norm()).item()
+t2f, t2u = timeit(lin2), timeit(lin2_unfused)
+print(f"rows {rows}: to_out + norm + to_q fused {t2f * 1e3:.1f} us = {2.0 * M * 2 * C * C / t2f / 1e9:.0f} TF/s | three launches {t2u * 1e3:.1f} us | "
+      f"speed-up {t2u / t2f:.2f} | rel diff {rel(q_c, q_k):.2e}")
+t4f, t4u = timeit(lin4), timeit(lin4_unfused)
+print(f"rows {rows}: GroupNorm + proj_in + norm + q|k|v^T fused {t4f * 1e3:.1f} us = {2.0 * M * 4 * C * C / t4f / 1e9:.0f} TF/s | unfused {t4u * 1e3:.1f} us | "
+      f"speed-up {t4u / t4f:.2f} | rel diff qk {rel(qk_c, qk_k):.2e} v^T {rel(vt_c, vt_k):.2e}")
+
 flops = 2.0 * M * 12 * C * C
 tc, tcu = timeit(chain), timeit(chain_unfused)
 errc = ((out_c.float() - out_ck.float()).norm() / out_ck.float().norm()).item()
