@@ -60,7 +60,7 @@ static_assert(LNB + 2 >= LEAD && LEAD <= LNB, "the read-ahead reaches into the n
 __host__ __device__ constexpr int stream_iters(int layers) { return layers * LKS; }
 // input feature (inside its group of 16) held by accumulator register r (0..7) of lane half hi
 __host__ __device__ inline int lin_unit_of_reg(int r, int hi) { return (r >> 2) * 8 + hi * 4 + (r & 3); }
-__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+__host__ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
 __global__ __launch_bounds__(256) void lin_pack_kernel(const float* __restrict__ w, int layer, float scale, int layers, bf16_t* __restrict__ stream) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -106,6 +106,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 __device__ __forceinline__ void mfma_l(f32x16& acc, const bf16x8& w, const bf16x8& a) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "a"(a));
 }
+// first k-step of a layer: C = 0 (inline constant)
+__device__ __forceinline__ void mfma_l0(f32x16& acc, const bf16x8& w, const bf16x8& a) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(acc) : "v"(w), "a"(a));
+}
 
 // NPOST: layers behind the LayerNorm (1 or 3).  GNIN: the first layer's input is GroupNorm'd on the fly and there is no
 // residual.  VT: the last result is written transposed.
@@ -135,15 +139,14 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
   float* const par = reinterpret_cast<float*>(smem + PAR_OFF);      // gamma | beta | bias_pre
 
 #if defined(__HIP_DEVICE_COMPILE__)
+  // inputs through bounds-checked descriptors: rows beyond M read as zeros
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.stream), (short)0, (int)(NIT * IT_BYTES), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.a), (short)0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(GNIN ? p.a : p.r1), (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.a), (short)0, (int)((long)p.M * p.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(GNIN ? p.a : p.r1), (short)0,
+                                                                        (int)((long)p.M * (GNIN ? p.lda : p.ldr1) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_ss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GNIN ? p.gn_ss : p.gamma), (short)0,
-                                                                         GNIN ? (int)(((p.M + p.rows_per_image - 1) / (GNIN ? p.rows_per_image : 1)) * LC * 8) : 16, 0x00020000);
+                                                                         GNIN ? (int)((p.M / (GNIN ? p.rows_per_image : 1)) * LC * 8) : 16, 0x00020000);
 #endif
-  // (the address arithmetic of the tile I/O is redone where it is used -- an opaque copy of the lane id per use -- instead
-  //  of living in ~150 registers across the whole tile loop, where the compiler would hoist it to)
-  auto fresh = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
   // weight DMA: piece k (0..2) of this wave for stream iteration `sit` -> ring bank `bank`: 1 KB piece q = wave + 4 k of the
   // iteration's ten (q = 10, 11 re-load piece 9: same bytes, same place)
   const int q2 = wave + 8 > 9 ? 9 : wave + 8;
@@ -157,24 +160,39 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
     (void)sit; (void)bank; (void)k;
 #endif
   };
-  // row DMA: the wave's 32 rows of a tile -> its staging area, 20 instructions of 64 consecutive 16-byte slots; slot s of
-  // row r holds chunk s ^ swz(r) (the XOR stays inside a group of eight chunks = one 128-byte line)
+  // ---- the tile I/O goes through the wave's staging area as 20 pieces of 64 consecutive 16-byte slots; slot s of row r
+  // holds chunk s ^ swz(r) (the XOR stays inside a group of eight chunks = one 128-byte line).  Per piece i this lane's
+  // slot is (row pr[i], byte pc[i] inside the row): the global offset of a piece is row * ld + pc, for loads and stores.
   char* const stage = smem + STAGE_OFF + wave * STAGE_BYTES;
   constexpr int ROW_DMAS = 32 * CPR / 64;
   static_assert(32 * CPR % 64 == 0, "rows must divide evenly over the lanes");
+  int prc[ROW_DMAS];                 // row << 16 | byte inside the row
+#pragma unroll
+  for (int i = 0; i < ROW_DMAS; ++i) {
+    const int s = i * 64 + lane;
+    const int r = s / CPR;
+    prc[i] = (r << 16) | (((s - r * CPR) ^ swz(r)) * 16);
+  }
+  auto piece_off = [&](int i, int ld2) __attribute__((always_inline)) { return (unsigned)((prc[i] >> 16) * ld2 + (prc[i] & 0xffff)); };
+  // (the row stride as an opaque value per use: otherwise the compiler computes the 20 offsets of every load / store site
+  //  once, in front of the tile loop, and keeps ~100 registers' worth of them in scratch)
+  auto opaque = [](int v) __attribute__((always_inline)) { asm volatile("" : "+s"(v)); return v; };
+  // this lane's own row in the staging area: the eight 16-byte slots of a 128-byte line in swizzled order (+ the lane
+  // half's 8 bytes: accumulator layout), and the four slot pairs the fragment reads cycle through
+  int slot8[8], slotx[4];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) slot8[k] = STAGE_OFF + wave * STAGE_BYTES + lm * ROW_BYTES + ((k ^ swz(lm)) * 16) + hi * 8;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) slotx[k] = STAGE_OFF + wave * STAGE_BYTES + lm * ROW_BYTES + (((2 * k + hi) ^ swz(lm)) * 16);
+
   auto stage_rows = [&](auto res_c, long ld, int tile) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int m0 = tile * BLOCK_ROWS + wave * 32;
-    const int ln = fresh(lane);
+    const int soff = (int)((long)(tile * BLOCK_ROWS + wave * 32) * ld * 2);
+    const int ld2 = opaque((int)ld * 2);
 #pragma unroll
-    for (int i = 0; i < ROW_DMAS; ++i) {
-      const int s = i * 64 + ln;
-      const int r = s / CPR, slot = s - r * CPR;
-      int row = m0 + r;
-      if (row > p.M - 1) row = p.M - 1;
-      const unsigned voff = (unsigned)((long)row * ld * 2 + ((slot ^ swz(r)) * 16));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(decltype(res_c)::value ? rs_r : rs_a, (__attribute__((address_space(3))) void*)(stage + i * 1024), 16, voff, 0, 0, 0);
-    }
+    for (int i = 0; i < ROW_DMAS; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(decltype(res_c)::value ? rs_r : rs_a, (__attribute__((address_space(3))) void*)(stage + i * 1024), 16,
+                                               piece_off(i, ld2), soff, 0, 0);
 #else
     (void)ld; (void)tile;
 #endif
@@ -204,24 +222,17 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
   // O[nb][4 q + j] of lane (lm, hi) = feature 32 nb + 8 q + 4 hi + j of row lm  (32x32 MFMA result layout)
   f32x16 O[LNB];
   bf16x8 Xn[LKS];        // lane (row lm, half hi): activation fragment of k-step ks (8 consecutive k, or 8 registers of O)
-  // (see ffn.hip) accumulators readable by the VALU behind asm MFMAs / VALU-written registers in front of asm MFMAs
+  // (see ffn.hip) the accumulators become readable by the VALU behind asm MFMAs
   auto settle = [&]() __attribute__((always_inline)) {
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
 #pragma unroll
     for (int nb = 0; nb < LNB; ++nb) asm volatile("" : "+a"(O[nb]));
   };
-  auto publish = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int nb = 0; nb < LNB; ++nb) asm volatile("" : "+a"(O[nb]));
-    asm volatile("s_nop 3" ::: "memory");
-  };
   // the first layer's fragments from the staged input rows (GNIN: x * scale + shift on the way)
   auto read_xn = [&]() __attribute__((always_inline)) {
-    const int lmf = fresh(lm);
-    const int my_row = lmf * ROW_BYTES, my_swz = swz(lmf);
 #pragma unroll
     for (int ks = 0; ks < LKS; ++ks) {
-      u32x4 raw = *reinterpret_cast<const u32x4*>(stage + my_row + (((2 * ks + hi) ^ my_swz) * 16));
+      u32x4 raw = *reinterpret_cast<const u32x4*>(smem + slotx[ks & 3] + (ks >> 2) * 128);
       if constexpr (GNIN) {
         float x[8];
 #pragma unroll
@@ -240,27 +251,12 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
       Xn[ks] = __builtin_bit_cast(bf16x8, raw);
       asm volatile("" : "+a"(Xn[ks]));       // home in the AGPR file from here on (every use is an MFMA operand)
     }
-  };
-  auto bias_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int nb = 0; nb < LNB; ++nb) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(par + 2 * LC + nb * 32 + q * 8 + hi * 4);
-        O[nb][4 * q] = bb[0]; O[nb][4 * q + 1] = bb[1]; O[nb][4 * q + 2] = bb[2]; O[nb][4 * q + 3] = bb[3];
-      }
-      asm volatile("" : "+a"(O[nb]));
-    }
-  };
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int nb = 0; nb < LNB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) O[nb][r] = 0.f;
+    asm volatile("s_nop 3" ::: "memory");    // (VALU-written fragments in front of asm MFMAs)
   };
 
   // ---- one iteration = ten bundles of [MFMA | a fragment read LEAD MFMAs ahead (the last LEAD fetch the first fragments
-  // of the next iteration; not across layers) | three of them a DMA piece], pinned by sched_barrier.  At the iteration
+  // of the next iteration; not across layers) | three of them a DMA piece], pinned by sched_barrier.  The first iteration
+  // of a layer starts the accumulators from the inline constant 0 (nobody writes 160 zeros).  At the iteration
   // boundary: [my pieces of iteration it + 2 have landed: vmcnt(the newest AHEAD - 2 iterations, + the burst in front of
   // the layer while it is younger than that)] [my reads of the iteration just finished have returned: lgkmcnt(the LEAD
   // newest = next iteration's)] barrier; the finished bank is refilled next.
@@ -291,7 +287,8 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
           constexpr int newer = (ks + 1 < LKS ? b + LEAD - 1 : (b + LEAD - 1 < LNB - 1 ? b + LEAD - 1 : LNB - 1)) - (b + 2);
           __builtin_amdgcn_s_waitcnt(0xC07F | ((newer > 0 ? newer : 0) << 8));
         }
-        mfma_l(O[b], fr[b], Xn[ks]);
+        if constexpr (ks == 0) mfma_l0(O[b], fr[b], Xn[ks]);
+        else mfma_l(O[b], fr[b], Xn[ks]);
         if constexpr (b + LEAD < LNB) fr[b + LEAD] = *reinterpret_cast<const bf16x8*>(smem + base + (b + LEAD) * 1024);
         else if constexpr (ks + 1 < LKS) pre[b + LEAD - LNB] = *reinterpret_cast<const bf16x8*>(smem + nbase + (b + LEAD - LNB) * 1024);
         if constexpr (b % 3 == 1) dma_piece(dit, pbank, b / 3);
@@ -306,14 +303,33 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
       frag_rd = nbase;
     });
   };
-  // bf16(O) -> the wave's staging area (swizzled like the inputs) -> whole-row pieces -> 16-byte coalesced stores:
-  // ROW_DMAS bounds-checked buffer stores, issued for every tile alike (rows beyond M fall outside the buffer)
-  auto store_rows = [&](bf16_t* dst, long ld, int tile) __attribute__((always_inline)) {
+  // the staged result -> whole-row pieces -> 16-byte coalesced stores: ROW_DMAS bounds-checked buffer stores, issued for
+  // every tile alike (rows beyond M fall outside the buffer)
+  auto flush_rows = [&](bf16_t* dst, long ld, int tile) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(dst, (short)0, (int)((((long)p.M - 1) * ld + LC) * 2), 0x00020000);
+    const int soff = (int)((long)(tile * BLOCK_ROWS + wave * 32) * ld * 2);
+    const int ld2 = opaque((int)ld * 2);
 #endif
-    const int lmf = fresh(lm), ln = fresh(lane);
-    const int my_row = lmf * ROW_BYTES, my_swz = swz(lmf);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (a wave reads back only what it wrote itself)
+    constexpr int GRP = 5;
+#pragma unroll
+    for (int i0 = 0; i0 < ROW_DMAS; i0 += GRP) {
+      u32x4 ov[GRP];
+#pragma unroll
+      for (int i = 0; i < GRP; ++i) ov[i] = *reinterpret_cast<const u32x4*>(stage + (i0 + i) * 1024 + lane * 16);
+#pragma unroll
+      for (int i = 0; i < GRP; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_o, piece_off(i0 + i, ld2), soff, 0);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the staging area may be overwritten from here on
+  };
+  // bf16(O) -> the wave's staging area (swizzled like the inputs) -> stores
+  auto store_rows = [&](bf16_t* dst, long ld, int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int nb = 0; nb < LNB; ++nb)
 #pragma unroll
@@ -321,33 +337,14 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
         u32x2 o;
         o[0] = pack_bf16x2(O[nb][4 * q], O[nb][4 * q + 1]);
         o[1] = pack_bf16x2(O[nb][4 * q + 2], O[nb][4 * q + 3]);
-        *reinterpret_cast<u32x2*>(stage + my_row + (((nb * 4 + q) ^ my_swz) * 16) + hi * 8) = o;
+        *reinterpret_cast<u32x2*>(smem + slot8[(nb * 4 + q) & 7] + ((nb * 4 + q) >> 3) * 128) = o;
       }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (a wave reads back only what it wrote itself)
-    const int m0 = tile * BLOCK_ROWS + wave * 32;
-    constexpr int GRP = 5;
-#pragma unroll
-    for (int i0 = 0; i0 < ROW_DMAS; i0 += GRP) {
-      u32x4 ov[GRP];
-#pragma unroll
-      for (int i = 0; i < GRP; ++i) ov[i] = *reinterpret_cast<const u32x4*>(stage + ((i0 + i) * 64 + ln) * 16);
-#pragma unroll
-      for (int i = 0; i < GRP; ++i) {
-        const int s = (i0 + i) * 64 + ln;
-        const int r = s / CPR, slot = s - r * CPR;
-#if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_o, (unsigned)(((long)(m0 + r) * ld + (slot ^ swz(r)) * 8) * 2), 0, 0);
-#endif
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the staging area may be overwritten from here on
+    flush_rows(dst, ld, tile);
   };
   // the same for the transposed result: [320 features][32 rows] per wave (64 bytes per feature; features permuted inside
   // their groups of eight so that the two lane halves, four features apart, write different bank halves), then per
   // feature 64 contiguous bytes of the [C][M] result as four 16-byte stores
   auto store_rows_t = [&](bf16_t* dst, long ld, int tile) __attribute__((always_inline)) {
-    const int lmf = fresh(lm), ln = fresh(lane);
 #pragma unroll
     for (int nb = 0; nb < LNB; ++nb)
 #pragma unroll
@@ -355,23 +352,29 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
         const int f = nb * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
         const int x = f & 7;
         const int slot = (f & ~7) + (x < 4 ? x : 4 + ((x + 1) & 3));
-        *reinterpret_cast<bf16_t*>(stage + slot * 64 + lmf * 2) = (bf16_t)(pack_bf16x2(O[nb][r], 0.f) & 0xffffu);
+        *reinterpret_cast<bf16_t*>(stage + slot * 64 + lm * 2) = (bf16_t)(pack_bf16x2(O[nb][r], 0.f) & 0xffffu);
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int m0 = tile * BLOCK_ROWS + wave * 32;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(dst, (short)0, (int)((long)LC * ld * 2), 0x00020000);
+    const int soff = (tile * BLOCK_ROWS + wave * 32) * 2;
+    const int ld2 = opaque((int)ld * 2);
+#endif
     constexpr int GRP = 5;
 #pragma unroll
     for (int i0 = 0; i0 < ROW_DMAS; i0 += GRP) {
       u32x4 ov[GRP];
 #pragma unroll
-      for (int i = 0; i < GRP; ++i) ov[i] = *reinterpret_cast<const u32x4*>(stage + ((i0 + i) * 64 + ln) * 16);
+      for (int i = 0; i < GRP; ++i) ov[i] = *reinterpret_cast<const u32x4*>(stage + (i0 + i) * 1024 + lane * 16);
 #pragma unroll
       for (int i = 0; i < GRP; ++i) {
-        const int s = (i0 + i) * 64 + ln;
+        const int s = (i0 + i) * 64 + lane;
         const int slot = s >> 2, part = s & 3;
         const int y = slot & 7;
         const int f = (slot & ~7) + (y < 4 ? y : 4 + ((y + 3) & 3));
-        *reinterpret_cast<u32x4*>(dst + (long)f * ld + m0 + part * 8) = ov[i];          // (M % 128 == 0: every row exists)
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_o, (unsigned)(f * ld2 + part * 16), soff, 0);      // (M % 128 == 0: every row exists)
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -396,51 +399,53 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
   dummy_dma(ROW_DMAS);                                                       // (stands in for the previous tile's final stores)
   if constexpr (!GNIN) stage_rows(std::true_type{}, p.ldr1, tile);
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(E_FIRST) : "memory");     // par[] and iterations 0 .. AHEAD-1 are in LDS
-  bias_acc();
-  publish();
 
   while (true) {
-    // ================================================================ first layer (+ residual), written out
+    // ================================================================ first layer
     linear_layer(std::integral_constant<int, E_FIRST>{});
     settle();
-    if constexpr (!GNIN) {
-      const int lmf = fresh(lm);
-      const int my_row = lmf * ROW_BYTES, my_swz = swz(lmf);
+    // ONE pass over the accumulator: + bias (+ the residual rows from the staging area), the result goes to the staging
+    // area (same slot the residual came from: each slot belongs to one lane) and on to HBM, its LayerNorm becomes the
+    // next layers' fragments.  Statistics in one sweep (sum and sum of squares, four partial sums each: fp32 over 320
+    // values of order one).
+    {
+      float X[LNB][16];
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int nb = 0; nb < LNB; ++nb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const u32x2 u = *reinterpret_cast<const u32x2*>(stage + my_row + (((nb * 4 + q) ^ my_swz) * 16) + hi * 8);
-          O[nb][4 * q] += __builtin_bit_cast(float, u[0] << 16);
-          O[nb][4 * q + 1] += __builtin_bit_cast(float, u[0] & 0xffff0000u);
-          O[nb][4 * q + 2] += __builtin_bit_cast(float, u[1] << 16);
-          O[nb][4 * q + 3] += __builtin_bit_cast(float, u[1] & 0xffff0000u);
-          if (q == 3) asm volatile("" : "+a"(O[nb]));
+          const int adr = slot8[(nb * 4 + q) & 7] + ((nb * 4 + q) >> 3) * 128;
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(par + 2 * LC + nb * 32 + q * 8 + hi * 4);
+          float r4[4] = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (!GNIN) {
+            const u32x2 u = *reinterpret_cast<const u32x2*>(smem + adr);
+            r4[0] = __builtin_bit_cast(float, u[0] << 16);
+            r4[1] = __builtin_bit_cast(float, u[0] & 0xffff0000u);
+            r4[2] = __builtin_bit_cast(float, u[1] << 16);
+            r4[3] = __builtin_bit_cast(float, u[1] & 0xffff0000u);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float x = (O[nb][4 * q + j] + bb[j]) + r4[j];
+            X[nb][4 * q + j] = x;
+            s1[j] += x;
+            s2[j] = __builtin_fmaf(x, x, s2[j]);
+          }
+          u32x2 o;
+          o[0] = pack_bf16x2(X[nb][4 * q], X[nb][4 * q + 1]);
+          o[1] = pack_bf16x2(X[nb][4 * q + 2], X[nb][4 * q + 3]);
+          *reinterpret_cast<u32x2*>(smem + adr) = o;
+          if (q == 3) __builtin_amdgcn_sched_barrier(0);       // (keeps the live set of this pass to X and one block's operands)
         }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    store_rows(p.out_mid, p.ldmid, tile);
-
-    // ================================================================ LayerNorm of the accumulator -> fragments
-    {
-      float s = 0.f;
-#pragma unroll
-      for (int nb = 0; nb < LNB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += O[nb][r];
+      float s = (s1[0] + s1[1]) + (s1[2] + s1[3]), q = (s2[0] + s2[1]) + (s2[2] + s2[3]);
       s += __shfl_xor(s, 32, 64);
-      const float mean = s / (float)LC;
-#pragma unroll
-      for (int nb = 0; nb < LNB; ++nb) asm volatile("" : "+a"(O[nb]));      // (each pass re-reads the AGPRs: no 160-register copy kept alive)
-      float q = 0.f;
-#pragma unroll
-      for (int nb = 0; nb < LNB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { const float d = O[nb][r] - mean; q += d * d; }
       q += __shfl_xor(q, 32, 64);
-      const float rstd = rsqrtf(q / (float)LC + p.eps);
-#pragma unroll
-      for (int nb = 0; nb < LNB; ++nb) asm volatile("" : "+a"(O[nb]));
+      const float mean = s / (float)LC;
+      float var = q / (float)LC - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      const float rstd = rsqrtf(var + p.eps);
+      const float shift = -mean * rstd;
 #pragma unroll
       for (int ks = 0; ks < LKS; ++ks) {
         float o[8];
@@ -450,24 +455,23 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
           const f32x4 gg = *reinterpret_cast<const f32x4*>(par + (ks / 2) * 32 + qq * 8 + hi * 4);
           const f32x4 bb = *reinterpret_cast<const f32x4*>(par + LC + (ks / 2) * 32 + qq * 8 + hi * 4);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[4 * h2 + j] = (O[ks / 2][4 * qq + j] - mean) * rstd * gg[j] + bb[j];
+          for (int j = 0; j < 4; ++j) o[4 * h2 + j] = __builtin_fmaf(__builtin_fmaf(X[ks / 2][4 * qq + j], rstd, shift), gg[j], bb[j]);
         }
         const u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
         Xn[ks] = __builtin_bit_cast(bf16x8, pk);
         asm volatile("" : "+a"(Xn[ks]));
+        __builtin_amdgcn_sched_barrier(0);
       }
+      asm volatile("s_nop 3" ::: "memory");
     }
+    flush_rows(p.out_mid, p.ldmid, tile);
 
     // ================================================================ the layers behind the LayerNorm
-    zero_acc();
-    publish();
 #pragma unroll 1
     for (int j = 0; j < NPOST - 1; ++j) {
       linear_layer(std::integral_constant<int, E_MID>{});
       settle();
       store_rows(p.out_p[j], p.ldp[j], tile);
-      zero_acc();
-      publish();
     }
     // the next tile's input rows travel while the last layer runs (behind the last tile: the same rows once more, so that
     // every tile puts the same number of operations into the queue)
@@ -484,8 +488,6 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
     if constexpr (!GNIN) stage_rows(std::true_type{}, p.ldr1, ltile);
     if (ntile >= ntiles) break;
     tile = ntile;
-    bias_acc();
-    publish();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (DMA still in flight lands in LDS that must still be this block's)
 }
@@ -538,7 +540,8 @@ int lin_chain_launch(const LinChainParams& c, hipStream_t st) {
   ARG_CHECK(c.rows_per_image > 0 && c.rows_per_image % BLOCK_ROWS == 0 && c.M % c.rows_per_image == 0 && c.out_q && c.out_k &&
                 c.ldq % 8 == 0 && c.ldk % 8 == 0,
             "lin_chain: GroupNorm'd input form (whole images of a multiple of 128 rows; q, k, v^T outputs)");
-  ARG_CHECK((long)c.M * c.ldq * 2 < (1L << 31) && (long)c.M * c.ldk * 2 < (1L << 31), "lin_chain: output beyond the 2 GB buffer window");
+  ARG_CHECK((long)c.M * c.ldq * 2 < (1L << 31) && (long)c.M * c.ldk * 2 < (1L << 31) && (long)LC * c.ldo * 2 < (1L << 31),
+            "lin_chain: output beyond the 2 GB buffer window");
   k.gn_ss = c.gn_ss; k.rows_per_image = c.rows_per_image;
   k.out_p[0] = c.out_q; k.ldp[0] = c.ldq; k.out_p[1] = c.out_k; k.ldp[1] = c.ldk;
   return launch<3, true, true>(k, st);
