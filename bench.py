@@ -442,7 +442,7 @@ def main():
                for k, v in prof.items()}
     sampled_ms = sum(v[0] for v in prof.values())
     roof = {"bound": "mfma", "kernel": {"conv3x3_gemm": "igemm_kernel<BN,conv> (3x3 conv as implicit GEMM)",
-                                        "linear_gemm": "igemm_kernel<BN,0> (linear / 1x1)",
+                                        "linear_gemm": "linear class: igemm_kernel<BN,0> (linear / 1x1) + ffn_chain_kernel / lin_chain_kernel (the token-local chains of the C=320 level, one kernel each)",
                                         "self_attn": "self_attn_kernel<D>", "cross_attn": "cross_attn_kernel<D>",
                                         "norm": "gn_*/layernorm kernels", "other": "geglu/concat"}[dk],
             "achieved": round(dfl / 1e9 / dms, 2) if dms > 0 else None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

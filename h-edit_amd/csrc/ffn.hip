@@ -291,21 +291,33 @@ __global__ __launch_bounds__(256, 1) void ffn_chain_kernel(ChainKernelParams p) 
 
   // O[nb][4 q + j] of lane (lm, hi) = feature 32 nb + 8 q + 4 hi + j of row lm  (32x32 MFMA result layout)
   f32x16 O[FNB];
-  // O = rows of `src` (bf16, this lane's 4-feature groups) + bias
+  // O = rows of `src` (bf16) + bias.  A lane owns one row, so every global access is its own request: 16-byte loads
+  // (chunk 2k + hi of the row, 20 per lane) instead of the 40 8-byte pieces the accumulator layout asks for, and one
+  // exchange between the lane halves puts the pieces where they belong (the lane of half `hi` needs half `hi` of EVERY
+  // chunk: it keeps that half of its own chunks and swaps the other for the partner lane's).
   auto load_rows = [&](const bf16_t* src, long ld, const float* bias) __attribute__((always_inline)) {
-    const bf16_t* rp = src + (long)row_c * ld + hi * 4;
+    const bf16_t* rp = src + (long)row_c * ld + hi * 8;
+    u32x4 raw[FKS];
 #pragma unroll
-    for (int nb = 0; nb < FNB; ++nb)
+    for (int k = 0; k < FKS; ++k) raw[k] = *reinterpret_cast<const u32x4*>(rp + k * 16);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const u32x2 u = *reinterpret_cast<const u32x2*>(rp + nb * 32 + q * 8);
+    for (int k = 0; k < FKS; ++k) {
+      // raw[k] = chunk 2k + hi = [low half: dwords 0, 1 | high half: dwords 2, 3]; after the swaps: x = this lane's half of
+      // chunk 2k, y = its half of chunk 2k + 1
+      const auto s0 = __builtin_amdgcn_permlane32_swap(raw[k][0], raw[k][2], false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(raw[k][1], raw[k][3], false, false);
+      const unsigned half[2][2] = {{s0[0], s1[0]}, {s0[1], s1[1]}};
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const int c = 2 * k + c2, nb = c / 4, q = c % 4;
         f32x4 bb = {0.f, 0.f, 0.f, 0.f};
         if (bias) bb = *reinterpret_cast<const f32x4*>(bias + nb * 32 + q * 8 + hi * 4);
-        O[nb][4 * q] = __builtin_bit_cast(float, u[0] << 16) + bb[0];
-        O[nb][4 * q + 1] = __builtin_bit_cast(float, u[0] & 0xffff0000u) + bb[1];
-        O[nb][4 * q + 2] = __builtin_bit_cast(float, u[1] << 16) + bb[2];
-        O[nb][4 * q + 3] = __builtin_bit_cast(float, u[1] & 0xffff0000u) + bb[3];
+        O[nb][4 * q] = __builtin_bit_cast(float, half[c2][0] << 16) + bb[0];
+        O[nb][4 * q + 1] = __builtin_bit_cast(float, half[c2][0] & 0xffff0000u) + bb[1];
+        O[nb][4 * q + 2] = __builtin_bit_cast(float, half[c2][1] << 16) + bb[2];
+        O[nb][4 * q + 3] = __builtin_bit_cast(float, half[c2][1] & 0xffff0000u) + bb[3];
       }
+    }
   };
   // make the accumulators readable by the VALU behind asm MFMAs: the last MFMAs must have retired before the first
   // v_accvgpr_read (an MFMA-write -> VALU-read hazard the compiler cannot see), and the empty asm statements re-define
@@ -558,6 +570,9 @@ __global__ __launch_bounds__(256, 1) void ffn_chain_kernel(ChainKernelParams p) 
     load_rows(p.r2, p.ldr2, p.bias_post);
     publish();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the residual loads are waited for by their uses; the DMA count restarts clean)
+    // (the read-ahead is taken afresh: carried through the transition above it would sit in scratch)
+#pragma unroll
+    for (int j = 0; j < LEAD; ++j) pre[j] = rd(frag_rd, false, j);
     linear_layer(std::false_type{});
   }
 

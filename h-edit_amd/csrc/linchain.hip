@@ -185,29 +185,34 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) slotx[k] = STAGE_OFF + wave * STAGE_BYTES + lm * ROW_BYTES + (((2 * k + hi) ^ swz(lm)) * 16);
 
-  auto stage_rows = [&](auto res_c, long ld, int tile) __attribute__((always_inline)) {
+  // piece i of the wave's 32 rows of a tile (res: the residual tensor instead of the input tensor)
+  auto row_piece = [&](auto res_c, int i, int ld2, int soff) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(decltype(res_c)::value ? rs_r : rs_a, (__attribute__((address_space(3))) void*)(stage + i * 1024), 16,
+                                             piece_off(i, ld2), soff, 0, 0);
+#else
+    (void)i; (void)ld2; (void)soff;
+#endif
+  };
+  auto stage_rows = [&](auto res_c, long ld, int tile) __attribute__((always_inline)) {
     const int soff = (int)((long)(tile * BLOCK_ROWS + wave * 32) * ld * 2);
     const int ld2 = opaque((int)ld * 2);
 #pragma unroll
-    for (int i = 0; i < ROW_DMAS; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(decltype(res_c)::value ? rs_r : rs_a, (__attribute__((address_space(3))) void*)(stage + i * 1024), 16,
-                                               piece_off(i, ld2), soff, 0, 0);
-#else
-    (void)ld; (void)tile;
-#endif
+    for (int i = 0; i < ROW_DMAS; ++i) row_piece(res_c, i, ld2, soff);
   };
   // the (scale, shift) pairs of the tile's image -> SS_OFF (every wave fetches the same 2.5 KB: identical bytes)
-  auto stage_ss = [&](int tile) __attribute__((always_inline)) {
+  auto ss_piece = [&](int k, int tile) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int img = (tile * BLOCK_ROWS) / p.rows_per_image;
-#pragma unroll
-    for (int k = 0; k < SS_DMAS; ++k)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ss, (__attribute__((address_space(3))) void*)(smem + SS_OFF + k * 1024), 16, dma_voff,
-                                               img * (LC * 8) + k * 1024, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ss, (__attribute__((address_space(3))) void*)(smem + SS_OFF + k * 1024), 16, dma_voff,
+                                             img * (LC * 8) + k * 1024, 0, 0);
 #else
-    (void)tile;
+    (void)k; (void)tile;
 #endif
+  };
+  auto stage_ss = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < SS_DMAS; ++k) ss_piece(k, tile);
   };
   auto dummy_dma = [&](int n) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -263,9 +268,19 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
   int sit = 0, bank = 0;                     // stream iteration being consumed (mod NIT), its ring bank
   int frag_rd = lane * 16;
   bf16x8 pre[LEAD];
-  auto linear_layer = [&](auto extra_c) __attribute__((always_inline)) {
+  // ROWS: row DMA carried by this layer, two pieces per iteration from its first iteration on (0: none; 1: the residual
+  // rows of this tile; 2: the input rows (and scale / shift pairs) of tile `rtile`) -- a DMA issue blocks the wave for
+  // 100+ cycles while the address path is busy, so the 20 pieces of a tile's rows ride in the MFMAs' shadow instead of
+  // standing as a block between two layers (measured there: 17 % of the tile time).
+  auto linear_layer = [&](auto extra_c, auto rows_c, int rtile) __attribute__((always_inline)) {
     constexpr int EXTRA = decltype(extra_c)::value;
-    static_assert((AHEAD - 2) * PPW + EXTRA <= 63, "vmcnt is a 6-bit counter");
+    constexpr int ROWS = decltype(rows_c)::value;
+    constexpr int NP = ROWS == 0 ? 0 : ROW_DMAS + (ROWS == 2 && GNIN ? SS_DMAS : 0);      // pieces carried
+    constexpr int PITER = (NP + 1) / 2;                                                    // iterations that carry pieces
+    static_assert(PITER + 4 <= LKS, "the carried pieces must be out four iterations before the layer ends");
+    static_assert((AHEAD - 2) * PPW + EXTRA + 8 <= 63, "vmcnt is a 6-bit counter");
+    const int r_ld2 = opaque((int)(ROWS == 1 ? p.ldr1 : p.lda) * 2);
+    const int r_soff = (int)((long)(rtile * BLOCK_ROWS + wave * 32) * (ROWS == 1 ? p.ldr1 : p.lda) * 2);
 #pragma unroll
     for (int j = 0; j < LEAD; ++j) pre[j] = *reinterpret_cast<const bf16x8*>(smem + frag_rd + j * 1024);
     static_for<LKS>([&](auto ks_) {
@@ -292,12 +307,28 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
         if constexpr (b + LEAD < LNB) fr[b + LEAD] = *reinterpret_cast<const bf16x8*>(smem + base + (b + LEAD) * 1024);
         else if constexpr (ks + 1 < LKS) pre[b + LEAD - LNB] = *reinterpret_cast<const bf16x8*>(smem + nbase + (b + LEAD - LNB) * 1024);
         if constexpr (b % 3 == 1) dma_piece(dit, pbank, b / 3);
+        if constexpr (b % 3 == 2 && b / 3 < 2) {
+          constexpr int pi = 2 * ks + b / 3;                 // carried piece of this bundle
+          if constexpr (pi < NP) {
+            if constexpr (pi < ROW_DMAS) {
+              if constexpr (ROWS == 1) row_piece(std::true_type{}, pi, r_ld2, r_soff);
+              else row_piece(std::false_type{}, pi, r_ld2, r_soff);
+            } else {
+              ss_piece(pi - ROW_DMAS, rtile);
+            }
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       });
-      if constexpr (ks < 4)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"((AHEAD - 2) * PPW + EXTRA), "n"(LEAD) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"((AHEAD - 2) * PPW), "n"(LEAD) : "memory");
+      // operations newer than the last piece of iteration ks + 2 (issued during iteration ks - 4): the weight pieces and
+      // carried pieces of iterations ks-3 .. ks, and the burst in front of the layer while ks - 3 <= 0
+      constexpr int carried = [] {
+        int n = 0;
+        for (int j = ks - 3; j <= ks; ++j)
+          if (j >= 0) n += (2 * j + 2 <= NP) ? 2 : (2 * j + 1 <= NP ? 1 : 0);
+        return n;
+      }();
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"((AHEAD - 2) * PPW + carried + (ks < 4 ? EXTRA : 0)), "n"(LEAD) : "memory");
       sit = sit + 1 == NIT ? 0 : sit + 1;
       bank = nbank;
       frag_rd = nbase;
@@ -393,16 +424,13 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * PPW) : "memory");        // my input rows (and the scale / shift pairs) are in LDS
   read_xn();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  constexpr int E_FIRST = ROW_DMAS + (GNIN ? 0 : ROW_DMAS);                  // in front of a first layer: the final stores (+ the residual DMA)
-  constexpr int E_MID = ROW_DMAS;                                            // in front of a middle layer: the stores of the previous result
-  constexpr int E_LAST = ROW_DMAS + ROW_DMAS + (GNIN ? SS_DMAS : 0);         // in front of the last layer: stores + the next tile's input
+  constexpr int E_STORES = ROW_DMAS;                                         // in front of every layer: the stores of the previous result
   dummy_dma(ROW_DMAS);                                                       // (stands in for the previous tile's final stores)
-  if constexpr (!GNIN) stage_rows(std::true_type{}, p.ldr1, tile);
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(E_FIRST) : "memory");     // par[] and iterations 0 .. AHEAD-1 are in LDS
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(E_STORES) : "memory");    // par[] and iterations 0 .. AHEAD-1 are in LDS
 
   while (true) {
     // ================================================================ first layer
-    linear_layer(std::integral_constant<int, E_FIRST>{});
+    linear_layer(std::integral_constant<int, E_STORES>{}, std::integral_constant<int, GNIN ? 0 : 1>{}, tile);     // (+ this tile's residual rows)
     settle();
     // ONE pass over the accumulator: + bias (+ the residual rows from the staging area), the result goes to the staging
     // area (same slot the residual came from: each slot belongs to one lane) and on to HBM, its LayerNorm becomes the
@@ -460,7 +488,6 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
         const u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
         Xn[ks] = __builtin_bit_cast(bf16x8, pk);
         asm volatile("" : "+a"(Xn[ks]));
-        __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_nop 3" ::: "memory");
     }
@@ -469,7 +496,7 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
     // ================================================================ the layers behind the LayerNorm
 #pragma unroll 1
     for (int j = 0; j < NPOST - 1; ++j) {
-      linear_layer(std::integral_constant<int, E_MID>{});
+      linear_layer(std::integral_constant<int, E_STORES>{}, std::integral_constant<int, 0>{}, tile);
       settle();
       store_rows(p.out_p[j], p.ldp[j], tile);
     }
@@ -477,15 +504,12 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
     // every tile puts the same number of operations into the queue)
     const int ntile = tile + (int)gridDim.x;
     const int ltile = ntile < ntiles ? ntile : tile;
-    stage_rows(std::false_type{}, p.lda, ltile);
-    if constexpr (GNIN) stage_ss(ltile);
-    linear_layer(std::integral_constant<int, E_LAST>{});
+    linear_layer(std::integral_constant<int, E_STORES>{}, std::integral_constant<int, 2>{}, ltile);
     settle();
     read_xn();                                             // the fragments of the NEXT tile's first layer (Xn is free now)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if constexpr (VT) store_rows_t(p.out, p.ldo, tile);
     else store_rows(p.out, p.ldo, tile);
-    if constexpr (!GNIN) stage_rows(std::true_type{}, p.ldr1, ltile);
     if (ntile >= ntiles) break;
     tile = ntile;
   }

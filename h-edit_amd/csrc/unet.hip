@@ -48,7 +48,7 @@ struct Attn {
   int C;
   float *gn_g, *gn_b, *pin_b, *ln1g, *ln1b, *ln2g, *ln2b, *ln3g, *ln3b, *o1_b, *o2_b, *ff1_b, *ff2_b, *pout_b;
   bf16_t *pin, *w_qk, *w_v1, *w_o1, *w_q2, *w_k2, *w_v2, *w_o2, *ff1, *ff2, *pout;
-  // C == ffn_fused_channels(): the token-local layers run as three chain kernels (ffn.hip) on these weight streams
+  // C == ffn_fused_channels(): the token-local layers run as three chain kernels (linchain.hip x 2, ffn.hip) on these weight streams
   // (+ the packed FF1 bias); pin / w_qk / w_v1 / w_o1 / w_q2 / w_o2 / ff1 / ff2 / ff1_b / pout are then not materialised
   bf16_t *frs = nullptr, *k1s = nullptr, *ffs = nullptr;
   float* ff1_bp = nullptr;
@@ -155,7 +155,7 @@ Attn make_attn(hedit_unet* h, const std::string& pre, int C) {
   const float qscale = 1.0f / sqrtf((float)d) * 1.4426950408889634f;   // softmax scale * log2(e)
   a.gn_g = f32p(h, pre + ".norm.weight", C);
   a.gn_b = f32p(h, pre + ".norm.bias", C);
-  // At the level ffn.hip exists for, the token-local layers of the block run as three kernels -- GroupNorm apply +
+  // At the level ffn.hip / linchain.hip exist for, the token-local layers of the block run as three kernels -- GroupNorm apply +
   // proj_in + norm1 + q | k | v^T;  attn1.to_out + residual + norm2 + attn2.to_q;  attn2.to_out + residual + norm3 +
   // feed-forward + proj_out + residual -- and their weights go into those kernels' streams (slot kind 5), the FF1 bias
   // into its packed form (kind 6); none of them is kept as a GEMM operand.
@@ -400,7 +400,7 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   TRY(aalloc(f, &qk, M * 2 * C));
   TRY(aalloc(f, &vt, M * C));
   if (chain) {
-    // GroupNorm statistics, then normalisation + proj_in -> norm1 -> q | k | v^T in ONE kernel (ffn.hip): x is read once,
+    // GroupNorm statistics, then normalisation + proj_in -> norm1 -> q | k | v^T in ONE kernel (linchain.hip): x is read once,
     // t0 (the residual stream), q, k and v^T are written, nothing else touches HBM
     float* ws;
     const float* ss = nullptr;

@@ -287,7 +287,7 @@ int hedit_k_ffn_fused(const void* x, int64_t ldx, const float* gamma, const floa
 int hedit_k_ffn_chain(const void* a, int64_t lda, const void* t1, int64_t ldt1, const void* x, int64_t ldx, const float* bias_pre,
                       const float* gamma, const float* beta, float eps, const void* w_stream, const float* bias1_packed,
                       const float* bias2, const float* bias_post, void* out, int64_t ldo, int M, int C, void* stream);
-/* The projections around an attention of the same level in one launch (csrc/ffn.hip), two forms:
+/* The projections around an attention of the same level in one launch (csrc/linchain.hip), two forms:
  *   n_out = 1 (gn_ss == NULL):  mid = attn1.to_out.0(a) + r1 (written to out_mid);  out[M][C] = attn2.to_q( norm2(mid) )
  *   n_out = 3 (gn_ss set):      mid = proj_in( a * scale + shift ) (GroupNorm applied on the fly; written to out_mid);
  *                               q, k = attn1.to_q / to_k ( norm1(mid) ) -> out_q, out_k;  out[C][ldo] = attn1.to_v(norm1(mid))^T

@@ -1,5 +1,6 @@
-"""Bit-level A/B of the row-sharing conv loop: prints one hash per (shape, split form) of the 3x3 conv output through the
-C ABI.  Run once with HEDIT_CONV_ROWSHARE=0 and once without, and diff the two outputs; also checks against torch."""
+"""Bit-level check of the row-sharing conv loop: prints one hash per (shape, split form) of the 3x3 conv output through the
+C ABI (diff the output of two builds, e.g. the product library and a tools/build_variant.sh side library); also checks
+against torch."""
 import sys, os, math, hashlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))

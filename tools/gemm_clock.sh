@@ -6,7 +6,7 @@ cp $R/h-edit_amd/hedit/libhedit_hip.so /tmp/keep.so
 for v in base nodma nomfma; do
   cp $R/h-edit_amd/hedit/lib_$v.so.bin $R/h-edit_amd/hedit/libhedit_hip.so
   rm -rf /tmp/ck_$v
-  HEDIT_GEMM_BM=128 timeout 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES -d /tmp/ck_$v -o ck -- python $R/tools/pmc_probe.py > /tmp/ck_$v.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES -d /tmp/ck_$v -o ck -- python $R/tools/pmc_probe.py > /tmp/ck_$v.log 2>&1
   db=$(find /tmp/ck_$v -name "*.db" | head -1)
   echo "== $v"; python $R/tools/rocpd_clock.py $db igemm
 done

@@ -16,6 +16,8 @@ def klass(name):
     if "igemm_kernel" in name:
         args = [a.strip() for a in name.split("igemm_kernel<")[1].split(">")[0].split(",")]   # BM, BN, MODE
         return "linear_gemm" if args[2] == "0" else "conv3x3_gemm"
+    if "ffn_chain_kernel" in name or "lin_chain_kernel" in name:      # the one-kernel token-local chains of the C = 320 level
+        return "linear_gemm"
     if "splitk_reduce" in name:
         return "splitk_reduce"
     if "self_attn" in name:

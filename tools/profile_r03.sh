@@ -17,6 +17,7 @@ bash $R/tools/pmc_traffic.sh > $O/pmc_traffic.log 2>&1; tail -8 $O/pmc_traffic.l
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/p_face -o trace -- python $R/bench.py --workload face --steps 1 --warmup 0 --diffusion-steps 20 > $O/bench_face_under_rocprof.json 2> $O/rocprof_face.err
 db=$(find /tmp/p_face -name "*.db" | head -1)
 [ -n "$db" ] && python $R/tools/rocpd_stats.py $db --loop > $O/face_kernel_stats.txt && head -10 $O/face_kernel_stats.txt
+[ -n "$db" ] && python $R/tools/rocpd_stats.py $db --loop --gaps > $O/face_gaps.txt && head -3 $O/face_gaps.txt
 rm -rf /tmp/p_face
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/p_style -o trace -- python $R/bench.py --workload style --images 8 --steps 1 --warmup 0 --diffusion-steps 10 --no-cpu-baseline > $O/bench_style_under_rocprof.json 2> $O/rocprof_style.err
 db=$(find /tmp/p_style -name "*.db" | head -1)
