@@ -8,10 +8,10 @@ ix = {k: i for i, k in enumerate(cols)}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     name = r[ix.get('kernel_name', ix.get('name'))]
-    want = sys.argv[2:] or ['igemm', 'self_attn', 'cross_attn', 'gn_', 'ffn_']
+    want = sys.argv[2:] or ['igemm', 'self_attn', 'cross_attn', 'gn_', 'ffn_', 'lin_chain', 'layernorm']
     if not any(w in name for w in want):
         continue
-    key = (name.split('::')[-1][:40], r[ix['grid_size_x']] if 'grid_size_x' in ix else 0)
+    key = (name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:60], r[ix['grid_size_x']] if 'grid_size_x' in ix else 0)
     agg[key][r[ix['counter_name']]].append(r[ix['value']])
 for key, d in agg.items():
     print(key)
