@@ -127,7 +127,7 @@ __device__ __forceinline__ void mfma_l0(f32x16& acc, const bf16x8& w, const bf16
 // a layer that follows E such operations allow E more outstanding ones (template parameter of the layer) -- the burst
 // gets four iterations to complete before anybody waits for it.  The burst sizes are made the same for every tile
 // (dummy DMA in front of the first tile, bounds-checked buffer stores that are issued whether or not the row exists).
-template <int NPOST, bool GNIN, bool VT>
+template <int NPOST, bool GNIN, bool VT, bool SSG>
 __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -185,34 +185,29 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) slotx[k] = STAGE_OFF + wave * STAGE_BYTES + lm * ROW_BYTES + (((2 * k + hi) ^ swz(lm)) * 16);
 
-  // piece i of the wave's 32 rows of a tile (res: the residual tensor instead of the input tensor)
-  auto row_piece = [&](auto res_c, int i, int ld2, int soff) __attribute__((always_inline)) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(decltype(res_c)::value ? rs_r : rs_a, (__attribute__((address_space(3))) void*)(stage + i * 1024), 16,
-                                             piece_off(i, ld2), soff, 0, 0);
-#else
-    (void)i; (void)ld2; (void)soff;
-#endif
-  };
   auto stage_rows = [&](auto res_c, long ld, int tile) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
     const int soff = (int)((long)(tile * BLOCK_ROWS + wave * 32) * ld * 2);
     const int ld2 = opaque((int)ld * 2);
 #pragma unroll
-    for (int i = 0; i < ROW_DMAS; ++i) row_piece(res_c, i, ld2, soff);
-  };
-  // the (scale, shift) pairs of the tile's image -> SS_OFF (every wave fetches the same 2.5 KB: identical bytes)
-  auto ss_piece = [&](int k, int tile) __attribute__((always_inline)) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int img = (tile * BLOCK_ROWS) / p.rows_per_image;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ss, (__attribute__((address_space(3))) void*)(smem + SS_OFF + k * 1024), 16, dma_voff,
-                                             img * (LC * 8) + k * 1024, 0, 0);
+    for (int i = 0; i < ROW_DMAS; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(decltype(res_c)::value ? rs_r : rs_a, (__attribute__((address_space(3))) void*)(stage + i * 1024), 16,
+                                               piece_off(i, ld2), soff, 0, 0);
 #else
-    (void)k; (void)tile;
+    (void)ld; (void)tile;
 #endif
   };
+  // the (scale, shift) pairs of the tile's image -> SS_OFF (every wave fetches the same 2.5 KB: identical bytes)
   auto stage_ss = [&](int tile) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int img = (tile * BLOCK_ROWS) / p.rows_per_image;
 #pragma unroll
-    for (int k = 0; k < SS_DMAS; ++k) ss_piece(k, tile);
+    for (int k = 0; k < SS_DMAS; ++k)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ss, (__attribute__((address_space(3))) void*)(smem + SS_OFF + k * 1024), 16, dma_voff,
+                                               img * (LC * 8) + k * 1024, 0, 0);
+#else
+    (void)tile;
+#endif
   };
   auto dummy_dma = [&](int n) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -234,7 +229,15 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
     for (int nb = 0; nb < LNB; ++nb) asm volatile("" : "+a"(O[nb]));
   };
   // the first layer's fragments from the staged input rows (GNIN: x * scale + shift on the way)
-  auto read_xn = [&]() __attribute__((always_inline)) {
+  // (scale, shift): from the staged pairs of the tile's image (SSG false), or -- images that are not whole tiles, e.g.
+  // 24 x 24 tokens -- per row from global memory (`rtile`: the tile the staged rows belong to)
+  auto read_xn = [&](int rtile) __attribute__((always_inline)) {
+    const float* ssg = nullptr;
+    if constexpr (GNIN && SSG) {
+      int row = rtile * BLOCK_ROWS + wave * 32 + lm;
+      if (row > p.M - 1) row = p.M - 1;
+      ssg = p.gn_ss + ((long)(row / p.rows_per_image) * LC + hi * 8) * 2;
+    }
 #pragma unroll
     for (int ks = 0; ks < LKS; ++ks) {
       u32x4 raw = *reinterpret_cast<const u32x4*>(smem + slotx[ks & 3] + (ks >> 2) * 128);
@@ -247,7 +250,9 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
         }
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {
-          const f32x4 c = *reinterpret_cast<const f32x4*>(smem + SS_OFF + (ks * 16 + hi * 8 + 2 * e2) * 8);       // channels 2 e2, 2 e2 + 1
+          f32x4 c;                                                                                             // channels 2 e2, 2 e2 + 1
+          if constexpr (!SSG) c = *reinterpret_cast<const f32x4*>(smem + SS_OFF + (ks * 16 + hi * 8 + 2 * e2) * 8);
+          else c = *reinterpret_cast<const f32x4*>(ssg + ks * 32 + e2 * 4);
           x[2 * e2] = __builtin_fmaf(x[2 * e2], c[0], c[1]);
           x[2 * e2 + 1] = __builtin_fmaf(x[2 * e2 + 1], c[2], c[3]);
         }
@@ -255,6 +260,7 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
       }
       Xn[ks] = __builtin_bit_cast(bf16x8, raw);
       asm volatile("" : "+a"(Xn[ks]));       // home in the AGPR file from here on (every use is an MFMA operand)
+      if constexpr (SSG) __builtin_amdgcn_sched_barrier(0);      // (the global loads of one k-step at a time: register pressure)
     }
     asm volatile("s_nop 3" ::: "memory");    // (VALU-written fragments in front of asm MFMAs)
   };
@@ -268,19 +274,9 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
   int sit = 0, bank = 0;                     // stream iteration being consumed (mod NIT), its ring bank
   int frag_rd = lane * 16;
   bf16x8 pre[LEAD];
-  // ROWS: row DMA carried by this layer, two pieces per iteration from its first iteration on (0: none; 1: the residual
-  // rows of this tile; 2: the input rows (and scale / shift pairs) of tile `rtile`) -- a DMA issue blocks the wave for
-  // 100+ cycles while the address path is busy, so the 20 pieces of a tile's rows ride in the MFMAs' shadow instead of
-  // standing as a block between two layers (measured there: 17 % of the tile time).
-  auto linear_layer = [&](auto extra_c, auto rows_c, int rtile) __attribute__((always_inline)) {
+  auto linear_layer = [&](auto extra_c) __attribute__((always_inline)) {
     constexpr int EXTRA = decltype(extra_c)::value;
-    constexpr int ROWS = decltype(rows_c)::value;
-    constexpr int NP = ROWS == 0 ? 0 : ROW_DMAS + (ROWS == 2 && GNIN ? SS_DMAS : 0);      // pieces carried
-    constexpr int PITER = (NP + 1) / 2;                                                    // iterations that carry pieces
-    static_assert(PITER + 4 <= LKS, "the carried pieces must be out four iterations before the layer ends");
-    static_assert((AHEAD - 2) * PPW + EXTRA + 8 <= 63, "vmcnt is a 6-bit counter");
-    const int r_ld2 = opaque((int)(ROWS == 1 ? p.ldr1 : p.lda) * 2);
-    const int r_soff = (int)((long)(rtile * BLOCK_ROWS + wave * 32) * (ROWS == 1 ? p.ldr1 : p.lda) * 2);
+    static_assert((AHEAD - 2) * PPW + EXTRA <= 63, "vmcnt is a 6-bit counter");
 #pragma unroll
     for (int j = 0; j < LEAD; ++j) pre[j] = *reinterpret_cast<const bf16x8*>(smem + frag_rd + j * 1024);
     static_for<LKS>([&](auto ks_) {
@@ -307,28 +303,12 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
         if constexpr (b + LEAD < LNB) fr[b + LEAD] = *reinterpret_cast<const bf16x8*>(smem + base + (b + LEAD) * 1024);
         else if constexpr (ks + 1 < LKS) pre[b + LEAD - LNB] = *reinterpret_cast<const bf16x8*>(smem + nbase + (b + LEAD - LNB) * 1024);
         if constexpr (b % 3 == 1) dma_piece(dit, pbank, b / 3);
-        if constexpr (b % 3 == 2 && b / 3 < 2) {
-          constexpr int pi = 2 * ks + b / 3;                 // carried piece of this bundle
-          if constexpr (pi < NP) {
-            if constexpr (pi < ROW_DMAS) {
-              if constexpr (ROWS == 1) row_piece(std::true_type{}, pi, r_ld2, r_soff);
-              else row_piece(std::false_type{}, pi, r_ld2, r_soff);
-            } else {
-              ss_piece(pi - ROW_DMAS, rtile);
-            }
-          }
-        }
         __builtin_amdgcn_sched_barrier(0);
       });
-      // operations newer than the last piece of iteration ks + 2 (issued during iteration ks - 4): the weight pieces and
-      // carried pieces of iterations ks-3 .. ks, and the burst in front of the layer while ks - 3 <= 0
-      constexpr int carried = [] {
-        int n = 0;
-        for (int j = ks - 3; j <= ks; ++j)
-          if (j >= 0) n += (2 * j + 2 <= NP) ? 2 : (2 * j + 1 <= NP ? 1 : 0);
-        return n;
-      }();
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"((AHEAD - 2) * PPW + carried + (ks < 4 ? EXTRA : 0)), "n"(LEAD) : "memory");
+      if constexpr (ks < 4)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"((AHEAD - 2) * PPW + EXTRA), "n"(LEAD) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"((AHEAD - 2) * PPW), "n"(LEAD) : "memory");
       sit = sit + 1 == NIT ? 0 : sit + 1;
       bank = nbank;
       frag_rd = nbase;
@@ -404,7 +384,10 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
         const int y = slot & 7;
         const int f = (slot & ~7) + (y < 4 ? y : 4 + ((y + 3) & 3));
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_o, (unsigned)(f * ld2 + part * 16), soff, 0);      // (M % 128 == 0: every row exists)
+        // (rows beyond M -- last tile of an M that is not a multiple of 128 -- get an offset outside the buffer: the store is
+        //  issued like every other one and dropped by the bounds check)
+        const bool live = tile * BLOCK_ROWS + wave * 32 + part * 8 < p.M;
+        __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_o, live ? (unsigned)(f * ld2 + part * 16) : 0x7ffffff0u, soff, 0);
 #endif
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -422,15 +405,18 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
 #pragma unroll
     for (int k = 0; k < PPW; ++k) dma_piece(it, it, k);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * PPW) : "memory");        // my input rows (and the scale / shift pairs) are in LDS
-  read_xn();
+  read_xn(tile);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  constexpr int E_STORES = ROW_DMAS;                                         // in front of every layer: the stores of the previous result
+  constexpr int E_FIRST = ROW_DMAS + (GNIN ? 0 : ROW_DMAS);                  // in front of a first layer: the final stores (+ the residual DMA)
+  constexpr int E_MID = ROW_DMAS;                                            // in front of a middle layer: the stores of the previous result
+  constexpr int E_LAST = ROW_DMAS + ROW_DMAS + (GNIN ? SS_DMAS : 0);         // in front of the last layer: stores + the next tile's input
   dummy_dma(ROW_DMAS);                                                       // (stands in for the previous tile's final stores)
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(E_STORES) : "memory");    // par[] and iterations 0 .. AHEAD-1 are in LDS
+  if constexpr (!GNIN) stage_rows(std::true_type{}, p.ldr1, tile);
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(E_FIRST) : "memory");     // par[] and iterations 0 .. AHEAD-1 are in LDS
 
   while (true) {
     // ================================================================ first layer
-    linear_layer(std::integral_constant<int, E_STORES>{}, std::integral_constant<int, GNIN ? 0 : 1>{}, tile);     // (+ this tile's residual rows)
+    linear_layer(std::integral_constant<int, E_FIRST>{});
     settle();
     // ONE pass over the accumulator: + bias (+ the residual rows from the staging area), the result goes to the staging
     // area (same slot the residual came from: each slot belongs to one lane) and on to HBM, its LayerNorm becomes the
@@ -488,6 +474,7 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
         const u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
         Xn[ks] = __builtin_bit_cast(bf16x8, pk);
         asm volatile("" : "+a"(Xn[ks]));
+        __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_nop 3" ::: "memory");
     }
@@ -496,7 +483,7 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
     // ================================================================ the layers behind the LayerNorm
 #pragma unroll 1
     for (int j = 0; j < NPOST - 1; ++j) {
-      linear_layer(std::integral_constant<int, E_STORES>{}, std::integral_constant<int, 0>{}, tile);
+      linear_layer(std::integral_constant<int, E_MID>{});
       settle();
       store_rows(p.out_p[j], p.ldp[j], tile);
     }
@@ -504,23 +491,26 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
     // every tile puts the same number of operations into the queue)
     const int ntile = tile + (int)gridDim.x;
     const int ltile = ntile < ntiles ? ntile : tile;
-    linear_layer(std::integral_constant<int, E_STORES>{}, std::integral_constant<int, 2>{}, ltile);
+    stage_rows(std::false_type{}, p.lda, ltile);
+    if constexpr (GNIN) stage_ss(ltile);
+    linear_layer(std::integral_constant<int, E_LAST>{});
     settle();
-    read_xn();                                             // the fragments of the NEXT tile's first layer (Xn is free now)
+    read_xn(ltile);                                        // the fragments of the NEXT tile's first layer (Xn is free now)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if constexpr (VT) store_rows_t(p.out, p.ldo, tile);
     else store_rows(p.out, p.ldo, tile);
+    if constexpr (!GNIN) stage_rows(std::true_type{}, p.ldr1, ltile);
     if (ntile >= ntiles) break;
     tile = ntile;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (DMA still in flight lands in LDS that must still be this block's)
 }
 
-template <int NPOST, bool GNIN, bool VT>
+template <int NPOST, bool GNIN, bool VT, bool SSG>
 int launch(const LinKernelParams& k, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_chain_kernel<NPOST, GNIN, VT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_chain_kernel<NPOST, GNIN, VT, SSG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
     attr_set = true;
   }
   static int cus = 0;
@@ -530,7 +520,7 @@ int launch(const LinKernelParams& k, hipStream_t st) {
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   }
   const int ntiles = cdiv(k.M, BLOCK_ROWS);
-  hipLaunchKernelGGL((lin_chain_kernel<NPOST, GNIN, VT>), dim3(ntiles < cus ? ntiles : cus), dim3(256), LDS_TOTAL, st, k);
+  hipLaunchKernelGGL((lin_chain_kernel<NPOST, GNIN, VT, SSG>), dim3(ntiles < cus ? ntiles : cus), dim3(256), LDS_TOTAL, st, k);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }
@@ -559,14 +549,14 @@ int lin_chain_launch(const LinChainParams& c, hipStream_t st) {
   if (!c.gn_ss) {
     ARG_CHECK(c.r1 && c.ldr1 % 8 == 0 && (long)c.M * c.ldr1 * 2 < (1L << 31), "lin_chain: residual rows");
     k.r1 = c.r1; k.ldr1 = c.ldr1;
-    return launch<1, false, false>(k, st);
+    return launch<1, false, false, false>(k, st);
   }
-  ARG_CHECK(c.rows_per_image > 0 && c.rows_per_image % BLOCK_ROWS == 0 && c.M % c.rows_per_image == 0 && c.out_q && c.out_k &&
-                c.ldq % 8 == 0 && c.ldk % 8 == 0,
-            "lin_chain: GroupNorm'd input form (whole images of a multiple of 128 rows; q, k, v^T outputs)");
+  ARG_CHECK(c.rows_per_image > 0 && c.M % c.rows_per_image == 0 && c.M % 8 == 0 && c.out_q && c.out_k && c.ldq % 8 == 0 && c.ldk % 8 == 0,
+            "lin_chain: GroupNorm'd input form (whole images, M % 8 == 0; q, k, v^T outputs)");
   ARG_CHECK((long)c.M * c.ldq * 2 < (1L << 31) && (long)c.M * c.ldk * 2 < (1L << 31) && (long)LC * c.ldo * 2 < (1L << 31),
             "lin_chain: output beyond the 2 GB buffer window");
   k.gn_ss = c.gn_ss; k.rows_per_image = c.rows_per_image;
   k.out_p[0] = c.out_q; k.ldp[0] = c.ldq; k.out_p[1] = c.out_k; k.ldp[1] = c.ldk;
-  return launch<3, true, true>(k, st);
+  // images of whole 128-row tiles: the (scale, shift) pairs of a tile are staged once; else they are read per row
+  return c.rows_per_image % BLOCK_ROWS == 0 ? launch<3, true, true, false>(k, st) : launch<3, true, true, true>(k, st);
 }

@@ -281,7 +281,7 @@ def test_lin_chain_out_then_query(lib, M):
     assert torch.equal(mid3, mid[lo:]) and torch.equal(q3, q[lo:])
 
 
-@pytest.mark.parametrize("B,N", [(1, 128), (3, 1024), (2, 4096), (11, 4096)])
+@pytest.mark.parametrize("B,N", [(1, 128), (3, 1024), (2, 4096), (11, 4096), (5, 576), (3, 64)])     # (24 x 24 / 8 x 8 tokens: images that are not whole 128-row tiles)
 def test_lin_chain_groupnorm_to_qkv(lib, B, N):
     """GroupNorm (applied on the fly) -> proj_in -> norm1 -> attn1.to_q | to_k | to_v^T in one kernel (hedit_k_lin_chain,
     three outputs; Transformer2DModel.norm / proj_in and the self-attention projections, oracle/sd_unet.py) == the layers

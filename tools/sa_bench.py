@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
 import ctypes as C
 import torch
 from hedit import _lib
+if os.environ.get("HEDIT_LIB_VARIANT"):       # tools/build_variant.sh side library (measurement builds)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"lib_{os.environ['HEDIT_LIB_VARIANT']}.so.bin")
 
 lib = _lib.lib()
 dev = torch.device("cuda:0")
