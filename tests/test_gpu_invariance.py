@@ -207,6 +207,19 @@ def test_sd15_reconstruction_invariant_50_steps(sd15):
     assert G.rel_err(recon, w0) < 2e-6
 
 
+def test_sd15_reconstruction_invariant_at_a_loaded_batch(sd15):
+    """The same invariant with 16 images in lock-step (80-, 64- and 32-row UNet calls: every CU walks over several
+    128-row tiles of the persistent chain kernels, 2 880 sample-forwards): exact reconstruction is the check that caught
+    a rare-row corruption no single-kernel repeat test showed."""
+    hip, _, _ = sd15
+    try:
+        w0, xts, edit, recon = _recon_run(hip, SD15_CONFIG, 16, 20, 1, 11, True)
+    finally:
+        hip.scheduler.set_timesteps(2)
+    assert torch.isfinite(edit).all()
+    assert torch.equal(recon, xts[0])
+
+
 # (function, total steps T, steps run after the skip, K, DDIM inversion / eta = 0 scheduler)
 SD15_LOOP_CASES = [
     ("h_Edit_p2p_implicit", 2, 2, 1, False),     # BASELINE configs[1]'s step
