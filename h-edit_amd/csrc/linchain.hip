@@ -122,11 +122,15 @@ __device__ __forceinline__ void mfma_l0(f32x16& acc, const bf16x8& w, const bf16
 //     stores of a result are in flight while the next layer runs.  The staging area is used strictly one thing after
 //     the other: [input rows -> fragments] [final result -> stores] [residual rows -> accumulator] [first result ->
 //     stores] ([q, k -> stores]) [next input rows ...].
-// Everything that enters the vector-memory queue between two layers (row DMA, stores) retires in issue order with the
-// weight DMA (one in-order vmcnt queue on gfx9), so the counted waits of the ring stay exact: the first iterations of
-// a layer that follows E such operations allow E more outstanding ones (template parameter of the layer) -- the burst
-// gets four iterations to complete before anybody waits for it.  The burst sizes are made the same for every tile
-// (dummy DMA in front of the first tile, bounds-checked buffer stores that are issued whether or not the row exists).
+// The bursts between two layers (row DMA, stores) sit in the same vector-memory queue as the weight DMA, so the counted
+// waits of the ring are widened while a burst is younger than the iteration waited for: the first four iterations of a
+// layer that follows E such operations allow E more outstanding ones (template parameter of the layer).  What this rests
+// on: loads retire in issue order (what every counted vmcnt ring rests on); the weights those four waits are about were
+// issued before the burst, a whole transition earlier; and a staged row is first touched a full layer (>= 7 us) after
+// its DMA was issued and behind waits that no longer tolerate it.  The burst sizes are made the same for every tile
+// (place-holder DMA in front of the first tile, bounds-checked buffer stores that are issued whether or not the row
+// exists).  Carrying the row DMA inside the layers instead was tried and is NOT what this file does: DESIGN.md 5.0.
+// SSG: the (scale, shift) pairs are read per row from global memory (images that are not whole 128-row tiles).
 template <int NPOST, bool GNIN, bool VT, bool SSG>
 __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
