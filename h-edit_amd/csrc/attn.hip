@@ -373,15 +373,12 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
     bf16x8 (&pf_cur)[2] = (J & 1) ? pfb : pfa;
     const char* st_cur = stage_of(U);
 
-    // An MFMA issued at raised priority keeps the matrix pipe fed while the VALU work written
-    // between the MFMAs (this wave's and the co-resident wave's) fills the 32-cycle gaps; s_setprio
-    // is also a scheduling boundary, so the interleaving below is what the hardware sees.
-    // (measured, tools/ubench/overlap.hip: [MFMA + 6 VALU] x2 on a 2-wave SIMD = 88 cycles flat,
-    // 70 with the MFMA at priority 1; the MFMAs alone are 65)
+    // (Round 2 issued every MFMA between s_setprio 1 / 0: on a two-wave SIMD a prioritised MFMA kept the matrix pipe fed,
+    // 88 -> 70 cycles for [MFMA + 6 VALU] x 2 in tools/ubench/overlap.hip.  With today's loop -- 92 instructions per unit,
+    // the SIMD's issue slots the scarce resource, DESIGN.md 5.0 item 7 -- the 14 s_setprio per unit cost more than the
+    // priority buys: 2.1 % faster without them at d = 40, 1.5 % at d = 80.)
     auto mfma_hi = [&](const bf16x8& x, const bf16x8& y, f32x16& acc) __attribute__((always_inline)) {
-      __builtin_amdgcn_s_setprio(1);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
     };
     constexpr int NPV = 2 * DT;
     // with a single stream the P.V of unit U-1 (formed against the old maximum) has to be
