@@ -24,7 +24,8 @@
 //     the arithmetic of the whole chain).  Inputs: DMA of whole rows (lanes fetch consecutive 16-byte chunks) into the
 //     staging area with the chunk index XOR-swizzled by the row, then ds_read of the fragment / accumulator layout.
 //     Outputs: bf16(O) written to the staging area in the same swizzle, read back as row pieces, 16-byte coalesced
-//     stores.  v^T leaves through a block-wide [320][128] transposing stage (the ring is free by then).
+//     stores.  v^T leaves through the same area staged transposed per wave ([320 features][32 rows]: 64 contiguous
+//     bytes of the [C][M] result per feature).
 // Every output row depends on its own input row only and the summation order is fixed.
 #include <type_traits>
 #include <utility>
