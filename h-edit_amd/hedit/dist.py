@@ -45,7 +45,28 @@ def _numel(shape):
     return n
 
 
-def broadcast_state_dict(shapes, sd, src=0, device="cpu", group=None, bf16_names=()):
+def _agree(rank, src, group, problem, extra):
+    """Rank `src` tells every rank how its preparation went BEFORE anybody enters a tensor collective: a rank that
+    raised on its own (missing file, missing key, wrong shape) would leave the others blocked in `dist.broadcast` until
+    the backend's timeout, with no message.  -> the list of checkpoint keys nobody asked for; raises on EVERY rank when
+    `src` reported a problem."""
+    box = [problem, list(extra)] if rank == src else [None, None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    if box[0] is not None:
+        raise RuntimeError(f"rank {src} could not provide the weights: {box[0]}")
+    return box[1]
+
+
+class UnexpectedKey:
+    """Stands in, on the receiving ranks, for a checkpoint tensor that rank 0 read and no module asked for: its NAME is
+    what a strict `load_state_dict` reports, so several ranks refuse the same checkpoints a single process refuses."""
+    shape = ()
+
+    def __repr__(self):
+        return "<checkpoint key without a parameter>"
+
+
+def broadcast_state_dict(shapes, sd, src=0, device="cpu", group=None, bf16_names=(), problem=None):
     """Every rank returns the full {name: tensor} dict that rank `src` holds in `sd` (other ranks pass None).
     The tensors are packed, in the deterministic order of `shapes`, into at most TWO flat blobs -- bf16 for the
     names in `bf16_names` (the matrices / convolutions the executor keeps as unscaled bf16 copies anyway:
@@ -53,7 +74,11 @@ def broadcast_state_dict(shapes, sd, src=0, device="cpu", group=None, bf16_names
     (biases, norm parameters, pre-scaled projections) -- and each blob is broadcast once: 1.7 GB instead of 3.4 GB for
     the SD-1.5 UNet, one collective per blob, no per-tensor launches.  Every tensor starts on a 16-byte
     boundary of its blob.  The returned tensors are VIEWS of the two blobs: consume them (load_state_dict) and drop
-    the dict as a whole -- keeping a single view alive pins its entire blob."""
+    the dict as a whole -- keeping a single view alive pins its entire blob.
+
+    Before the blobs, `src` announces whether it has every tensor in the right shape (`problem`: what already went
+    wrong while reading, if anything) and which keys of `sd` are not in `shapes`; a failure raises on every rank, and
+    the surplus keys come back as `UnexpectedKey` entries behind the real ones, so a strict load sees them everywhere."""
     rank = dist.get_rank(group)
     bf16_names = set(bf16_names)
     plans = {torch.bfloat16: [], torch.float32: []}
@@ -64,6 +89,19 @@ def broadcast_state_dict(shapes, sd, src=0, device="cpu", group=None, bf16_names
         plans[dt].append((name, tuple(shape), totals[dt], n))
         align = 16 // (2 if dt == torch.bfloat16 else 4)
         totals[dt] += (n + align - 1) // align * align
+    extra = []
+    if rank == src and problem is None:
+        if sd is None:
+            problem = "no state dict on the source rank"
+        else:
+            missing = [n for n in shapes if n not in sd]
+            bad = [f"{n}: {tuple(sd[n].shape)} != {tuple(shapes[n])}" for n in shapes if n in sd and tuple(sd[n].shape) != tuple(shapes[n])]
+            if missing:
+                problem = f"missing {missing[:5]} ({len(missing)})"
+            elif bad:
+                problem = f"shape mismatch {bad[:5]} ({len(bad)})"
+            extra = [n for n in sd if n not in shapes]
+    extra = _agree(rank, src, group, problem, extra)
     out = {}
     for dt, plan in plans.items():
         if not plan:
@@ -71,25 +109,30 @@ def broadcast_state_dict(shapes, sd, src=0, device="cpu", group=None, bf16_names
         flat = torch.zeros(totals[dt], dtype=dt, device=device)
         if rank == src:
             for name, shape, off, n in plan:
-                t = sd[name]
-                if tuple(t.shape) != shape:
-                    raise ValueError(f"{name}: shape {tuple(t.shape)} != {shape}")
-                flat[off:off + n].copy_(t.reshape(-1).to(dtype=dt))
+                flat[off:off + n].copy_(sd[name].reshape(-1).to(dtype=dt))
         dist.broadcast(flat, src=src, group=group)
         for name, shape, off, n in plan:
             out[name] = flat[off:off + n].view(shape)
-    return {name: out[name] for name in shapes}
+    res = {name: out[name] for name in shapes}
+    for name in extra:
+        res[name] = sd[name] if rank == src else UnexpectedKey()
+    return res
 
 
 def state_dict_from_rank0(read_fn, shapes, device="cpu", bf16_names=(), group=None):
     """The product drivers' checkpoint path: ONLY rank 0 calls ``read_fn()`` (reads the file), every rank gets the
     tensors by broadcast -- one file read per job instead of one per GPU (replaces the per-process
     StableDiffusionPipeline.from_pretrained of text-guided/main_p2p.py:119 when the job has several ranks).
-    A single process (no group) just reads."""
+    A single process (no group) just reads.  If the read fails on rank 0, every rank raises with its message."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return read_fn()
-    sd = read_fn() if dist.get_rank(group) == 0 else None
-    return broadcast_state_dict(shapes, sd, src=0, device=device, group=group, bf16_names=bf16_names)
+    sd, problem = None, None
+    if dist.get_rank(group) == 0:
+        try:
+            sd = read_fn()
+        except Exception as e:      # noqa: BLE001 -- whatever it was, the other ranks must hear about it
+            problem = f"{type(e).__name__}: {e}"
+    return broadcast_state_dict(shapes, sd, src=0, device=device, group=group, bf16_names=bf16_names, problem=problem)
 
 
 def max_over_ranks(value, device="cpu", group=None):

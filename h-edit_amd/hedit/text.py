@@ -25,25 +25,48 @@ class WordTokenizer:
         self._ids = {}
         self._words = {}
 
+    @staticmethod
+    def _hash_id(w, attempt, n_ids):
+        import hashlib
+        key = w if attempt == 0 else f"{w}\x00{attempt}"
+        return 1 + int.from_bytes(hashlib.sha256(key.encode("utf-8")).digest()[:8], "big") % n_ids
+
     def _id(self, w):
         # default: ids in order of first sight (what the committed golden vectors were generated with).  stable_ids: a
         # word's id is a function of the word ALONE (64 bits of SHA-256 into the id range), so a synthetic-weights run
         # gives a prompt the same embedding whether its image is edited alone or inside a lock-step batch (the drivers'
-        # --random_init pipelines).  Two different words landing on one id would make an id depend on the order of
-        # first sight again: that is refused loudly instead of being probed around.
+        # --random_init pipelines).  The id range has ~49 k slots, so a real prompt set (a few hundred distinct words)
+        # does see collisions: the later word is then re-hashed with a counter until it finds a free id -- deterministic
+        # for a given order of first sight, and reported once per word, because for THAT word the id now does depend
+        # on what was tokenised before it.  `prescan` assigns the ids of a known vocabulary in sorted order up front,
+        # which removes that dependence altogether (the drivers call it with every prompt of the run).
         if w not in self._ids:
             if len(self._ids) >= self.bos_token_id - 1:
                 raise RuntimeError("WordTokenizer vocabulary exhausted")
             i = 1 + len(self._ids)
             if self.stable_ids:
-                import hashlib
-                i = 1 + int.from_bytes(hashlib.sha256(w.encode("utf-8")).digest()[:8], "big") % (self.bos_token_id - 1)
-                if i in self._words:
-                    raise RuntimeError(f"WordTokenizer(stable_ids): {w!r} and {self._words[i]!r} hash to the same id {i}; "
-                                       "word ids would depend on prompt order -- use a real tokenizer for this vocabulary")
+                n_ids = self.bos_token_id - 1
+                attempt = 0
+                i = self._hash_id(w, 0, n_ids)
+                while i in self._words:
+                    attempt += 1
+                    i = self._hash_id(w, attempt, n_ids)
+                if attempt:
+                    import warnings
+                    warnings.warn(f"WordTokenizer(stable_ids): {w!r} collides with {self._words[self._hash_id(w, 0, n_ids)]!r}; "
+                                  f"re-hashed to id {i} (attempt {attempt}) -- for this word the id depends on the order of "
+                                  "first sight; call prescan() with the run's prompts to make it order-independent", stacklevel=3)
             self._ids[w] = i
             self._words[i] = w
         return self._ids[w]
+
+    def prescan(self, prompts):
+        """Assign the ids of every word of `prompts` now, in sorted word order: with stable_ids a collision is then
+        resolved the same way whatever order the prompts are tokenised in later (batch invariance of a whole run)."""
+        words = sorted({w for p in prompts for w in p.split(" ") if w != ""})
+        for w in words:
+            self._id(w)
+        return len(words)
 
     def encode(self, text):
         return [self.bos_token_id] + [self._id(w) for w in text.split(" ") if w != ""] + [self.eos_token_id]
@@ -61,6 +84,21 @@ class WordTokenizer:
             ids = self.encode(p)[:max_length]
             rows.append(ids + [self.eos_token_id] * (max_length - len(ids)))
         return types.SimpleNamespace(input_ids=torch.tensor(rows, dtype=torch.int64))
+
+
+def prescan_prompts(tokenizer, records):
+    """Give a stand-in tokenizer the whole vocabulary of a run before any work starts (a no-op for real tokenizers,
+    which have no `prescan`).  `records`: dataset entries with ``original_prompt`` / ``editing_prompt`` as the drivers
+    read them (the demo file calls them ``source_prompt`` / ``target_prompt``; square brackets around the edited words are stripped there, so they are stripped here).  Every rank
+    of a sharded run passes the FULL dataset, so the ids do not depend on the shard either."""
+    if not hasattr(tokenizer, "prescan"):
+        return 0
+    prompts = []
+    for r in records:
+        for k in ("original_prompt", "editing_prompt", "source_prompt", "target_prompt"):
+            if isinstance(r, dict) and r.get(k):
+                prompts.append(r[k].replace("[", "").replace("]", ""))
+    return tokenizer.prescan(prompts)
 
 
 class ClipTextEncoder(nn.Module):

@@ -29,6 +29,7 @@ if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
 from hedit import dist as D  # noqa: E402
+from hedit.text import prescan_prompts  # noqa: E402
 from hedit.inversion.ddim_inversion import ddim_inversion  # noqa: E402
 from hedit.inversion.ddpm_inversion import inversion_forward_process_ddpm  # noqa: E402
 from hedit.inversion.p2p_h_edit import (h_Edit_p2p_explicit, h_Edit_p2p_implicit, h_Edit_R_explicit,  # noqa: E402
@@ -105,6 +106,7 @@ def main(argv=None):
                      f'_tar_scale_{args.cfg_tar}_w_rec_{args.weight_reconstruction}_n_opts_{args.optimization_steps}'
                      f'_time_{time_stamp}')
     model = load_model(args, device)
+    prescan_prompts(model.tokenizer, (full_data.values() if isinstance(full_data, dict) else full_data))      # (stand-in tokenizer only: word ids independent of order / shard)
     if model.vae is None:
         raise SystemExit("the checkpoint has no vae/ sub-folder: images cannot be encoded / decoded")
     scale = model.vae.config["scaling_factor"]

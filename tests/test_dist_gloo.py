@@ -72,7 +72,9 @@ def _driver_worker(rank, world, port, q, ckpt_dir):
             reads.append(1)
             return CK.read_component(ckpt_dir)[1]
         got = HD.state_dict_from_rank0(read, shapes, device="cpu", bf16_names={"m.weight", "conv.weight"})
-        q.put((rank, {k: (str(v.dtype), v.float().clone(), v.data_ptr() % 16) for k, v in got.items()}, len(reads), (rk, w)))
+        surplus = [k for k in got if k not in shapes]
+        q.put((rank, {k: (str(got[k].dtype), got[k].float().clone(), got[k].data_ptr() % 16) for k in shapes}, len(reads), (rk, w),
+               list(got), surplus))
     finally:
         dist.destroy_process_group()
 
@@ -95,15 +97,60 @@ def test_driver_reads_on_rank0_and_broadcasts(tmp_path):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, a, reads0, rw0), (_, b, reads1, rw1) = res
+    (_, a, reads0, rw0, keys0, sur0), (_, b, reads1, rw1, keys1, sur1) = res
     assert reads0 == 1 and reads1 == 0 and rw0 == (0, 2) and rw1 == (1, 2)
     assert list(a) == list(shapes) == list(b)
+    # the checkpoint key no module asked for is reported on BOTH ranks, behind the real ones: a strict load_state_dict
+    # refuses the same checkpoints on several ranks as in a single process
+    assert keys0 == keys1 == list(shapes) + ["unused.extra"] and sur0 == sur1 == ["unused.extra"]
     for k in shapes:
         assert a[k][0] == b[k][0] == ("torch.bfloat16" if k in ("m.weight", "conv.weight") else "torch.float32")
         assert torch.equal(a[k][1], b[k][1])                       # every rank holds the same bits
         want = sd[k].to(torch.bfloat16).float() if k in ("m.weight", "conv.weight") else sd[k]
         assert torch.equal(a[k][1], want)                          # bf16 only where it was asked for; fp32 tensors exact
         assert a[k][2] == 0 and b[k][2] == 0                       # 16-byte aligned views
+
+
+def _failing_worker(rank, world, port, q, what):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    HD.init_from_env("cpu")
+    try:
+        shapes = {"m.weight": (6, 5), "m.bias": (6,)}
+
+        def read():
+            if what == "io":
+                raise FileNotFoundError("no such checkpoint: /nowhere/unet")
+            sd = {"m.weight": torch.zeros(6, 5), "m.bias": torch.zeros(6)}
+            if what == "missing":
+                del sd["m.bias"]
+            if what == "shape":
+                sd["m.weight"] = torch.zeros(5, 6)
+            return sd
+        try:
+            HD.state_dict_from_rank0(read, shapes, device="cpu")
+            q.put((rank, None))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank0_failure_reaches_every_rank():
+    """A checkpoint problem on rank 0 (file, key, shape) raises on BOTH ranks with rank 0's message instead of leaving
+    rank 1 blocked in the broadcast until the backend times out."""
+    ctx = mp.get_context("spawn")
+    for what, needle in (("io", "FileNotFoundError"), ("missing", "missing ['m.bias']"), ("shape", "shape mismatch")):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q, what)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        for rank, msg in res:
+            assert msg is not None and needle in msg and "rank 0" in msg, (what, rank, msg)
 
 
 def test_shard_properties():

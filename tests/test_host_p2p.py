@@ -176,3 +176,32 @@ def test_word_tokenizer_stable_ids_do_not_depend_on_prompt_order():
     assert len(set(ia1[1:-1])) == len(set(p1.split(" ")))
     c, d = WordTokenizer(), WordTokenizer()
     assert c.encode(p1)[1:4] == [1, 2, 3] and d.encode(p2)[1:4] == [1, 2, 3]
+
+
+def test_word_tokenizer_stable_ids_survive_collisions():
+    """A real prompt set collides in the ~49 k id range (birthday bound: ~10 % at 100 words): the later word is re-hashed
+    with a counter and reported, nothing raises in the middle of a run; `prescan` with the run's vocabulary makes the
+    resolution independent of the order the prompts are tokenised in."""
+    import warnings
+    from hedit.text import WordTokenizer, prescan_prompts
+
+    class Small(WordTokenizer):           # 40 id slots: 30 words must collide
+        bos_token_id, eos_token_id = 41, 42
+
+    words = [f"w{i}" for i in range(30)]
+    prompts = [" ".join(words[i:i + 5]) for i in range(0, 30, 5)]
+    a = Small(stable_ids=True)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        ids = [a.encode(p)[1:-1] for p in prompts]
+    flat = [i for row in ids for i in row]
+    assert len(set(flat)) == 30 and all(1 <= i <= 40 for i in flat)          # every word its own id, inside the range
+    assert any("collides" in str(w.message) for w in rec)
+    # order-independent once the vocabulary was pre-scanned (records as the drivers hold them)
+    recs = [{"original_prompt": f"[{p}]", "editing_prompt": p} for p in prompts]
+    b, c = Small(stable_ids=True), Small(stable_ids=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert prescan_prompts(b, recs) == 30 and prescan_prompts(c, list(reversed(recs))) == 30
+        assert [b.encode(p) for p in prompts] == [c.encode(p) for p in reversed(prompts)][::-1]
+    assert prescan_prompts(object(), recs) == 0                                 # real tokenizers: untouched
