@@ -571,12 +571,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
 template <int D, int QG, int NS>
 int launch_self(const SelfAttnParams& p, hipStream_t st) {
   using C = SelfCfg<D, QG>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_kernel<D, QG, NS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL));
-    attr_set = true;
-  }
+  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&self_attn_kernel<D, QG, NS>), C::TOTAL)) return rc;
   dim3 grid(cdiv(p.N, 128 * QG) * p.heads * p.B);
   hipLaunchKernelGGL((self_attn_kernel<D, QG, NS>), grid, dim3(256), C::TOTAL, st, p);
   LAUNCH_CHECK();
@@ -790,12 +785,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void cross_attn_kernel(Cros
 template <int D>
 int launch_cross(const CrossAttnParams& p, hipStream_t st) {
   using S = CrossSmem<D>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_kernel<D>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, S::TOTAL));
-    attr_set = true;
-  }
+  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&cross_attn_kernel<D>), S::TOTAL)) return rc;
   dim3 grid(cdiv(p.N, 128), p.heads, p.n_pairs + p.n_single);
   hipLaunchKernelGGL((cross_attn_kernel<D>), grid, dim3(256), S::TOTAL, st, p);
   LAUNCH_CHECK();

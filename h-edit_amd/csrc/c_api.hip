@@ -2,7 +2,11 @@
 // parity tests call (see include/hedit.h).
 #include "../../include/hedit.h"
 #include <exception>
+#include <map>
+#include <mutex>
 #include <new>
+#include <set>
+#include <utility>
 
 #include "common.h"
 #include "kernels.h"
@@ -25,6 +29,36 @@ int hedit_abi_catch() noexcept {
     // even the message could not be stored; the code alone reports the failure
   }
   return HEDIT_ERR_STATE;
+}
+
+namespace {
+std::mutex g_dev_mu;
+std::set<std::pair<const void*, int>> g_lds_set;      // (kernel, device) pairs whose dynamic-LDS limit was raised
+std::map<int, int> g_cus;                              // device -> CU count
+}  // namespace
+
+int hedit_dyn_lds(const void* kernel, int bytes) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  if (g_lds_set.count({kernel, dev})) return HEDIT_OK;
+  HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  g_lds_set.insert({kernel, dev});
+  return HEDIT_OK;
+}
+
+int hedit_cu_count(int* cus) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  auto it = g_cus.find(dev);
+  if (it == g_cus.end()) {
+    int n = 0;
+    HIP_TRY(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    it = g_cus.emplace(dev, n).first;
+  }
+  *cus = it->second;
+  return HEDIT_OK;
 }
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }

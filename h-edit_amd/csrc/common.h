@@ -17,6 +17,11 @@ void hedit_set_error(const std::string& msg);
 // Called from the catch (...) of every extern "C" entry point (they are function-try-blocks): turns whatever the C++
 // runtime threw inside the library (std::bad_alloc from a handle's containers, ...) into an error code + message.
 int hedit_abi_catch() noexcept;
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are PER DEVICE: a process that drives several GPUs (or
+// switches devices) must not inherit the first device's answer.  Both are remembered per (kernel, device) / per device
+// behind a mutex; a launch pays one hipGetDevice and a small lookup.
+int hedit_dyn_lds(const void* kernel, int bytes);      // HEDIT_OK, or HEDIT_ERR_HIP with the message set
+int hedit_cu_count(int* cus);                          // CUs of the CURRENT device
 #define HEDIT_OK 0
 #define HEDIT_ERR_ARG (-1)
 #define HEDIT_ERR_HIP (-2)

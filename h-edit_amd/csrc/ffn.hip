@@ -637,11 +637,7 @@ int ffn_pack_bias_launch(const float* b1, float* out, hipStream_t st) {
 
 template <bool PRE, bool POST>
 static int launch_chain(const ChainKernelParams& k, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_chain_kernel<PRE, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    attr_set = true;
-  }
+  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&ffn_chain_kernel<PRE, POST>), LDS_TOTAL)) return rc;
   hipLaunchKernelGGL((ffn_chain_kernel<PRE, POST>), dim3(cdiv(k.M, BLOCK_ROWS)), dim3(256), LDS_TOTAL, st, k);
   LAUNCH_CHECK();
   return HEDIT_OK;

@@ -868,12 +868,7 @@ template <int BM, int BN, int MODE, bool CHUNK>
 int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
   using S = Smem<BM, BN>;
   constexpr int LDS = (MODE == 4 || MODE == 5) ? S::RS_TOTAL : S::TOTAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
+  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK>), LDS)) return rc;
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), splits);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, CHUNK>), grid, dim3(BM * 2), LDS, st, p);
   LAUNCH_CHECK();

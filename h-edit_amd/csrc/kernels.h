@@ -74,7 +74,11 @@ struct LinChainParams {
 int lin_chain_launch(const LinChainParams& c, hipStream_t st);
 size_t lin_chain_stream_bytes(int layers);        // layers = 2 (to_out, to_q) or 4 (proj_in, to_q, to_k, to_v)
 // w [C][C] fp32 -> layer `layer` of the stream (layer 0 takes its input from HBM: natural k order; the others read an
-// accumulator: register order); the call for layer 0 also zeroes the DMA overrun behind the last layer
+// accumulator: register order).  The stream is CYCLIC (layers * 20 iterations of 10 KB, no padding, no overrun: the
+// kernel wraps around to iteration 0 for the next tile), and every byte of it is written by exactly one layer's pack
+// call -- a stream is complete once all `layers` calls have run; nothing is zeroed by anybody.
+// Largest launch: M * ld * 2 bytes of every row tensor below 2 GiB (32-bit buffer offsets), i.e. M < 1 677 721 rows of
+// 320 channels with dense rows = 409 rows of 64 x 64 tokens (the bench runs 120); lin_chain_launch refuses more.
 int lin_chain_pack_launch(const float* w, int layer, float scale, int layers, bf16_t* stream, hipStream_t st);
 int ffn_fused_channels();
 size_t ffn_stream_bytes(int pre, int post);

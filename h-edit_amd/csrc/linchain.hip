@@ -513,17 +513,9 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
 
 template <int NPOST, bool GNIN, bool VT, bool SSG>
 int launch(const LinKernelParams& k, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_chain_kernel<NPOST, GNIN, VT, SSG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    attr_set = true;
-  }
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&lin_chain_kernel<NPOST, GNIN, VT, SSG>), LDS_TOTAL)) return rc;
+  int cus = 0;
+  if (int rc = hedit_cu_count(&cus)) return rc;
   const int ntiles = cdiv(k.M, BLOCK_ROWS);
   hipLaunchKernelGGL((lin_chain_kernel<NPOST, GNIN, VT, SSG>), dim3(ntiles < cus ? ntiles : cus), dim3(256), LDS_TOTAL, st, k);
   LAUNCH_CHECK();
@@ -542,26 +534,65 @@ int lin_chain_pack_launch(const float* w, int layer, float scale, int layers, bf
   return HEDIT_OK;
 }
 
-int lin_chain_launch(const LinChainParams& c, hipStream_t st) {
-  ARG_CHECK(c.C == LC, "lin_chain: exists for C = 320");
-  ARG_CHECK(c.M > 0 && c.a && c.stream && c.gamma && c.beta && c.bias_pre && c.out_mid && c.out, "lin_chain: null");
-  ARG_CHECK(c.lda % 8 == 0 && c.ldmid % 8 == 0 && c.ldo % 8 == 0, "lin_chain: rows must be 16-byte aligned");
+// one launch: every row tensor inside the 2 GiB window of a buffer descriptor's 32-bit offsets
+static int lin_chain_launch_one(const LinChainParams& c, hipStream_t st) {
   ARG_CHECK((long)c.M * c.lda * 2 < (1L << 31) && (long)c.M * c.ldmid * 2 < (1L << 31) && (c.gn_ss || (long)c.M * c.ldo * 2 < (1L << 31)),
             "lin_chain: tensor beyond the 2 GB buffer window");
   LinKernelParams k{};
   k.a = c.a; k.lda = c.lda; k.bias_pre = c.bias_pre; k.gamma = c.gamma; k.beta = c.beta; k.eps = c.eps;
   k.stream = c.stream; k.M = c.M; k.out_mid = c.out_mid; k.ldmid = c.ldmid; k.out = c.out; k.ldo = c.ldo;
   if (!c.gn_ss) {
-    ARG_CHECK(c.r1 && c.ldr1 % 8 == 0 && (long)c.M * c.ldr1 * 2 < (1L << 31), "lin_chain: residual rows");
+    ARG_CHECK((long)c.M * c.ldr1 * 2 < (1L << 31), "lin_chain: residual rows beyond the 2 GB buffer window");
     k.r1 = c.r1; k.ldr1 = c.ldr1;
     return launch<1, false, false, false>(k, st);
   }
-  ARG_CHECK(c.rows_per_image > 0 && c.M % c.rows_per_image == 0 && c.M % 8 == 0 && c.out_q && c.out_k && c.ldq % 8 == 0 && c.ldk % 8 == 0,
-            "lin_chain: GroupNorm'd input form (whole images, M % 8 == 0; q, k, v^T outputs)");
   ARG_CHECK((long)c.M * c.ldq * 2 < (1L << 31) && (long)c.M * c.ldk * 2 < (1L << 31) && (long)LC * c.ldo * 2 < (1L << 31),
             "lin_chain: output beyond the 2 GB buffer window");
   k.gn_ss = c.gn_ss; k.rows_per_image = c.rows_per_image;
   k.out_p[0] = c.out_q; k.ldp[0] = c.ldq; k.out_p[1] = c.out_k; k.ldp[1] = c.ldk;
   // images of whole 128-row tiles: the (scale, shift) pairs of a tile are staged once; else they are read per row
   return c.rows_per_image % BLOCK_ROWS == 0 ? launch<3, true, true, false>(k, st) : launch<3, true, true, true>(k, st);
+}
+
+int lin_chain_launch(const LinChainParams& c, hipStream_t st) {
+  ARG_CHECK(c.C == LC, "lin_chain: exists for C = 320");
+  ARG_CHECK(c.M > 0 && c.a && c.stream && c.gamma && c.beta && c.bias_pre && c.out_mid && c.out, "lin_chain: null");
+  ARG_CHECK(c.lda % 8 == 0 && c.ldmid % 8 == 0 && c.ldo % 8 == 0, "lin_chain: rows must be 16-byte aligned");
+  if (!c.gn_ss) ARG_CHECK(c.r1 && c.ldr1 % 8 == 0, "lin_chain: residual rows");
+  else
+    ARG_CHECK(c.rows_per_image > 0 && c.M % c.rows_per_image == 0 && c.M % 8 == 0 && c.out_q && c.out_k && c.ldq % 8 == 0 && c.ldk % 8 == 0,
+              "lin_chain: GroupNorm'd input form (whole images, M % 8 == 0; q, k, v^T outputs)");
+  // Rows are independent and a launch addresses its tensors through 32-bit buffer offsets, so a batch whose widest row
+  // tensor passes 2 GiB (M >= 1.67 M rows of 320 dense channels: > 400 rows of 64 x 64 tokens) runs as several launches
+  // over row ranges -- whole tiles, and whole images where the GroupNorm pairs are per image.  Same bits as one launch.
+  long ldmax = c.lda > c.ldmid ? c.lda : c.ldmid;
+  if (!c.gn_ss) { if (c.ldo > ldmax) ldmax = c.ldo; if (c.ldr1 > ldmax) ldmax = c.ldr1; }
+  else { if (c.ldq > ldmax) ldmax = c.ldq; if (c.ldk > ldmax) ldmax = c.ldk; }
+  long cap = ((1L << 31) - 1) / (ldmax * 2);
+  if (c.M <= cap) return lin_chain_launch_one(c, st);
+  long unit = BLOCK_ROWS;
+  if (c.gn_ss) {      // lcm(128, rows_per_image): ranges start on an image boundary AND a tile boundary
+    long a = unit, b = c.rows_per_image;
+    while (b) { const long t = a % b; a = b; b = t; }
+    unit = unit / a * c.rows_per_image;
+  }
+  cap = cap / unit * unit;
+  ARG_CHECK(cap > 0, "lin_chain: one image's rows do not fit the 2 GB buffer window");
+  for (long r0 = 0; r0 < c.M; r0 += cap) {
+    LinChainParams p = c;
+    p.M = (int)(c.M - r0 < cap ? c.M - r0 : cap);
+    p.a = c.a + r0 * c.lda;
+    p.out_mid = c.out_mid + r0 * c.ldmid;
+    if (!c.gn_ss) {
+      p.r1 = c.r1 + r0 * c.ldr1;
+      p.out = c.out + r0 * c.ldo;
+    } else {
+      p.gn_ss = c.gn_ss + (r0 / c.rows_per_image) * LC * 2;
+      p.out_q = c.out_q + r0 * c.ldq;
+      p.out_k = c.out_k + r0 * c.ldk;
+      p.out = c.out + r0;                       // v^T [C][ldo]: a column range
+    }
+    if (int rc = lin_chain_launch_one(p, st)) return rc;
+  }
+  return HEDIT_OK;
 }

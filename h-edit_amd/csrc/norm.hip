@@ -732,13 +732,8 @@ int conv_in_launch(const float* x, const float* w, const float* bias, bf16_t* y,
   ARG_CHECK(Cout % 8 == 0, "conv_in: Cout % 8");
   const size_t lds = ((size_t)Cin * 9 * Cout + CI_PIX * (size_t)Cin * 9) * sizeof(float);
   ARG_CHECK(lds <= 160 * 1024, "conv_in: Cin*9*(Cout+128) floats must fit 160 KiB of LDS");
-  if (lds > 64 * 1024) {
-    static size_t attr_set = 0;
-    if (lds > attr_set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_in_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = lds;
-    }
-  }
+  if (lds > 64 * 1024)
+    if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&conv_in_kernel), 160 * 1024)) return rc;      // (the ceiling once, per device)
   hipLaunchKernelGGL(conv_in_kernel, dim3(cdiv((long)B * H * W, CI_PIX)), dim3(256), lds, st, x, w, bias, y, B, Cin, H, W, Cout);
   LAUNCH_CHECK();
   return HEDIT_OK;

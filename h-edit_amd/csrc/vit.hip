@@ -654,13 +654,9 @@ int hedit_vit_finalize(hedit_vit* h, void* stream) try {
     TRY(make_pconv(h, k.fc, k.wfc, nullptr, 4 * W, W, 1, 0, 0, st));
     TRY(make_pconv(h, k.proj, k.wp, nullptr, W, 4 * W, 1, 0, 0, st));
   }
-  static bool attr = false;
-  if (!attr) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATTN_LDS_FWD));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATTN_LDS_DQ));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATTN_LDS_DKV));
-    attr = true;
-  }
+  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&attn_fwd_kernel), (int)ATTN_LDS_FWD)) return rc;
+  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&attn_bwd_dq_kernel), (int)ATTN_LDS_DQ)) return rc;
+  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel), (int)ATTN_LDS_DKV)) return rc;
   HIP_TRY(hipStreamSynchronize(st));
   if (h->alloc_failed) { hedit_set_error("hipMalloc failed while packing the ViT weights"); return HEDIT_ERR_HIP; }
   h->finalized = true;

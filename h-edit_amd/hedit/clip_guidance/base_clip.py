@@ -180,8 +180,9 @@ class _NativeGramResidual(torch.autograd.Function):
     """Gram(x_b) - Gram_ref as a differentiable (B, D, D) tensor, for callers that take the residual itself (the
     reference's closure: torch.linalg.norm(get_gram_matrix_residual(img)), h_edit.py:172-175).  Backward for an
     arbitrary upstream gradient U_b through the executor's norm-gradient entry: a Gram matrix is symmetric, so only the
-    symmetric part of U_b acts on it; with the per-image reference R_b = Gram_b - sym(U_b) that entry back-propagates
-    (Gram_b - R_b) / |Gram_b - R_b| = sym(U_b) / |sym(U_b)|, so |sym(U_b)| times its result is exactly J^T U_b."""
+    symmetric part of U_b acts on it; with the per-image reference R_b = Gram_b - s_b sym(U_b) (s_b > 0, see backward)
+    that entry back-propagates (Gram_b - R_b) / |Gram_b - R_b| = sym(U_b) / |sym(U_b)|, so |sym(U_b)| times its result
+    is exactly J^T U_b."""
 
     @staticmethod
     def forward(ctx, x, owner):
@@ -197,7 +198,15 @@ class _NativeGramResidual(torch.autograd.Function):
         up = 0.5 * (up.float() + up.float().transpose(1, 2))
         nrm = up.flatten(1).norm(dim=1)
         live = nrm > 0
-        ref = torch.where(live.view(-1, 1, 1), gram - up, gram - 1.0).contiguous()      # (a dead row must not divide by 0)
+        # The native entry normalises Gram - R, so any positive multiple of sym(U) gives the same direction: scale it
+        # (by a power of two, exact) to the magnitude of the Gram entries before it is subtracted from them.  Unscaled,
+        # Gram - (Gram - sym(U)) only returns sym(U) up to half an ulp of Gram: with ViT-B/16 features the Gram
+        # entries are 1e3...1e5 (ulp 1e-4...1e-2) and the entries of a unit-norm U about 1e-3, i.e. mostly lost.
+        gmax = gram.flatten(1).abs().amax(dim=1)
+        umax = up.flatten(1).abs().amax(dim=1)
+        s = torch.exp2(torch.round(torch.log2(torch.where(live & (gmax > 0), gmax / umax.clamp_min(1e-38), torch.ones_like(gmax)))))
+        s = torch.where(torch.isfinite(s) & (s > 0), s, torch.ones_like(s)).view(-1, 1, 1)
+        ref = torch.where(live.view(-1, 1, 1), gram - s * up, gram - 1.0).contiguous()  # (a dead row must not divide by 0)
         _, grad = ctx.owner._native_loss_and_grad(xd, ref=ref)
         return grad * torch.where(live, nrm, torch.zeros_like(nrm)).view(-1, 1, 1, 1), None
 
