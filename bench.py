@@ -513,11 +513,13 @@ def main():
 def cpu_baseline(cfg, sd_cpu, T, K, tok, text_layers=12, text_heads=12):
     """The oracle (CPU fp32 eager restatement = "port" of the reference's CPU path, oracle/loops.py + oracle/sd_unet.py)
     timed on this box's host cores on a bounded sample of BASELINE configs[0] ITSELF (C1 =
-    text-guided implicit h-edit without the P2P controller, 1 image, 64x64 latent, 20 DDIM steps, K = 1): ONE sampler
-    step of h_Edit_R_implicit (text-guided/inversion/p2p_h_edit.py:281-315) in the reference's loop shape = 6 of C1's
-    120 sample-forwards (a 2-row base pass and a 4-row correction pass), after one untimed 1-row forward that
-    touches the weights and spins up the thread pool.  `value` is the bench metric's configuration (configs[1],
-    (4 + 5K) T sample-forwards per image) extrapolated by sample-forward count; the C1 figure is beside it."""
+    text-guided implicit h-edit without the P2P controller, 1 image, 64x64 latent, 20 DDIM steps, K = 1): TWO
+    consecutive sampler steps of h_Edit_R_implicit (text-guided/inversion/p2p_h_edit.py:281-315) in the reference's loop
+    shape = 12 of C1's 120 sample-forwards (per step a 2-row base pass and a 4-row correction pass), after one untimed
+    1-row forward that touches the weights and spins up the thread pool.  The host's load average is recorded beside
+    the timing (the figure moves 25 -> 46 s per step with what else runs on the box).  `value` is the bench metric's
+    configuration (configs[1], (4 + 5K) T sample-forwards per image) extrapolated by sample-forward count -- an
+    EXTRAPOLATION, x37.5 --; the C1 figure (x10) is beside it."""
     import types
     sys.path.insert(0, ROOT)
     from oracle import loops as OL
@@ -525,7 +527,7 @@ def cpu_baseline(cfg, sd_cpu, T, K, tok, text_layers=12, text_heads=12):
     from oracle import sd_unet as OU
     from hedit.scheduler import DDIMScheduler
     from hedit.text import ClipTextEncoder
-    T0 = 20
+    T0, NS = 20, 2
     net = OU.UNet2DConditionModel(**cfg)
     net.load_state_dict(sd_cpu)
     net.eval()
@@ -533,30 +535,35 @@ def cpu_baseline(cfg, sd_cpu, T, K, tok, text_layers=12, text_heads=12):
         p.requires_grad_(False)
     om = types.SimpleNamespace(device=torch.device("cpu"), unet=net, scheduler=DDIMScheduler(), tokenizer=tok, vae=None,
                                text_encoder=ClipTextEncoder(dim=cfg["cross_attention_dim"], layers=text_layers, heads=text_heads, seed=7))
-    om.scheduler.set_timesteps(1)        # a one-step schedule: after_skip_steps == num_inference_steps, so the loop runs exactly one
-    src, tar, _, _ = DEMO_PAIRS[0]       # regular sampler step (no time-ahead correction); a step's cost does not depend on t
+    om.scheduler.set_timesteps(NS)       # an NS-step schedule: after_skip_steps == num_inference_steps, so the loop runs exactly NS
+    src, tar, _, _ = DEMO_PAIRS[0]       # regular sampler steps (no time-ahead correction); a step's cost does not depend on t
     oc = OP.Controller("store")
     g = torch.Generator().manual_seed(5)
     S = cfg["sample_size"]
     x = torch.randn(1, 4, S, S, generator=g)
-    z = torch.randn(1, 1, 4, S, S, generator=g)
+    z = torch.randn(NS, 4, S, S, generator=g)
     threads = torch.get_num_threads()
     OP.register(om, oc)
+    load0 = os.getloadavg()
     with torch.no_grad():
         net(x, int(om.scheduler.timesteps[-1]), encoder_hidden_states=torch.randn(1, 77, cfg["cross_attention_dim"], generator=g))   # warm-up, untimed
         t0 = time.perf_counter()
-        OL.h_edit_r_implicit(om, xT=x, eta=1.0, prompts=[src, tar], cfg_scales=[1.0, 5.0, 7.5], zs=z[:, 0], controller=oc,
-                             weight_reconstruction=0.1, optimization_steps=1, after_skip_steps=1, is_ddim_inversion=False)
-        dt = time.perf_counter() - t0
+        OL.h_edit_r_implicit(om, xT=x, eta=1.0, prompts=[src, tar], cfg_scales=[1.0, 5.0, 7.5], zs=z, controller=oc,
+                             weight_reconstruction=0.1, optimization_steps=1, after_skip_steps=NS, is_ddim_inversion=False)
+        dt = (time.perf_counter() - t0) / NS
+    load1 = os.getloadavg()
     per_fwd = dt / 6
     per_img = per_fwd * (4 + 5 * K) * T
     return {"value": round(1.0 / per_img, 6), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"BASELINE configs[0] (C1): one sampler step of h_Edit_R_implicit, K = 1, no P2P controller, 1 image = 6 of C1's 120 "
-                      f"sample-forwards (2-row base pass + 4-row correction pass, step algebra included) by the fp32 eager oracle on "
-                      f"{threads} host threads = {dt:.2f} s, warm; value = configs[1] ({(4 + 5 * K) * T} sample-forwards per image) "
-                      "extrapolated by sample-forward count",
+            "sample": f"BASELINE configs[0] (C1): {NS} consecutive sampler steps of h_Edit_R_implicit, K = 1, no P2P controller, 1 image = "
+                      f"{6 * NS} of C1's 120 sample-forwards (per step a 2-row base pass + a 4-row correction pass, step algebra included) by "
+                      f"the fp32 eager oracle on {threads} host threads = {dt * NS:.2f} s, warm ({dt:.2f} s per step); value = configs[1] "
+                      f"({(4 + 5 * K) * T} sample-forwards per image) EXTRAPOLATED by sample-forward count (x{(4 + 5 * K) * T / (6 * NS):.1f}); "
+                      f"configs0_* = C1 itself extrapolated x{T0 // NS}",
             "configs0_s_per_image": round(dt * T0, 1), "configs0_images_per_s": round(1.0 / (dt * T0), 6),
-            "s_per_sampler_step": round(dt, 2), "s_per_unet_sample_forward": round(per_fwd, 3)}
+            "s_per_sampler_step": round(dt, 2), "s_per_unet_sample_forward": round(per_fwd, 3), "sampler_steps_timed": NS,
+            "host_loadavg_before": [round(v, 2) for v in load0], "host_loadavg_after": [round(v, 2) for v in load1],
+            "host_cpus": os.cpu_count()}
 
 
 if __name__ == "__main__":

@@ -89,20 +89,7 @@ def test_batch_rows_are_independent_and_deterministic(tiny):
     assert torch.equal(hip.encode(x5[2:3]).latent_dist.mode(), m5[2:3])
 
 
-def test_sd15_decode_512():
-    """full-size autoencoder (random weights): (1,4,64,64) latent -> finite (1,3,512,512) image,
-    and encode returns to a (1,4,64,64) latent."""
-    from hedit.vae import AutoencoderKL
-    vae = AutoencoderKL(device=G.dev())
-    vae.init_random(1)
-    g = torch.Generator().manual_seed(9)
-    z = torch.randn(1, 4, 64, 64, generator=g).to(G.dev())
-    img = vae.decode(z / vae.config.scaling_factor).sample
-    G.sync()
-    assert img.shape == (1, 3, 512, 512) and torch.isfinite(img).all()
-    lat = vae.encode(img.clamp(-1, 1)).latent_dist.mode()
-    G.sync()
-    assert lat.shape == (1, 4, 64, 64) and torch.isfinite(lat).all()
+# (the full-size autoencoder against the oracle: tests/test_gpu_sd_shape_style.py)
 
 
 def test_error_paths(tiny):
