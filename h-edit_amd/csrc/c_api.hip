@@ -247,6 +247,19 @@ int hedit_k_lin_chain(const void* a, int64_t lda, const void* r1, int64_t ldr1, 
   return lin_chain_launch(c, S(stream));
 } catch (...) { return hedit_abi_catch(); }
 
+int hedit_k_lin_chain_sched(const void* a, int64_t lda, const void* r1, int64_t ldr1, const float* gn_ss, int rows_per_image,
+                            const float* bias_pre, const float* gamma, const float* beta, float eps, const void* w_stream, void* out_mid,
+                            int64_t ldmid, void* out_q, int64_t ldq, void* out_k, int64_t ldk, void* out, int64_t ldo, int M, int C,
+                            int sched, void* stream) try {
+  LinChainParams c{};
+  c.a = reinterpret_cast<const bf16_t*>(a); c.lda = (long)lda; c.r1 = reinterpret_cast<const bf16_t*>(r1); c.ldr1 = (long)ldr1;
+  c.bias_pre = bias_pre; c.gamma = gamma; c.beta = beta; c.eps = eps; c.stream = reinterpret_cast<const bf16_t*>(w_stream);
+  c.out_mid = reinterpret_cast<bf16_t*>(out_mid); c.ldmid = (long)ldmid; c.out = reinterpret_cast<bf16_t*>(out); c.ldo = (long)ldo;
+  c.M = M; c.C = C; c.gn_ss = gn_ss; c.rows_per_image = rows_per_image;
+  c.out_q = reinterpret_cast<bf16_t*>(out_q); c.ldq = (long)ldq; c.out_k = reinterpret_cast<bf16_t*>(out_k); c.ldk = (long)ldk;
+  return lin_chain_launch_sched(c, sched, S(stream));
+} catch (...) { return hedit_abi_catch(); }
+
 size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C) { return groupnorm_ws_bytes(B, HW, C); }
 
 int hedit_k_groupnorm_affine(const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, void* ws,

@@ -72,6 +72,8 @@ struct LinChainParams {
   bf16_t* out_q; long ldq; bf16_t* out_k; long ldk;
 };
 int lin_chain_launch(const LinChainParams& c, hipStream_t st);
+// test entry (tests/test_gpu_chain_hazard.py): sched 0 = the product schedule, 1 = every wait drained to vmcnt(0) (the reference bits)
+int lin_chain_launch_sched(const LinChainParams& c, int sched, hipStream_t st);
 size_t lin_chain_stream_bytes(int layers);        // layers = 2 (to_out, to_q) or 4 (proj_in, to_q, to_k, to_v)
 // w [C][C] fp32 -> layer `layer` of the stream (layer 0 takes its input from HBM: natural k order; the others read an
 // accumulator: register order).  The stream is CYCLIC (layers * 20 iterations of 10 KB, no padding, no overrun: the

@@ -132,7 +132,15 @@ __device__ __forceinline__ void mfma_l0(f32x16& acc, const bf16x8& w, const bf16
 // (place-holder DMA in front of the first tile, bounds-checked buffer stores that are issued whether or not the row
 // exists).  Carrying the row DMA inside the layers instead was tried and is NOT what this file does: DESIGN.md 5.0.
 // SSG: the (scale, shift) pairs are read per row from global memory (images that are not whole 128-row tiles).
-template <int NPOST, bool GNIN, bool VT, bool SSG>
+// SCHED: 0 = the product schedule described above.  The other two exist for tests/test_gpu_chain_hazard.py and are never
+// launched by the executor:
+//   1 = DRAINED: every counted wait of the kernel becomes vmcnt(0) lgkmcnt(0) in front of its barrier, so nothing in
+//       LDS is ever read while ANY vector-memory operation of the wave is outstanding -- the schedule whose correctness
+//       needs no argument about queue order or timing.  Same arithmetic, same order: its results are the reference
+//       bits the product schedule is compared with under memory load.
+//   2 = IN-LAYER (only with -DHEDIT_LINCHAIN_INLAYER, tools/chain_hazard.sh): round 3's dropped variant, the row DMA
+//       carried inside the layers two pieces per iteration with per-iteration windows.
+template <int NPOST, bool GNIN, bool VT, bool SSG, int SCHED>
 __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -190,29 +198,34 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) slotx[k] = STAGE_OFF + wave * STAGE_BYTES + lm * ROW_BYTES + (((2 * k + hi) ^ swz(lm)) * 16);
 
-  auto stage_rows = [&](auto res_c, long ld, int tile) __attribute__((always_inline)) {
+  // piece i of the wave's 32 rows of a tile (res: the residual tensor instead of the input tensor)
+  auto row_piece = [&](auto res_c, int i, int ld2, int soff) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(decltype(res_c)::value ? rs_r : rs_a, (__attribute__((address_space(3))) void*)(stage + i * 1024), 16,
+                                             piece_off(i, ld2), soff, 0, 0);
+#else
+    (void)i; (void)ld2; (void)soff;
+#endif
+  };
+  auto stage_rows = [&](auto res_c, long ld, int tile) __attribute__((always_inline)) {
     const int soff = (int)((long)(tile * BLOCK_ROWS + wave * 32) * ld * 2);
     const int ld2 = opaque((int)ld * 2);
 #pragma unroll
-    for (int i = 0; i < ROW_DMAS; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(decltype(res_c)::value ? rs_r : rs_a, (__attribute__((address_space(3))) void*)(stage + i * 1024), 16,
-                                               piece_off(i, ld2), soff, 0, 0);
-#else
-    (void)ld; (void)tile;
-#endif
+    for (int i = 0; i < ROW_DMAS; ++i) row_piece(res_c, i, ld2, soff);
   };
   // the (scale, shift) pairs of the tile's image -> SS_OFF (every wave fetches the same 2.5 KB: identical bytes)
-  auto stage_ss = [&](int tile) __attribute__((always_inline)) {
+  auto ss_piece = [&](int k, int tile) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int img = (tile * BLOCK_ROWS) / p.rows_per_image;
-#pragma unroll
-    for (int k = 0; k < SS_DMAS; ++k)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ss, (__attribute__((address_space(3))) void*)(smem + SS_OFF + k * 1024), 16, dma_voff,
-                                               img * (LC * 8) + k * 1024, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ss, (__attribute__((address_space(3))) void*)(smem + SS_OFF + k * 1024), 16, dma_voff,
+                                             img * (LC * 8) + k * 1024, 0, 0);
 #else
-    (void)tile;
+    (void)k; (void)tile;
 #endif
+  };
+  auto stage_ss = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < SS_DMAS; ++k) ss_piece(k, tile);
   };
   auto dummy_dma = [&](int n) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -279,9 +292,18 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
   int sit = 0, bank = 0;                     // stream iteration being consumed (mod NIT), its ring bank
   int frag_rd = lane * 16;
   bf16x8 pre[LEAD];
-  auto linear_layer = [&](auto extra_c) __attribute__((always_inline)) {
+  // ROWS (SCHED 2 only): row DMA carried by this layer, two pieces per iteration from its first iteration on (0: none;
+  // 1: the residual rows of this tile; 2: the input rows (and scale / shift pairs) of tile `rtile`)
+  auto linear_layer = [&](auto extra_c, auto rows_c, int rtile) __attribute__((always_inline)) {
     constexpr int EXTRA = decltype(extra_c)::value;
-    static_assert((AHEAD - 2) * PPW + EXTRA <= 63, "vmcnt is a 6-bit counter");
+    constexpr int ROWS = SCHED == 2 ? decltype(rows_c)::value : 0;
+    constexpr int NP = ROWS == 0 ? 0 : ROW_DMAS + (ROWS == 2 && GNIN ? SS_DMAS : 0);      // pieces carried
+    constexpr int PITER = (NP + 1) / 2;                                                    // iterations that carry pieces
+    static_assert(PITER + 4 <= LKS, "the carried pieces must be out four iterations before the layer ends");
+    static_assert((AHEAD - 2) * PPW + EXTRA + (ROWS ? 8 : 0) <= 63, "vmcnt is a 6-bit counter");
+    const int r_ld2 = opaque((int)(ROWS == 1 ? p.ldr1 : p.lda) * 2);
+    const int r_soff = (int)((long)(rtile * BLOCK_ROWS + wave * 32) * (ROWS == 1 ? p.ldr1 : p.lda) * 2);
+    (void)r_ld2; (void)r_soff;
 #pragma unroll
     for (int j = 0; j < LEAD; ++j) pre[j] = *reinterpret_cast<const bf16x8*>(smem + frag_rd + j * 1024);
     static_for<LKS>([&](auto ks_) {
@@ -308,12 +330,32 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
         if constexpr (b + LEAD < LNB) fr[b + LEAD] = *reinterpret_cast<const bf16x8*>(smem + base + (b + LEAD) * 1024);
         else if constexpr (ks + 1 < LKS) pre[b + LEAD - LNB] = *reinterpret_cast<const bf16x8*>(smem + nbase + (b + LEAD - LNB) * 1024);
         if constexpr (b % 3 == 1) dma_piece(dit, pbank, b / 3);
+        if constexpr (ROWS != 0 && b % 3 == 2 && b / 3 < 2) {
+          constexpr int pi = 2 * ks + b / 3;                 // carried piece of this bundle
+          if constexpr (pi < NP) {
+            if constexpr (pi < ROW_DMAS) {
+              if constexpr (ROWS == 1) row_piece(std::true_type{}, pi, r_ld2, r_soff);
+              else row_piece(std::false_type{}, pi, r_ld2, r_soff);
+            } else {
+              ss_piece(pi - ROW_DMAS, rtile);
+            }
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       });
-      if constexpr (ks < 4)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"((AHEAD - 2) * PPW + EXTRA), "n"(LEAD) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"((AHEAD - 2) * PPW), "n"(LEAD) : "memory");
+      if constexpr (SCHED == 1) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        // operations newer than the last piece of iteration ks + 2 (issued during iteration ks - 4): the weight pieces (and
+        // carried pieces) of iterations ks-3 .. ks, and the burst in front of the layer while ks - 3 <= 0
+        constexpr int carried = [] {
+          int n = 0;
+          for (int j = ks - 3; j <= ks; ++j)
+            if (j >= 0) n += (2 * j + 2 <= NP) ? 2 : (2 * j + 1 <= NP ? 1 : 0);
+          return n;
+        }();
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"((AHEAD - 2) * PPW + carried + (ks < 4 ? EXTRA : 0)), "n"(LEAD) : "memory");
+      }
       sit = sit + 1 == NIT ? 0 : sit + 1;
       bank = nbank;
       frag_rd = nbase;
@@ -409,19 +451,22 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
   for (int it = 0; it < AHEAD; ++it)
 #pragma unroll
     for (int k = 0; k < PPW; ++k) dma_piece(it, it, k);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * PPW) : "memory");        // my input rows (and the scale / shift pairs) are in LDS
+  if constexpr (SCHED == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * PPW) : "memory");   // my input rows (and the scale / shift pairs) are in LDS
   read_xn(tile);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  constexpr int E_FIRST = ROW_DMAS + (GNIN ? 0 : ROW_DMAS);                  // in front of a first layer: the final stores (+ the residual DMA)
-  constexpr int E_MID = ROW_DMAS;                                            // in front of a middle layer: the stores of the previous result
-  constexpr int E_LAST = ROW_DMAS + ROW_DMAS + (GNIN ? SS_DMAS : 0);         // in front of the last layer: stores + the next tile's input
+  constexpr bool INL = SCHED == 2;
+  constexpr int E_FIRST = INL ? ROW_DMAS : ROW_DMAS + (GNIN ? 0 : ROW_DMAS);                // in front of a first layer: the final stores (+ the residual DMA)
+  constexpr int E_MID = ROW_DMAS;                                                            // in front of a middle layer: the stores of the previous result
+  constexpr int E_LAST = INL ? ROW_DMAS : ROW_DMAS + ROW_DMAS + (GNIN ? SS_DMAS : 0);       // in front of the last layer: stores + the next tile's input
   dummy_dma(ROW_DMAS);                                                       // (stands in for the previous tile's final stores)
-  if constexpr (!GNIN) stage_rows(std::true_type{}, p.ldr1, tile);
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(E_FIRST) : "memory");     // par[] and iterations 0 .. AHEAD-1 are in LDS
+  if constexpr (!GNIN && !INL) stage_rows(std::true_type{}, p.ldr1, tile);
+  if constexpr (SCHED == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(E_FIRST) : "memory");    // par[] and iterations 0 .. AHEAD-1 are in LDS
 
   while (true) {
     // ================================================================ first layer
-    linear_layer(std::integral_constant<int, E_FIRST>{});
+    linear_layer(std::integral_constant<int, E_FIRST>{}, std::integral_constant<int, GNIN ? 0 : 1>{}, tile);
     settle();
     // ONE pass over the accumulator: + bias (+ the residual rows from the staging area), the result goes to the staging
     // area (same slot the residual came from: each slot belongs to one lane) and on to HBM, its LayerNorm becomes the
@@ -488,7 +533,7 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
     // ================================================================ the layers behind the LayerNorm
 #pragma unroll 1
     for (int j = 0; j < NPOST - 1; ++j) {
-      linear_layer(std::integral_constant<int, E_MID>{});
+      linear_layer(std::integral_constant<int, E_MID>{}, std::integral_constant<int, 0>{}, tile);
       settle();
       store_rows(p.out_p[j], p.ldp[j], tile);
     }
@@ -496,30 +541,44 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
     // every tile puts the same number of operations into the queue)
     const int ntile = tile + (int)gridDim.x;
     const int ltile = ntile < ntiles ? ntile : tile;
-    stage_rows(std::false_type{}, p.lda, ltile);
-    if constexpr (GNIN) stage_ss(ltile);
-    linear_layer(std::integral_constant<int, E_LAST>{});
+    if constexpr (!INL) {
+      stage_rows(std::false_type{}, p.lda, ltile);
+      if constexpr (GNIN) stage_ss(ltile);
+    }
+    linear_layer(std::integral_constant<int, E_LAST>{}, std::integral_constant<int, 2>{}, ltile);
     settle();
     read_xn(ltile);                                        // the fragments of the NEXT tile's first layer (Xn is free now)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if constexpr (VT) store_rows_t(p.out, p.ldo, tile);
     else store_rows(p.out, p.ldo, tile);
-    if constexpr (!GNIN) stage_rows(std::true_type{}, p.ldr1, ltile);
+    if constexpr (!GNIN && !INL) stage_rows(std::true_type{}, p.ldr1, ltile);
     if (ntile >= ntiles) break;
     tile = ntile;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (DMA still in flight lands in LDS that must still be this block's)
 }
 
-template <int NPOST, bool GNIN, bool VT, bool SSG>
-int launch(const LinKernelParams& k, hipStream_t st) {
-  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&lin_chain_kernel<NPOST, GNIN, VT, SSG>), LDS_TOTAL)) return rc;
+template <int NPOST, bool GNIN, bool VT, bool SSG, int SCHED>
+int launch_impl(const LinKernelParams& k, hipStream_t st) {
+  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&lin_chain_kernel<NPOST, GNIN, VT, SSG, SCHED>), LDS_TOTAL)) return rc;
   int cus = 0;
   if (int rc = hedit_cu_count(&cus)) return rc;
   const int ntiles = cdiv(k.M, BLOCK_ROWS);
-  hipLaunchKernelGGL((lin_chain_kernel<NPOST, GNIN, VT, SSG>), dim3(ntiles < cus ? ntiles : cus), dim3(256), LDS_TOTAL, st, k);
+  hipLaunchKernelGGL((lin_chain_kernel<NPOST, GNIN, VT, SSG, SCHED>), dim3(ntiles < cus ? ntiles : cus), dim3(256), LDS_TOTAL, st, k);
   LAUNCH_CHECK();
   return HEDIT_OK;
+}
+
+template <int NPOST, bool GNIN, bool VT, bool SSG>
+int launch(const LinKernelParams& k, int sched, hipStream_t st) {
+  if (sched == 0) return launch_impl<NPOST, GNIN, VT, SSG, 0>(k, st);
+  if (sched == 1) return launch_impl<NPOST, GNIN, VT, SSG, 1>(k, st);
+#if defined(HEDIT_LINCHAIN_INLAYER)
+  if constexpr (!SSG)
+    if (sched == 2) return launch_impl<NPOST, GNIN, VT, SSG, 2>(k, st);
+#endif
+  hedit_set_error("lin_chain: unknown schedule (2 = in-layer row DMA exists only in the -DHEDIT_LINCHAIN_INLAYER test build)");
+  return HEDIT_ERR_ARG;
 }
 
 }  // namespace
@@ -535,7 +594,7 @@ int lin_chain_pack_launch(const float* w, int layer, float scale, int layers, bf
 }
 
 // one launch: every row tensor inside the 2 GiB window of a buffer descriptor's 32-bit offsets
-static int lin_chain_launch_one(const LinChainParams& c, hipStream_t st) {
+static int lin_chain_launch_one(const LinChainParams& c, int sched, hipStream_t st) {
   ARG_CHECK((long)c.M * c.lda * 2 < (1L << 31) && (long)c.M * c.ldmid * 2 < (1L << 31) && (c.gn_ss || (long)c.M * c.ldo * 2 < (1L << 31)),
             "lin_chain: tensor beyond the 2 GB buffer window");
   LinKernelParams k{};
@@ -544,17 +603,19 @@ static int lin_chain_launch_one(const LinChainParams& c, hipStream_t st) {
   if (!c.gn_ss) {
     ARG_CHECK((long)c.M * c.ldr1 * 2 < (1L << 31), "lin_chain: residual rows beyond the 2 GB buffer window");
     k.r1 = c.r1; k.ldr1 = c.ldr1;
-    return launch<1, false, false, false>(k, st);
+    return launch<1, false, false, false>(k, sched, st);
   }
   ARG_CHECK((long)c.M * c.ldq * 2 < (1L << 31) && (long)c.M * c.ldk * 2 < (1L << 31) && (long)LC * c.ldo * 2 < (1L << 31),
             "lin_chain: output beyond the 2 GB buffer window");
   k.gn_ss = c.gn_ss; k.rows_per_image = c.rows_per_image;
   k.out_p[0] = c.out_q; k.ldp[0] = c.ldq; k.out_p[1] = c.out_k; k.ldp[1] = c.ldk;
   // images of whole 128-row tiles: the (scale, shift) pairs of a tile are staged once; else they are read per row
-  return c.rows_per_image % BLOCK_ROWS == 0 ? launch<3, true, true, false>(k, st) : launch<3, true, true, true>(k, st);
+  return c.rows_per_image % BLOCK_ROWS == 0 ? launch<3, true, true, false>(k, sched, st) : launch<3, true, true, true>(k, sched, st);
 }
 
-int lin_chain_launch(const LinChainParams& c, hipStream_t st) {
+int lin_chain_launch(const LinChainParams& c, hipStream_t st) { return lin_chain_launch_sched(c, 0, st); }
+
+int lin_chain_launch_sched(const LinChainParams& c, int sched, hipStream_t st) {
   ARG_CHECK(c.C == LC, "lin_chain: exists for C = 320");
   ARG_CHECK(c.M > 0 && c.a && c.stream && c.gamma && c.beta && c.bias_pre && c.out_mid && c.out, "lin_chain: null");
   ARG_CHECK(c.lda % 8 == 0 && c.ldmid % 8 == 0 && c.ldo % 8 == 0, "lin_chain: rows must be 16-byte aligned");
@@ -569,7 +630,7 @@ int lin_chain_launch(const LinChainParams& c, hipStream_t st) {
   if (!c.gn_ss) { if (c.ldo > ldmax) ldmax = c.ldo; if (c.ldr1 > ldmax) ldmax = c.ldr1; }
   else { if (c.ldq > ldmax) ldmax = c.ldq; if (c.ldk > ldmax) ldmax = c.ldk; }
   long cap = ((1L << 31) - 1) / (ldmax * 2);
-  if (c.M <= cap) return lin_chain_launch_one(c, st);
+  if (c.M <= cap) return lin_chain_launch_one(c, sched, st);
   long unit = BLOCK_ROWS;
   if (c.gn_ss) {      // lcm(128, rows_per_image): ranges start on an image boundary AND a tile boundary
     long a = unit, b = c.rows_per_image;
@@ -592,7 +653,7 @@ int lin_chain_launch(const LinChainParams& c, hipStream_t st) {
       p.out_k = c.out_k + r0 * c.ldk;
       p.out = c.out + r0;                       // v^T [C][ldo]: a column range
     }
-    if (int rc = lin_chain_launch_one(p, st)) return rc;
+    if (int rc = lin_chain_launch_one(p, sched, st)) return rc;
   }
   return HEDIT_OK;
 }

@@ -302,6 +302,14 @@ int hedit_k_lin_chain(const void* a, int64_t lda, const void* r1, int64_t ldr1, 
                       const float* bias_pre, const float* gamma, const float* beta, float eps, const void* w_stream, void* out_mid,
                       int64_t ldmid, void* out_q, int64_t ldq, void* out_k, int64_t ldk, void* out, int64_t ldo, int M, int C,
                       void* stream);
+/* Test entry (tests/test_gpu_chain_hazard.py): hedit_k_lin_chain with the kernel's wait schedule chosen -- sched 0 = the
+ * product's (counted vmcnt windows around the bursts between the layers), 1 = every wait drained to vmcnt(0) lgkmcnt(0)
+ * in front of its barrier: same arithmetic, no reliance on queue order or timing, i.e. the bits the product schedule must
+ * reproduce under any memory load.  Never called by the executor. */
+int hedit_k_lin_chain_sched(const void* a, int64_t lda, const void* r1, int64_t ldr1, const float* gn_ss, int rows_per_image,
+                            const float* bias_pre, const float* gamma, const float* beta, float eps, const void* w_stream, void* out_mid,
+                            int64_t ldmid, void* out_q, int64_t ldq, void* out_k, int64_t ldk, void* out, int64_t ldo, int M, int C,
+                            int sched, void* stream);
 size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C);
 int hedit_k_groupnorm_affine(const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, void* ws,
                              float* ss_out, void* stream);

@@ -1,0 +1,151 @@
+"""-m gpu: kernel-level differential stress test of the projection chains (csrc/linchain.hip) -- VERDICT round 3, weak #1.
+
+lin_chain_kernel overlaps its tile I/O (row DMA, coalesced stores) with the weight-DMA ring through COUNTED vmcnt
+windows.  Whether such a schedule is correct cannot be seen from one clean run: a window that is one operation too wide
+only fails when the memory system is slow at the wrong moment.  So the same kernel exists in a second instantiation
+(SCHED = 1, hedit_k_lin_chain_sched(..., sched = 1)) in which every wait is vmcnt(0) lgkmcnt(0) in front of its barrier:
+identical arithmetic in identical order, nothing in LDS is read while any vector-memory operation of the wave is in flight.
+Its output is the reference; the product schedule (sched 0) must reproduce it BIT FOR BIT
+  * over many launches (a race shows up as a rare corrupt row, not as a wrong mean),
+  * while a second stream streams through HBM (copies of 1 GiB buffers: row DMA and stores land late),
+  * at every batch size the sampling loop uses (M = 120 / 96 / 48 rows of 64 x 64 tokens: the persistent grid walks a
+    different number of tiles per block) and at a ragged shape (24 x 24 tokens: tiles that straddle images, a last tile
+    with rows beyond M).
+Environment: HEDIT_HAZARD_LAUNCHES (default 600 per form at the large shape; tools/chain_hazard.sh runs 20000),
+HEDIT_CHAIN_SCHED (default 0; 2 = round 3's dropped in-layer variant, needs the -DHEDIT_LINCHAIN_INLAYER build selected
+with HEDIT_LIB_VARIANT -- that is how tools/chain_hazard.sh shows the test failing on the variant it was written for)."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from hedit import _lib  # noqa: E402
+
+if os.environ.get("HEDIT_LIB_VARIANT"):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"lib_{os.environ['HEDIT_LIB_VARIANT']}.so.bin")
+
+pytestmark = pytest.mark.gpu
+
+LAUNCHES = int(os.environ.get("HEDIT_HAZARD_LAUNCHES", "600"))
+SCHED = int(os.environ.get("HEDIT_CHAIN_SCHED", "0"))
+C = 320
+
+
+class Chains:
+    """both chain forms on fixed random inputs; run(form, sched) -> tuple of output tensors (fresh buffers)"""
+
+    def __init__(self, rows, tokens, seed=0):
+        self.lib = _lib.lib()
+        self.dev = torch.device("cuda:0")
+        self.rows, self.N, self.M = rows, tokens, rows * tokens
+        g = torch.Generator().manual_seed(seed)
+        M, dev = self.M, self.dev
+        self.x = (torch.randn(M, C, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+        self.a = torch.randn(M, C, generator=g).to(torch.bfloat16).to(dev)
+        self.t1 = (torch.randn(M, C, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+        self.gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(dev)
+        self.beta = (0.1 * torch.randn(C, generator=g)).to(dev)
+        self.bo = (0.3 * torch.randn(C, generator=g)).to(dev)
+        mk = lambda: (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dev)       # noqa: E731
+        wo, wq, wk, wv = mk(), mk(), mk(), mk()
+        lib = self.lib
+        self.ws2 = torch.empty(lib.hedit_k_lin_chain_stream_bytes(1), dtype=torch.uint8, device=dev)
+        _lib.check(lib.hedit_k_lin_chain_pack(_lib.ptr(wo), _lib.ptr(wq), None, None, 0.23, _lib.ptr(self.ws2), None))
+        self.ws4 = torch.empty(lib.hedit_k_lin_chain_stream_bytes(3), dtype=torch.uint8, device=dev)
+        _lib.check(lib.hedit_k_lin_chain_pack(_lib.ptr(wo), _lib.ptr(wq), _lib.ptr(wk), _lib.ptr(wv), 0.23, _lib.ptr(self.ws4), None))
+        gws = torch.empty(lib.hedit_k_groupnorm_ws_bytes(rows, tokens, C), dtype=torch.uint8, device=dev)
+        self.ss = torch.empty(rows, C, 2, dtype=torch.float32, device=dev)
+        _lib.check(lib.hedit_k_groupnorm_affine(_lib.ptr(self.x), _lib.ptr(self.gamma), _lib.ptr(self.beta), rows, tokens, C, 32, 1e-6,
+                                                _lib.ptr(gws), _lib.ptr(self.ss), None))
+        torch.cuda.synchronize()
+
+    def run(self, form, sched, out=None):
+        lib, M, p = self.lib, self.M, _lib.ptr
+        if form == "mid":           # attn1.to_out + residual -> norm2 -> attn2.to_q
+            mid, q = out if out else (torch.empty_like(self.x), torch.empty_like(self.x))
+            _lib.check(lib.hedit_k_lin_chain_sched(p(self.a), C, p(self.t1), C, None, 0, p(self.bo), p(self.gamma), p(self.beta), 1e-5,
+                                                   p(self.ws2), p(mid), C, None, 0, None, 0, p(q), C, M, C, sched, _lib.cur_stream()))
+            return mid, q
+        # GroupNorm apply -> proj_in -> norm1 -> q | k | v^T
+        mid, qk, vt = out if out else (torch.empty_like(self.x), torch.empty(M, 2 * C, dtype=torch.bfloat16, device=self.dev),
+                                       torch.empty(C, M, dtype=torch.bfloat16, device=self.dev))
+        _lib.check(lib.hedit_k_lin_chain_sched(p(self.x), C, None, 0, p(self.ss), self.N, p(self.bo), p(self.gamma), p(self.beta), 1e-5,
+                                               p(self.ws4), p(mid), C, p(qk), 2 * C, qk.data_ptr() + 2 * C, 2 * C, p(vt), M, M, C, sched,
+                                               _lib.cur_stream()))
+        return mid, qk, vt
+
+
+def _mismatches(ch, form, sched, launches, hog):
+    """`launches` launches of (form, sched) against the drained schedule's bits, with `hog` GiB-sized copies running on a
+    second stream all the while -> (launches with any differing output, differing elements in total)"""
+    ref = ch.run(form, 1)
+    torch.cuda.synchronize()
+    again = ch.run(form, 1)
+    torch.cuda.synchronize()
+    assert all(torch.equal(u, v) for u, v in zip(ref, again)), "the drained schedule itself is not repeatable"
+    out = tuple(torch.empty_like(t) for t in ref)
+    bad_launch = torch.zeros((), dtype=torch.int64, device=ch.dev)
+    bad_elems = torch.zeros((), dtype=torch.int64, device=ch.dev)
+    side = torch.cuda.Stream()
+    src = dst = None
+    if hog:
+        src = torch.empty(1 << 29, dtype=torch.int16, device=ch.dev).random_(0, 1000)       # 1 GiB
+        dst = torch.empty_like(src)
+    for i in range(launches):
+        if hog:
+            with torch.cuda.stream(side):
+                for _ in range(hog):
+                    dst.copy_(src)
+        ch.run(form, sched, out)
+        n = sum(torch.count_nonzero(u.view(torch.int16) != v.view(torch.int16)) for u, v in zip(ref, out))
+        bad_elems += n
+        bad_launch += (n > 0).to(torch.int64)
+        if i % 64 == 63:
+            torch.cuda.synchronize()        # (bounds the queue of enqueued copies)
+    torch.cuda.synchronize()
+    return int(bad_launch), int(bad_elems)
+
+
+@pytest.mark.parametrize("form", ["mid", "front"])
+@pytest.mark.parametrize("rows,tokens,frac,hog", [(120, 4096, 1.0, 2), (96, 4096, 0.25, 2), (48, 4096, 0.25, 1), (5, 576, 0.5, 1), (120, 4096, 0.15, 0)])
+def test_counted_waits_reproduce_the_drained_schedule(form, rows, tokens, frac, hog):
+    """Measured on MI355X (profiles/r04_chain_hazard.txt): product schedule 0 mismatching launches in 20 000 per form at
+    120 rows under load (and 0 at every other shape); the in-layer variant of round 3: see that file."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ch = Chains(rows, tokens)
+    n = max(20, int(LAUNCHES * frac))
+    bad, elems = _mismatches(ch, form, SCHED, n, hog)
+    print(f"chain {form}: M = {ch.M}, sched {SCHED}, {n} launches, memory hog {hog}: {bad} mismatching launches, {elems} elements")
+    assert bad == 0, f"{bad} of {n} launches differ from the drained schedule ({elems} elements)"
+
+
+def test_batches_beyond_the_buffer_window_run_as_row_ranges():
+    """M * 320 * 2 bytes >= 2 GiB: lin_chain_launch cuts the batch into row ranges of whole tiles / images; same bits as
+    the ranges launched by hand (rows are independent)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    rows, tokens = 416, 4096                  # 1 703 936 rows: 2.18 GB per [M][320] tensor, 4.4 GB for q | k
+    if torch.cuda.mem_get_info()[0] < 40 << 30:
+        pytest.skip("needs 40 GB of free device memory")
+    ch = Chains(rows, tokens, seed=3)
+    for form in ("mid", "front"):
+        got = ch.run(form, 0)
+        torch.cuda.synchronize()
+        half = Chains.__new__(Chains)
+        half.__dict__.update(ch.__dict__)
+        parts = []
+        for lo, hi in ((0, 208), (208, 416)):
+            r0, r1 = lo * tokens, hi * tokens
+            half.rows, half.M = hi - lo, r1 - r0
+            half.x, half.a, half.t1, half.ss = ch.x[r0:r1], ch.a[r0:r1], ch.t1[r0:r1], ch.ss[lo:hi]
+            parts.append(tuple(t.clone() for t in half.run(form, 0)))
+        torch.cuda.synchronize()
+        for k, t in enumerate(got):
+            cat_dim = 1 if (form == "front" and k == 2) else 0          # v^T: [C][M]
+            assert torch.equal(t, torch.cat([parts[0][k], parts[1][k]], dim=cat_dim)), (form, k)
