@@ -26,7 +26,9 @@ struct GemmParams {
   float* raw_f32;        // if set: write the plain fp32 products [M][N] here (no bias / residual / bf16 C)
   int chunk_kt;          // canonical K-chunking (gemm_canonical_chunk), in K-tiles of 64; 0 = one plain chain
 };
+#ifndef GEMM_NOMINAL_BATCH
 #define GEMM_NOMINAL_BATCH 4   // the canonical chunking is sized for this many rows of the batch dimension
+#endif
 int gemm_prepare();   // allocates the zero page (call once outside any timed / captured region)
 int gemm_pick_bn(int N);
 int gemm_pick_splits(int M, int N, int K, int force);      // explicit split count clamped to the K-tiles (C entry points)

@@ -6,6 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
 import numpy as np
 import torch
+from hedit import _lib
+if os.environ.get("HEDIT_LIB_VARIANT"):       # tools/build_variant.sh side library (measurement builds)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"lib_{os.environ['HEDIT_LIB_VARIANT']}.so.bin")
 from hedit.unet import UNet2DConditionModel
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 120
