@@ -51,8 +51,7 @@ constexpr int STAGE_BYTES = 32 * ROW_BYTES;            // per wave
 constexpr int PAR_OFF = STAGE_OFF + 4 * STAGE_BYTES;   // gamma | beta | bias of the first layer (fp32)
 constexpr int SS_OFF = PAR_OFF + 3 * LC * 4;           // GroupNorm (scale, shift) pairs of the tile's image, 3 x 1 KB DMA pieces
 constexpr int SS_DMAS = 3;
-constexpr int DUMMY_OFF = SS_OFF + SS_DMAS * 1024;     // target of the place-holder DMA in front of the first tile
-constexpr int LDS_TOTAL = DUMMY_OFF + 1024;
+constexpr int LDS_TOTAL = SS_OFF + SS_DMAS * 1024;
 constexpr int BLOCK_ROWS = 128;
 constexpr int CPR = LC / 8;              // 16-byte chunks per row
 static_assert(LDS_TOTAL <= 160 * 1024, "ring + staging must fit the LDS");
@@ -128,9 +127,19 @@ __device__ __forceinline__ void mfma_l0(f32x16& acc, const bf16x8& w, const bf16
 // layer that follows E such operations allow E more outstanding ones (template parameter of the layer).  What this rests
 // on: loads retire in issue order (what every counted vmcnt ring rests on); the weights those four waits are about were
 // issued before the burst, a whole transition earlier; and a staged row is first touched a full layer (>= 7 us) after
-// its DMA was issued and behind waits that no longer tolerate it.  The burst sizes are made the same for every tile
-// (place-holder DMA in front of the first tile, bounds-checked buffer stores that are issued whether or not the row
-// exists).  Carrying the row DMA inside the layers instead was tried and is NOT what this file does: DESIGN.md 5.0.
+// its DMA was issued and behind waits that no longer tolerate it.  A window may be WIDER than the burst in front of it
+// (it then waits for less, which is only safe when everything it protects has landed anyway) but never narrower, so the
+// bursts are sized per position (E_FIRST / E_MID / E_LAST) and issued for every tile alike -- bounds-checked buffer stores
+// go out whether or not the row exists.  The FIRST tile of a block has no burst in front of its first layer; it needs
+// none: the prologue drains the queue completely (vmcnt(0)) before the first barrier, so iterations 0 .. AHEAD-1 of the
+// stream have landed whatever the first windows tolerate.
+// (Round 3 put 20 identical place-holder DMAs in front of the first tile instead, to make its burst as long as every
+//  other tile's, and waited vmcnt(burst).  LLVM's dead-store elimination collapses identical LDS-DMAs to the same LDS
+//  address into ONE, the wait then tolerated 19 operations that did not exist, i.e. the 18 pieces of the stream's head
+//  were never waited for: a first-tile race, invisible while the weights hit L2 and the prologue's own work gave them
+//  time, visible as stale 32-column weight blocks under memory load -- what tests/test_gpu_chain_hazard.py caught, and what
+//  made the in-layer variant of round 3, whose prologue is shorter, fail in every full sampling run.  DESIGN.md 5.0.)
+// Carrying the row DMA inside the layers instead was tried and is NOT what this file does: DESIGN.md 5.0.
 // SSG: the (scale, shift) pairs are read per row from global memory (images that are not whole 128-row tiles).
 // SCHED: 0 = the product schedule described above.  The other two exist for tests/test_gpu_chain_hazard.py and are never
 // launched by the executor:
@@ -227,16 +236,6 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
 #pragma unroll
     for (int k = 0; k < SS_DMAS; ++k) ss_piece(k, tile);
   };
-  auto dummy_dma = [&](int n) __attribute__((always_inline)) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-    for (int k = 0; k < n; ++k)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(smem + DUMMY_OFF), 16, dma_voff, 0, 0, 0);
-#else
-    (void)n;
-#endif
-  };
-
   // O[nb][4 q + j] of lane (lm, hi) = feature 32 nb + 8 q + 4 hi + j of row lm  (32x32 MFMA result layout)
   f32x16 O[LNB];
   bf16x8 Xn[LKS];        // lane (row lm, half hi): activation fragment of k-step ks (8 consecutive k, or 8 registers of O)
@@ -459,10 +458,10 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
   constexpr int E_FIRST = INL ? ROW_DMAS : ROW_DMAS + (GNIN ? 0 : ROW_DMAS);                // in front of a first layer: the final stores (+ the residual DMA)
   constexpr int E_MID = ROW_DMAS;                                                            // in front of a middle layer: the stores of the previous result
   constexpr int E_LAST = INL ? ROW_DMAS : ROW_DMAS + ROW_DMAS + (GNIN ? SS_DMAS : 0);       // in front of the last layer: stores + the next tile's input
-  dummy_dma(ROW_DMAS);                                                       // (stands in for the previous tile's final stores)
   if constexpr (!GNIN && !INL) stage_rows(std::true_type{}, p.ldr1, tile);
-  if constexpr (SCHED == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(E_FIRST) : "memory");    // par[] and iterations 0 .. AHEAD-1 are in LDS
+  // everything issued so far has landed before anybody passes the first barrier: par[], the input rows, and iterations
+  // 0 .. AHEAD-1 of the stream in full (vmcnt(0), NOT a counted wait: see the kernel comment)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   while (true) {
     // ================================================================ first layer
