@@ -90,14 +90,6 @@ size_t ffn_bias_bytes();
 int ffn_pack_launch(const float* w, int which, int pre, int post, bf16_t* stream, hipStream_t st);
 int ffn_pack_bias_launch(const float* b1, float* out, hipStream_t st);
 int ffn_fused_launch(const FfnParams& f, hipStream_t st);
-// ---------------------------------------------------------------- xffn.hip
-// The same block tail (leading AND trailing layer: a, r2 set) in round 4's mapping -- the row tile in LDS, every wave a
-// column slice of each layer with its weight fragments straight from L2 into registers.  Own stream / bias layouts.
-size_t xffn_stream_bytes();
-size_t xffn_bias_bytes();
-int xffn_pack_launch(const float* w, int which, bf16_t* stream, hipStream_t st);      // which as ffn_pack_launch
-int xffn_pack_bias_launch(const float* b1, float* out, hipStream_t st);
-int xffn_launch(const FfnParams& f, hipStream_t st);
 
 #define HEDIT_MAXW 77
 #define HEDIT_WPAD 96

@@ -287,15 +287,6 @@ int hedit_k_ffn_fused(const void* x, int64_t ldx, const float* gamma, const floa
 int hedit_k_ffn_chain(const void* a, int64_t lda, const void* t1, int64_t ldt1, const void* x, int64_t ldx, const float* bias_pre,
                       const float* gamma, const float* beta, float eps, const void* w_stream, const float* bias1_packed,
                       const float* bias2, const float* bias_post, void* out, int64_t ldo, int M, int C, void* stream);
-/* The same block tail in round 4's mapping (csrc/xffn.hip: row tile in LDS, weight slices from L2 into registers); its own
- * weight stream and FF1 bias order (hedit_k_xffn_pack), otherwise the arguments of hedit_k_ffn_chain. */
-size_t hedit_k_xffn_stream_bytes(void);
-size_t hedit_k_xffn_bias_bytes(void);
-int hedit_k_xffn_pack(const float* w1, const float* b1, const float* w2, const float* w_pre, const float* w_post, void* stream_out,
-                      float* bias1_out, void* stream);
-int hedit_k_xffn_chain(const void* a, int64_t lda, const void* t1, int64_t ldt1, const void* x, int64_t ldx, const float* bias_pre,
-                       const float* gamma, const float* beta, float eps, const void* w_stream, const float* bias1_packed,
-                       const float* bias2, const float* bias_post, void* out, int64_t ldo, int M, int C, void* stream);
 /* The projections around an attention of the same level in one launch (csrc/linchain.hip), two forms:
  *   n_out = 1 (gn_ss == NULL):  mid = attn1.to_out.0(a) + r1 (written to out_mid);  out[M][C] = attn2.to_q( norm2(mid) )
  *   n_out = 3 (gn_ss set):      mid = proj_in( a * scale + shift ) (GroupNorm applied on the fly; written to out_mid);

@@ -1,3 +1,10 @@
+// EXPERIMENT (round 4), not part of the product library: built into a side library by tools/experiments/build_xffn.sh and
+// timed against csrc/ffn.hip by tools/experiments/xffn_bench.py.  Outcome: correct (1.7e-3 vs the
+// fp32 reference, rows independent bit for bit) and its inner loop is the fast one (tools/ubench/chain_core.hip: 1.5 PFLOP/s),
+// but as a whole 821 TFLOP/s against 939 for ffn.hip: with one wave per SIMD the ~900 VALU instructions of a chunk's
+// bias + GELU + bf16 hand-over cost as long as its 250 MFMAs, and hiding them needs a second FF1 accumulator set the
+// 256 AGPRs do not have next to Y.
+//
 // The token-local tail of a BasicTransformerBlock at the C = 320 level of the SD UNet as ONE kernel per row tile -- round 4's
 // mapping, "the tile in LDS, the weights straight from L2 into registers" (what ffn.hip computes, oracle/sd_unet.py
 // BasicTransformerBlock / Transformer2DModel.proj_out):
@@ -9,9 +16,9 @@
 // Why a second mapping.  ffn.hip keeps 32 ROWS per wave in registers and streams every weight fragment through LDS to
 // every wave: each MFMA consumes its own 1 KB fragment read, four waves = 128 B/clk = the LDS port, and the kernel stops at
 // 0.34-0.41 of the MFMA rate.  Here the roles are swapped:
-//   * a block = 4 waves (one per SIMD) owns a tile of BM = 96 rows.  The activation tile X[96][320] (bf16, 60 KB) lives in
+//   * a block = 4 waves (one per SIMD) owns a tile of BM = 80 rows.  The activation tile X[80][320] (bf16, 50 KB) lives in
 //     LDS, written once per layer; wave w owns the output COLUMNS [80 w, 80 w + 80) of every layer.
-//   * per 32-deep k-step a wave reads the tile's 6 activation fragments from LDS (6 KB for 30 MFMAs: 0.2 KB per MFMA
+//   * per 32-deep k-step a wave reads the tile's 5 activation fragments from LDS (5 KB for 25 MFMAs: 0.2 KB per MFMA
 //     instead of 1 KB) and takes its 5 weight fragments (16 x 32, 1 KB each) straight from global memory / L2 into
 //     VGPRs -- nobody else needs them, so they never touch LDS.  The weights are packed at load time into a stream in
 //     consumption order whose k-step holds, per wave, 5 contiguous lane-linear KB (one coalesced 16-byte load per lane
@@ -23,19 +30,23 @@
 //     consecutive output columns of one row, the layout of the bias / residual / LayerNorm passes and of the 8-byte LDS
 //     writes that hand a layer's result to the next one as activation tile.
 //   * the feed-forward runs in 8 chunks of 160 hidden units: FF1 chunk (320 value | gate rows interleaved so that a
-//     lane holds (v, g) pairs) -> bias -> v * gelu(g) in registers -> bf16 G[96][160] in LDS -> FF2 chunk accumulates
+//     lane holds (v, g) pairs) -> bias -> v * gelu(g) in registers -> bf16 G[80][160] in LDS -> FF2 chunk accumulates
 //     onto Y, which starts as t2 + b2 (the residual stream stays in fp32 registers for the whole block).
 //   * tile I/O: the three input tiles (a, t1, x) come in with coalesced 16-byte loads through registers into the
 //     swizzled LDS image, the result leaves the same way; t1 and x land behind the arithmetic that precedes their use.
-// LDS: X 60 KB | B 60 KB (t1 -> x -> result) | G 36 KB (384-byte rows: whole 128-byte swizzle groups) | 3 KB LayerNorm scratch.
+// LDS: X 50 KB | B 50 KB (t1 -> x -> result) | G 30 KB (384-byte rows: whole 128-byte swizzle groups) | 2.5 KB LayerNorm scratch.
+// Registers (one wave per SIMD, 512): accumulators Y, F 2 x 100 AGPR, activation fragments 2 x 20 AGPR, weight ring 100 VGPR --
+// 96-row tiles (2 x 120 + 48 + 100) left the allocator ~30 registers short and it spilled loop-invariant addresses, whose
+// reloads inside the chunk loop drained the weight ring; 80 rows divide the bench's M = 120 / 96 / 48 x 4096 evenly.
 // Every output row depends on its own input rows only and every summation order is fixed (k ascending in the MFMA chains,
 // LayerNorm statistics: a lane's 20 values in order, the four lanes of a row by xor-shuffle, the four waves in order),
 // so results do not depend on the batch.
 #include <type_traits>
 #include <utility>
 
-#include "common.h"
-#include "kernels.h"
+#include "../../h-edit_amd/csrc/common.h"
+#include "../../h-edit_amd/csrc/kernels.h"
+#include "xffn_decl.h"
 
 namespace {
 
@@ -43,7 +54,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 constexpr int XC = 320;                  // channels
-constexpr int XBM = 96;                  // rows per tile
+constexpr int XBM = 80;                  // rows per tile
 constexpr int XNW = 4;                   // waves = column slices
 constexpr int XWN = XC / XNW;            // 80 output columns per wave
 constexpr int XNI = XWN / 16;            // 5 weight fragments per wave and k-step
@@ -62,7 +73,8 @@ constexpr int X_OFF = 0, B_OFF = XTILE, G_OFF = 2 * XTILE, S_OFF = G_OFF + XBM *
 constexpr int XLDS = S_OFF + XNW * XBM * 8;
 static_assert(XLDS <= 160 * 1024, "tiles + scratch must fit the LDS");
 static_assert(XKS % XRING == 0 && XKS2 % XRING == 0, "every phase a multiple of the register ring");
-static_assert(XBM % 6 == 0 && 6 * (XC / 8) <= 256, "tile I/O: groups of six rows over 240 threads");
+constexpr int XIOR = XBM % 6 == 0 ? 6 : 5;   // rows per I/O group (XIOR x 40 chunks <= 256 threads)
+static_assert(XBM % XIOR == 0 && XIOR * (XC / 8) <= 256, "tile I/O: groups of XIOR rows");
 
 __host__ __device__ constexpr size_t xffn_stream_bytes_c() { return (size_t)XNPOS * XSET; }
 
@@ -170,9 +182,14 @@ __global__ __launch_bounds__(256, 1) void xffn_kernel(XParams p) {
   };
   xstatic_for<XRING - 1>([&](auto s_) { load_set(s_); });
 
-  // one phase = NK k-steps over the activation tile at `tile_off` (fragment offsets rd), accumulating onto acc
-  auto k_loop = [&](auto nk_, f32x4 (&acc)[XNI][XMI], int tile_off, const int (&rd)[XMI]) __attribute__((always_inline)) {
+  // one phase = NK k-steps over the activation tile at `tile_off` (fragment offsets rd), accumulating onto acc (FRESH: the
+  // first k-step starts from the inline constant 0 -- nobody writes 120 zeros).  The MFMAs are inline asm so that the
+  // register files are ours to choose: accumulators and activation fragments in AGPRs (200 + 40 of 256), weight ring in VGPRs -- left to itself the allocator
+  // mixes the files, runs out of one of them and spills into the k loops, whose reloads drain the weight ring
+  // (vmcnt(0) between MFMAs).  What the compiler does not do for asm MFMAs is hazard padding: settle() below.
+  auto k_loop = [&](auto nk_, auto fresh_, f32x4 (&acc)[XNI][XMI], int tile_off, const int (&rd)[XMI]) __attribute__((always_inline)) {
     constexpr int NK = decltype(nk_)::value;
+    constexpr bool FRESH = decltype(fresh_)::value;
     bf16x8 xa[XMI], xb[XMI];
     auto read_x = [&](bf16x8 (&xf)[XMI], int ks) __attribute__((always_inline)) {
 #pragma unroll
@@ -188,23 +205,27 @@ __global__ __launch_bounds__(256, 1) void xffn_kernel(XParams p) {
 #pragma unroll
       for (int j = 0; j < XNI; ++j)
 #pragma unroll
-        for (int i = 0; i < XMI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[ks % XRING][j], xc[i], acc[j][i], 0, 0, 0);
+        for (int i = 0; i < XMI; ++i) {
+          if constexpr (FRESH && ks == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc[j][i]) : "v"(wr[ks % XRING][j]), "a"(xc[i]));
+          else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j][i]) : "v"(wr[ks % XRING][j]), "a"(xc[i]));
+        }
       __builtin_amdgcn_sched_barrier(0);             // (keeps later k-steps' reads where they are: register pressure)
     });
   };
-  auto zero = [&](f32x4 (&acc)[XNI][XMI]) __attribute__((always_inline)) {
+  // the accumulators of the last asm MFMAs become readable by the VALU (8-pass MFMA: the result lands 16+ cycles after issue)
+  auto settle = [&](f32x4 (&acc)[XNI][XMI]) __attribute__((always_inline)) {
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
     for (int j = 0; j < XNI; ++j)
 #pragma unroll
-      for (int i = 0; i < XMI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < XMI; ++i) asm volatile("" : "+a"(acc[j][i]));
   };
-
-  // ---- coalesced tile I/O by the first 240 threads: thread -> (row tid / 40 of a group of six, chunk tid % 40), sixteen
+  // ---- coalesced tile I/O by the first XIOR x 40 threads: thread -> (row tid / 40 of a group of XIOR rows, chunk tid % 40), XBM / XIOR
   // groups per tile; bounds-checked buffer accesses (rows beyond M read as zeros / are not written: no branches).  The row
   // stride is made opaque per use: hoisted in front of the tile loop the 16 offsets of every site would live in scratch.
-  constexpr int XIOG = XBM / 6;
+  constexpr int XIOG = XBM / XIOR;
   const int io_r = tid / (XC / 8), io_c = tid - io_r * (XC / 8);
-  const bool io_on = tid < 6 * (XC / 8);
+  const bool io_on = tid < XIOR * (XC / 8);
   auto opaque = [](int v) __attribute__((always_inline)) { asm volatile("" : "+s"(v)); return v; };
 #if defined(__HIP_DEVICE_COMPILE__)
   auto rsrc = [&](const bf16_t* ptr, long ld) __attribute__((always_inline)) {
@@ -217,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void xffn_kernel(XParams p) {
     const int ld2 = opaque((int)ld * 2);
     const unsigned voff = io_on ? (unsigned)((row0 + io_r) * ld2 + io_c * 16) : 0x7ffffff0u;
 #pragma unroll
-    for (int t = 0; t < XIOG; ++t) buf[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, t * 6 * ld2, 0));
+    for (int t = 0; t < XIOG; ++t) buf[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, t * XIOR * ld2, 0));
 #else
     (void)src; (void)ld; (void)row0; (void)buf;
 #endif
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void xffn_kernel(XParams p) {
   auto put_tile = [&](int tile_off, const u32x4 (&buf)[XIOG]) __attribute__((always_inline)) {
     if (io_on) {
 #pragma unroll
-      for (int t = 0; t < XIOG; ++t) *reinterpret_cast<u32x4*>(smem + tile_off + xswz(opaque(t * 6) + io_r, io_c, XROW)) = buf[t];
+      for (int t = 0; t < XIOG; ++t) *reinterpret_cast<u32x4*>(smem + tile_off + xswz(opaque(t * XIOR) + io_r, io_c, XROW)) = buf[t];
     }
   };
   auto store_tile = [&](int tile_off, bf16_t* dst, long ld, int row0) __attribute__((always_inline)) {
@@ -238,9 +259,9 @@ __global__ __launch_bounds__(256, 1) void xffn_kernel(XParams p) {
     for (int t0 = 0; t0 < XIOG; t0 += GRP) {
       u32x4 buf[GRP];
 #pragma unroll
-      for (int t = 0; t < GRP; ++t) buf[t] = *reinterpret_cast<const u32x4*>(smem + tile_off + xswz(opaque((t0 + t) * 6) + (io_on ? io_r : 0), io_c % (XC / 8), XROW));
+      for (int t = 0; t < GRP; ++t) buf[t] = *reinterpret_cast<const u32x4*>(smem + tile_off + xswz(opaque((t0 + t) * XIOR) + (io_on ? io_r : 0), io_c % (XC / 8), XROW));
 #pragma unroll
-      for (int t = 0; t < GRP; ++t) __builtin_amdgcn_raw_buffer_store_b128(buf[t], rs, voff, (t0 + t) * 6 * ld2, 0);
+      for (int t = 0; t < GRP; ++t) __builtin_amdgcn_raw_buffer_store_b128(buf[t], rs, voff, (t0 + t) * XIOR * ld2, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
 #else
@@ -266,20 +287,34 @@ __global__ __launch_bounds__(256, 1) void xffn_kernel(XParams p) {
       u32x4 ba[XIOG], bt[XIOG];
       load_tile(p.a, p.lda, row0, ba);
       load_tile(p.t1, p.ldt1, row0, bt);
+      // the per-column parameters of the first epilogue (b_pre | gamma | beta | b2) go through the G region, which is idle
+      // until the first feed-forward chunk: read from global memory where they are used, each load would be YOUNGER than
+      // the weight sets in flight, and waiting for it would drain the ring (one in-order queue)
+      f32x4 pv[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int idx = t * 256 + tid;                        // float4 index over the four vectors of 80 float4 each
+        const int which = idx / (XC / 4), c4 = idx - which * (XC / 4);
+        const float* src = which == 0 ? p.bias_pre : (which == 1 ? p.gamma : (which == 2 ? p.beta : p.bias2));
+        pv[t] = idx < XC ? *reinterpret_cast<const f32x4*>(src + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
       put_tile(X_OFF, ba);
       put_tile(B_OFF, bt);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if (t * 256 + tid < XC) *reinterpret_cast<f32x4*>(smem + G_OFF + (t * 256 + tid) * 16) = pv[t];
     }
     __syncthreads();
 
     // ================================================================ t2 = to_out(a) + b + t1;  LayerNorm -> X;  Y = t2 + b2
-    zero(Y);
-    k_loop(std::integral_constant<int, XKS>{}, Y, X_OFF, xrd);
+    k_loop(std::integral_constant<int, XKS>{}, std::true_type{}, Y, X_OFF, xrd);
+    settle(Y);
     float rs[XMI], rq[XMI];
 #pragma unroll
     for (int i = 0; i < XMI; ++i) rs[i] = rq[i] = 0.f;
 #pragma unroll
     for (int j = 0; j < XNI; ++j) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias_pre + ncol0 + j * 16);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(smem + G_OFF + (ncol0 + j * 16) * 4);
 #pragma unroll
       for (int i = 0; i < XMI; ++i) {
         float r4[4];
@@ -301,6 +336,11 @@ __global__ __launch_bounds__(256, 1) void xffn_kernel(XParams p) {
       if (fq == 0) scratch[wave * XBM + i * 16 + fr] = make_float2(rs[i], rq[i]);
     }
     __syncthreads();        // statistics of all four column slices are in LDS; everybody is done reading X and B
+    {   // t1 has been consumed: the rows of x take its place in B (needed by the trailing layer's epilogue)
+      u32x4 bx[XIOG];
+      load_tile(p.x, p.ldx, row0, bx);
+      put_tile(B_OFF, bx);
+    }
     {
       float mean[XMI], rstd[XMI];
 #pragma unroll
@@ -318,9 +358,9 @@ __global__ __launch_bounds__(256, 1) void xffn_kernel(XParams p) {
       }
 #pragma unroll
       for (int j = 0; j < XNI; ++j) {
-        const f32x4 gg = *reinterpret_cast<const f32x4*>(p.gamma + ncol0 + j * 16);
-        const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + ncol0 + j * 16);
-        const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bias2 + ncol0 + j * 16);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(smem + G_OFF + (XC + ncol0 + j * 16) * 4);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(smem + G_OFF + (2 * XC + ncol0 + j * 16) * 4);
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(smem + G_OFF + (3 * XC + ncol0 + j * 16) * 4);
 #pragma unroll
         for (int i = 0; i < XMI; ++i) {
           f32x4 o;
@@ -337,12 +377,15 @@ __global__ __launch_bounds__(256, 1) void xffn_kernel(XParams p) {
     // ================================================================ feed-forward, 8 chunks of 160 hidden units
 #pragma unroll 1
     for (int h = 0; h < XNCH; ++h) {
-      zero(F);
-      k_loop(std::integral_constant<int, XKS>{}, F, X_OFF, xrd);
+      f32x4 b1v[XNI];                              // requested in front of the k loop: older than the weight sets in flight at its use
+#pragma unroll
+      for (int j = 0; j < XNI; ++j) b1v[j] = *reinterpret_cast<const f32x4*>(p.bias1p + h * XC + ncol0 + j * 16);
+      k_loop(std::integral_constant<int, XKS>{}, std::true_type{}, F, X_OFF, xrd);
+      settle(F);
       // bias, v * gelu(g): the lane's 4 columns of block j are (v, g, v, g) of hidden units 40 wave + 8 j + 2 fq + {0, 1}
 #pragma unroll
       for (int j = 0; j < XNI; ++j) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias1p + h * XC + ncol0 + j * 16);
+        const f32x4 bb = b1v[j];
 #pragma unroll
         for (int i = 0; i < XMI; ++i) {
           const f32x4 v = F[j][i] + bb;
@@ -353,29 +396,25 @@ __global__ __launch_bounds__(256, 1) void xffn_kernel(XParams p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();      // G is complete
-      if (h == 0) {
-        // the rows of x travel into B (t1 has been consumed) behind this chunk's FF2 (F is dead: its registers carry them)
-        u32x4 bx[XIOG];
-        load_tile(p.x, p.ldx, row0, bx);
-        k_loop(std::integral_constant<int, XKS2>{}, Y, G_OFF, grd);
-        put_tile(B_OFF, bx);
-      } else {
-        k_loop(std::integral_constant<int, XKS2>{}, Y, G_OFF, grd);
-      }
+      k_loop(std::integral_constant<int, XKS2>{}, std::false_type{}, Y, G_OFF, grd);
       __syncthreads();      // G may be overwritten
     }
 
     // ================================================================ out = proj_out(t3) + b + x
+    settle(Y);
 #pragma unroll
     for (int j = 0; j < XNI; ++j)
 #pragma unroll
       for (int i = 0; i < XMI; ++i) *reinterpret_cast<u32x2*>(smem + X_OFF + pc_off(i, j, XROW)) = pack4(Y[j][i]);
     __syncthreads();        // t3 is in X
-    zero(F);
-    k_loop(std::integral_constant<int, XKS>{}, F, X_OFF, xrd);
+    f32x4 bpv[XNI];
+#pragma unroll
+    for (int j = 0; j < XNI; ++j) bpv[j] = *reinterpret_cast<const f32x4*>(p.bias_post + ncol0 + j * 16);
+    k_loop(std::integral_constant<int, XKS>{}, std::true_type{}, F, X_OFF, xrd);
+    settle(F);
 #pragma unroll
     for (int j = 0; j < XNI; ++j) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias_post + ncol0 + j * 16);
+      const f32x4 bb = bpv[j];
 #pragma unroll
       for (int i = 0; i < XMI; ++i) {
         const int off = B_OFF + pc_off(i, j, XROW);

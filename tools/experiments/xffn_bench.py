@@ -1,16 +1,23 @@
 """The block tail of the 320-channel level at the bench's shape: csrc/xffn.hip (row tile in LDS, weight slices from L2 into
 registers) against csrc/ffn.hip (rows in registers, weights through LDS) on the same operands: time, TFLOP/s, difference.
-Usage: python tools/xffn_bench.py [rows=120] [reps=10]      (HEDIT_LIB_VARIANT=name loads lib_name.so.bin)"""
+Usage: tools/experiments/build_xffn.sh (no GPU needed), then on the GPU box: python tools/experiments/xffn_bench.py [rows=120] [reps=10]"""
 import math, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
 import torch
+import ctypes as C
 from hedit import _lib
-if os.environ.get("HEDIT_LIB_VARIANT"):
-    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"lib_{os.environ['HEDIT_LIB_VARIANT']}.so.bin")
+# the side library of tools/experiments/build_xffn.sh: the product library plus the experiment's units
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "lib_xffn.so.bin")
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-lib = _lib.lib(); dev = "cuda:0"; C = lib.hedit_k_ffn_channels(); M = rows * 4096
+lib = _lib.lib(); dev = "cuda:0"
+lib.hedit_k_xffn_stream_bytes.restype = C.c_size_t; lib.hedit_k_xffn_stream_bytes.argtypes = []
+lib.hedit_k_xffn_bias_bytes.restype = C.c_size_t; lib.hedit_k_xffn_bias_bytes.argtypes = []
+lib.hedit_k_xffn_pack.restype = C.c_int; lib.hedit_k_xffn_pack.argtypes = [C.c_void_p] * 8
+lib.hedit_k_xffn_chain.restype = C.c_int
+lib.hedit_k_xffn_chain.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]; C = lib.hedit_k_ffn_channels(); M = rows * 4096
 g = torch.Generator().manual_seed(0)
 a = torch.randn(M, C, generator=g).to(torch.bfloat16).to(dev)
 t1 = (torch.randn(M, C, generator=g) * 1.5).to(torch.bfloat16).to(dev)
