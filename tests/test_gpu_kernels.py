@@ -242,8 +242,9 @@ def test_ffn_fused_rows_are_independent_and_repeatable(lib):
     assert torch.equal(full[-1:], one)
 
 
-@pytest.mark.parametrize("M", [128, 4096 + 77, 3 * 4096, 11 * 4096 + 5])     # (the last: more tiles than CUs, several per block)
-def test_lin_chain_out_then_query(lib, M):
+@pytest.mark.parametrize("impl", ["chain", "tile"])      # csrc/linchain.hip | csrc/lintile.hip: same contract
+@pytest.mark.parametrize("M", [128, 4096 + 77, 3 * 4096, 11 * 4096 + 5, 70 * 4096 + 8])     # (more tiles than CUs, several per block)
+def test_lin_chain_out_then_query(lib, M, impl):
     """attn1.to_out + residual -> norm2 -> attn2.to_q in one kernel (csrc/ffn.hip, hedit_k_lin_chain, one output) == the
     three layers in fp32 on the bf16-rounded operands (diffusers BasicTransformerBlock, oracle/sd_unet.py); both results
     (the residual stream and the query) are functions of their own row alone, bit for bit."""
@@ -256,14 +257,15 @@ def test_lin_chain_out_then_query(lib, M):
     bo = G.f32(torch.randn(Cc, generator=g) * 0.3)
     wq = G.f32(torch.randn(Cc, Cc, generator=g) / math.sqrt(Cc))
     scale = 0.2281
-    ws = torch.empty(lib.hedit_k_lin_chain_stream_bytes(1), dtype=torch.uint8, device=G.dev())
-    _lib.check(lib.hedit_k_lin_chain_pack(_lib.ptr(wo), _lib.ptr(wq), None, None, scale, _lib.ptr(ws), None))
+    f_bytes, f_pack, f_run = (getattr(lib, f"hedit_k_lin_{impl}{sfx}") for sfx in ("_stream_bytes", "_pack", ""))
+    ws = torch.empty(f_bytes(1), dtype=torch.uint8, device=G.dev())
+    _lib.check(f_pack(_lib.ptr(wo), _lib.ptr(wq), None, None, scale, _lib.ptr(ws), None))
 
     def run(a_, r1_):
         m = a_.shape[0]
         mid = torch.zeros(m, Cc, dtype=torch.bfloat16, device=G.dev())
         q = torch.zeros(m, Cc, dtype=torch.bfloat16, device=G.dev())
-        _lib.check(lib.hedit_k_lin_chain(_lib.ptr(a_), Cc, _lib.ptr(r1_), Cc, None, 0, _lib.ptr(bo), _lib.ptr(gamma), _lib.ptr(beta), 1e-5,
+        _lib.check(f_run(_lib.ptr(a_), Cc, _lib.ptr(r1_), Cc, None, 0, _lib.ptr(bo), _lib.ptr(gamma), _lib.ptr(beta), 1e-5,
                                          _lib.ptr(ws), _lib.ptr(mid), Cc, None, 0, None, 0, _lib.ptr(q), Cc, m, Cc, None))
         G.sync()
         return mid, q
@@ -281,8 +283,9 @@ def test_lin_chain_out_then_query(lib, M):
     assert torch.equal(mid3, mid[lo:]) and torch.equal(q3, q[lo:])
 
 
-@pytest.mark.parametrize("B,N", [(1, 128), (3, 1024), (2, 4096), (11, 4096), (5, 576), (3, 64)])     # (24 x 24 / 8 x 8 tokens: images that are not whole 128-row tiles)
-def test_lin_chain_groupnorm_to_qkv(lib, B, N):
+@pytest.mark.parametrize("impl", ["chain", "tile"])
+@pytest.mark.parametrize("B,N", [(1, 128), (3, 1024), (2, 4096), (11, 4096), (5, 576), (3, 64), (70, 4096)])     # (24 x 24 / 8 x 8 tokens: images that are not whole 128-row tiles)
+def test_lin_chain_groupnorm_to_qkv(lib, B, N, impl):
     """GroupNorm (applied on the fly) -> proj_in -> norm1 -> attn1.to_q | to_k | to_v^T in one kernel (hedit_k_lin_chain,
     three outputs; Transformer2DModel.norm / proj_in and the self-attention projections, oracle/sd_unet.py) == the layers
     in fp32 on the bf16-rounded operands; q and k go into one [M][2C] buffer, v comes out transposed ([C][M])."""
@@ -296,8 +299,9 @@ def test_lin_chain_groupnorm_to_qkv(lib, B, N):
     b_in = G.f32(torch.randn(Cc, generator=g) * 0.3)
     wq, wk, wv = (G.f32(torch.randn(Cc, Cc, generator=g) / math.sqrt(Cc)) for _ in range(3))
     scale = 0.2281
-    ws = torch.empty(lib.hedit_k_lin_chain_stream_bytes(3), dtype=torch.uint8, device=G.dev())
-    _lib.check(lib.hedit_k_lin_chain_pack(_lib.ptr(w_in), _lib.ptr(wq), _lib.ptr(wk), _lib.ptr(wv), scale, _lib.ptr(ws), None))
+    f_bytes, f_pack, f_run = (getattr(lib, f"hedit_k_lin_{impl}{sfx}") for sfx in ("_stream_bytes", "_pack", ""))
+    ws = torch.empty(f_bytes(3), dtype=torch.uint8, device=G.dev())
+    _lib.check(f_pack(_lib.ptr(w_in), _lib.ptr(wq), _lib.ptr(wk), _lib.ptr(wv), scale, _lib.ptr(ws), None))
     gws = torch.empty(lib.hedit_k_groupnorm_ws_bytes(B, N, Cc), dtype=torch.uint8, device=G.dev())
 
     def run(x_):
@@ -308,9 +312,9 @@ def test_lin_chain_groupnorm_to_qkv(lib, B, N):
         mid = torch.zeros(m, Cc, dtype=torch.bfloat16, device=G.dev())
         qk = torch.zeros(m, 2 * Cc, dtype=torch.bfloat16, device=G.dev())
         vt = torch.zeros(Cc, m, dtype=torch.bfloat16, device=G.dev())
-        _lib.check(lib.hedit_k_lin_chain(_lib.ptr(x_), Cc, None, 0, _lib.ptr(ss), N, _lib.ptr(b_in), _lib.ptr(gamma), _lib.ptr(beta), 1e-5,
-                                         _lib.ptr(ws), _lib.ptr(mid), Cc, _lib.ptr(qk), 2 * Cc, qk.data_ptr() + 2 * Cc, 2 * Cc,
-                                         _lib.ptr(vt), m, m, Cc, None))
+        _lib.check(f_run(_lib.ptr(x_), Cc, None, 0, _lib.ptr(ss), N, _lib.ptr(b_in), _lib.ptr(gamma), _lib.ptr(beta), 1e-5,
+                         _lib.ptr(ws), _lib.ptr(mid), Cc, _lib.ptr(qk), 2 * Cc, qk.data_ptr() + 2 * Cc, 2 * Cc,
+                         _lib.ptr(vt), m, m, Cc, None))
         G.sync()
         return mid, qk, vt
     mid, qk, vt = run(x)

@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256, 1) void xffn_kernel(XParams p) {
       for (int j = 0; j < XNI; ++j)
 #pragma unroll
         for (int i = 0; i < XMI; ++i) {
-          if constexpr (FRESH && ks == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc[j][i]) : "v"(wr[ks % XRING][j]), "a"(xc[i]));
-          else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j][i]) : "v"(wr[ks % XRING][j]), "a"(xc[i]));
+          if constexpr (FRESH && ks == 0) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc[j][i]) : "v"(wr[ks % XRING][j]), "a"(xc[i]));
+          else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j][i]) : "v"(wr[ks % XRING][j]), "a"(xc[i]));
         }
       __builtin_amdgcn_sched_barrier(0);             // (keeps later k-steps' reads where they are: register pressure)
     });
