@@ -84,12 +84,6 @@ size_t lin_chain_stream_bytes(int layers);        // layers = 2 (to_out, to_q) o
 // Largest launch: M * ld * 2 bytes of every row tensor below 2 GiB (32-bit buffer offsets), i.e. M < 1 677 721 rows of
 // 320 channels with dense rows = 409 rows of 64 x 64 tokens (the bench runs 120); lin_chain_launch refuses more.
 int lin_chain_pack_launch(const float* w, int layer, float scale, int layers, bf16_t* stream, hipStream_t st);
-// ---------------------------------------------------------------- lintile.hip
-// the same two chains (same LinChainParams) in round 4's mapping: 64-row tile in LDS, weight slices from L2 into registers,
-// two blocks per CU; own stream layout (lin_tile_pack_launch: same arguments as lin_chain_pack_launch)
-int lin_tile_launch(const LinChainParams& c, hipStream_t st);
-size_t lin_tile_stream_bytes(int layers);
-int lin_tile_pack_launch(const float* w, int layer, float scale, int layers, bf16_t* stream, hipStream_t st);
 int ffn_fused_channels();
 size_t ffn_stream_bytes(int pre, int post);
 size_t ffn_bias_bytes();

@@ -302,15 +302,6 @@ int hedit_k_lin_chain(const void* a, int64_t lda, const void* r1, int64_t ldr1, 
                       const float* bias_pre, const float* gamma, const float* beta, float eps, const void* w_stream, void* out_mid,
                       int64_t ldmid, void* out_q, int64_t ldq, void* out_k, int64_t ldk, void* out, int64_t ldo, int M, int C,
                       void* stream);
-/* The same two forms in round 4's mapping (csrc/lintile.hip: 64-row tile in LDS, weight slices from L2 into registers, two blocks
- * per CU); arguments as hedit_k_lin_chain / _pack / _stream_bytes, own weight-stream layout. */
-size_t hedit_k_lin_tile_stream_bytes(int n_out);
-int hedit_k_lin_tile_pack(const float* w_pre, const float* w0, const float* w1, const float* w2, float scale0, void* stream_out,
-                          void* stream);
-int hedit_k_lin_tile(const void* a, int64_t lda, const void* r1, int64_t ldr1, const float* gn_ss, int rows_per_image,
-                     const float* bias_pre, const float* gamma, const float* beta, float eps, const void* w_stream, void* out_mid,
-                     int64_t ldmid, void* out_q, int64_t ldq, void* out_k, int64_t ldk, void* out, int64_t ldo, int M, int C,
-                     void* stream);
 /* Test entry (tests/test_gpu_chain_hazard.py): hedit_k_lin_chain with the kernel's wait schedule chosen -- sched 0 = the
  * product's (counted vmcnt windows around the bursts between the layers), 1 = every wait drained to vmcnt(0) lgkmcnt(0)
  * in front of its barrier: same arithmetic, no reliance on queue order or timing, i.e. the bits the product schedule must

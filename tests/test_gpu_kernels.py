@@ -242,7 +242,7 @@ def test_ffn_fused_rows_are_independent_and_repeatable(lib):
     assert torch.equal(full[-1:], one)
 
 
-@pytest.mark.parametrize("impl", ["chain", "tile"])      # csrc/linchain.hip | csrc/lintile.hip: same contract
+@pytest.mark.parametrize("impl", ["chain"])
 @pytest.mark.parametrize("M", [128, 4096 + 77, 3 * 4096, 11 * 4096 + 5, 70 * 4096 + 8])     # (more tiles than CUs, several per block)
 def test_lin_chain_out_then_query(lib, M, impl):
     """attn1.to_out + residual -> norm2 -> attn2.to_q in one kernel (csrc/ffn.hip, hedit_k_lin_chain, one output) == the
@@ -283,7 +283,7 @@ def test_lin_chain_out_then_query(lib, M, impl):
     assert torch.equal(mid3, mid[lo:]) and torch.equal(q3, q[lo:])
 
 
-@pytest.mark.parametrize("impl", ["chain", "tile"])
+@pytest.mark.parametrize("impl", ["chain"])
 @pytest.mark.parametrize("B,N", [(1, 128), (3, 1024), (2, 4096), (11, 4096), (5, 576), (3, 64), (70, 4096)])     # (24 x 24 / 8 x 8 tokens: images that are not whole 128-row tiles)
 def test_lin_chain_groupnorm_to_qkv(lib, B, N, impl):
     """GroupNorm (applied on the fly) -> proj_in -> norm1 -> attn1.to_q | to_k | to_v^T in one kernel (hedit_k_lin_chain,

@@ -13,7 +13,7 @@ if [ "$1" == "build" ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -DHEDIT_LINCHAIN_INLAYER \
       -c $ROOT/h-edit_amd/csrc/linchain.hip -o $OBJ
   OBJS=""
-  for u in gemm ffn linchain lintile norm attn step grad pnet unet vae ddpm irse lpips vit c_api; do
+  for u in gemm ffn linchain norm attn step grad pnet unet vae ddpm irse lpips vit c_api; do
     if [ $u == linchain ]; then OBJS="$OBJS $OBJ"; else OBJS="$OBJS $ROOT/h-edit_amd/build/$u.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/h-edit_amd/hedit/lib_inlayer.so.bin $OBJS

@@ -1,16 +1,19 @@
 """The projection chains around the attentions of the 320-channel level at the bench's shape: csrc/lintile.hip (64-row tile in
 LDS, weight slices from L2 into registers, two blocks per CU) against csrc/linchain.hip (rows in registers, weights through
-LDS) on the same operands: time per launch, algorithmic TFLOP/s and GB/s, difference.  python tools/lin_bench.py [rows=120] [reps=20]"""
+LDS) on the same operands: time per launch, algorithmic TFLOP/s and GB/s, difference.  tools/experiments/build_xffn.sh, then on the GPU box: python tools/experiments/lin_bench.py [rows=120] [reps=20]"""
 import math, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
 import torch
 from hedit import _lib
-if os.environ.get("HEDIT_LIB_VARIANT"):
-    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"lib_{os.environ['HEDIT_LIB_VARIANT']}.so.bin")
+import ctypes as C
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "lib_xffn.so.bin")      # side library of tools/experiments/build_xffn.sh
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-lib = _lib.lib(); dev = "cuda:0"; C = 320; N = 4096; M = rows * N
+lib = _lib.lib(); dev = "cuda:0"
+lib.hedit_k_lin_tile_stream_bytes.restype = C.c_size_t; lib.hedit_k_lin_tile_stream_bytes.argtypes = [C.c_int]
+lib.hedit_k_lin_tile_pack.restype = C.c_int; lib.hedit_k_lin_tile_pack.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p]
+lib.hedit_k_lin_tile.restype = C.c_int; lib.hedit_k_lin_tile.argtypes = lib.hedit_k_lin_chain.argtypes; C = 320; N = 4096; M = rows * N
 g = torch.Generator().manual_seed(0)
 x = (torch.randn(M, C, generator=g) * 1.5).to(torch.bfloat16).to(dev)
 a = torch.randn(M, C, generator=g).to(torch.bfloat16).to(dev)

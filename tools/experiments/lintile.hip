@@ -1,3 +1,10 @@
+// EXPERIMENT (round 4), not part of the product library: built into the side library of tools/experiments/build_xffn.sh and
+// timed against csrc/linchain.hip by tools/experiments/lin_bench.py.  Outcome: correct (same bits as
+// linchain.hip for the residual stream, 5e-5 apart for q / k / v^T; rows independent bit for bit) but no faster: 408 us against
+// 410 for the two-layer chain and 899 against 611 for the four-layer one at M = 491 520 -- with 80 KB of LDS per block there is
+// no room to stage the next tile, two blocks per CU do not hide five dependent memory round trips per tile, and smaller tiles
+// pay for it in weight traffic (every block streams every weight).
+//
 // The token-local projections AROUND the two attentions of a BasicTransformerBlock at the C = 320 level of the SD UNet (what
 // linchain.hip computes; oracle/sd_unet.py: Transformer2DModel.norm / proj_in, BasicTransformerBlock norm1 / attn1.to_q|k|v,
 // attn1.to_out, norm2, attn2.to_q), in round 4's mapping -- "the row tile in LDS, the weights straight from L2 into registers":
@@ -27,8 +34,9 @@
 #include <type_traits>
 #include <utility>
 
-#include "common.h"
-#include "kernels.h"
+#include "../../h-edit_amd/csrc/common.h"
+#include "../../h-edit_amd/csrc/kernels.h"
+#include "lintile_decl.h"
 
 namespace {
 
