@@ -43,7 +43,7 @@ def sd_vae_pair():
 def test_sd15_decode_and_encode_512_match_oracle(sd_vae_pair):
     """(1,4,64,64) latent -> (1,3,512,512) image and back to the mode of the posterior, both against oracle/sd_vae.py
     (reference call sites text-guided/main_p2p.py:159 encode(...).latent_dist.mode(), :263 decode; n-style h_edit.py:170).
-    Measured on MI355X: decode 7.6e-3, encode 7.4e-3."""
+    Measured on MI355X: decode 9.2e-3, encode 1.3e-2."""
     hip, om = sd_vae_pair
     g = torch.Generator().manual_seed(9)
     z = torch.randn(1, 4, 64, 64, generator=g)
@@ -69,7 +69,7 @@ def test_sd15_decode_vjp_512_matches_oracle_autograd(sd_vae_pair):
     """d_z = J^T d_image of the full-size decoder from the HIP backward pass (hedit_vae_decode_vjp) against
     torch.autograd.grad through the fp32 oracle -- how the reference's style closure obtains it (n-style h_edit.py:176-179).
     d_image is the gradient of a smooth functional of the image (its squared distance to a fixed target), like the
-    closure's.  Measured on MI355X: 1.6e-2."""
+    closure's.  Measured on MI355X: 7.4e-3."""
     hip, om = sd_vae_pair
     g = torch.Generator().manual_seed(4)
     z = torch.randn(1, 4, 64, 64, generator=g) / 0.18215
@@ -103,7 +103,7 @@ def test_style_step_at_sd_shape_matches_oracle(sd_vae_pair):
     rho = rms(correction) / rms(g) * weight (n-style h_edit.py:162-182), HIP (engine.style_step: hedit_step_tweedie,
     hedit_vae_decode + _vjp, hedit_vit_gram_fwd_bwd, hedit_step_style) against oracle/loops.py::_style_step with the
     oracle autoencoder and style encoder.  The update renormalises g, so what is compared is the step (its direction)
-    and the result.  Measured on MI355X: step 2.3e-2, result 1.4e-3."""
+    and the result.  Measured on MI355X: step 1.1e-2, result 1.1e-2."""
     from oracle import loops as OL
     from hedit.clip_guidance import CLIPEncoder
     from hedit.clip_guidance.base_clip import ClipVisualPrefix
