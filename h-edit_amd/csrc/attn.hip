@@ -252,21 +252,9 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
 
   f32x16 o[NS][DT];
   float m_run[NS], l_run[NS];
-#pragma unroll
-  for (int a = 0; a < NS; ++a) {
-    m_run[a] = -1e30f;
-    l_run[a] = 0.f;
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[a][t][r] = 0.f;
-  }
-
   const int ntiles = p.N / 64;
   const int TU = ntiles * C::UT;
   __syncthreads();          // zero / ones fill done
-  for (int t = 0; t <= C::PD && t < ntiles; ++t) dma_tile(t, t);
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
   // Lazy rescale: the running maximum (log2 domain) of a stream is only raised -- and O, l
   // rescaled -- when some row's block maximum exceeds it by more than RESCALE_THR; until then
@@ -285,13 +273,6 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
   f32x16 S[4];
   bf16x8 kf[DK], vf[DT][2], pfa[2], pfb[2];
   float mx_next;          // row max of the unit whose softmax comes next
-  pfa[0] = pfa[1] = pfb[0] = pfb[1] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) vf[dt][0] = vf[dt][1] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-  if (FOLD) {
-#pragma unroll
-    for (int a = 0; a < NS; ++a) m_run[a] = 0.f;         // Q's pad column is 0: S - 0
-  }
 
   // unit U -> (tile, sub, stream a, query group g)
   auto unit_tile = [&](int U) __attribute__((always_inline)) { return QG == 2 ? (U >> 2) : (U >> 1); };
@@ -346,8 +327,26 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
     return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
   };
 
-  // prologue: scores of units 0 and 1, max of unit 0
-  {
+  // (re)start: accumulators, the ring's first tiles, scores of units 0 and 1, max of unit 0
+  auto start = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+      m_run[a] = FOLD ? 0.f : -1e30f;                      // FOLD: Q's pad column is 0: S - 0
+      l_run[a] = 0.f;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[a][t][r] = 0.f;
+    }
+    if (FOLD) {
+#pragma unroll
+      for (int g = 0; g < QG; ++g) set_q_shift(g, 0.f);
+    }
+    pfa[0] = pfa[1] = pfb[0] = pfb[1] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vf[dt][0] = vf[dt][1] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t <= C::PD && t < ntiles; ++t) dma_tile(t, t);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     read_kf(smem, 0);
     if (FOLD) fix_kf();
     do_qk(S[0], 0);
@@ -356,12 +355,14 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
     float mxa = -1e30f, mxb = -1e30f;
     max4(mxa, S[0], 0); max4(mxa, S[0], 1); max4(mxb, S[0], 2); max4(mxb, S[0], 3);
     mx_next = max_halves(mxa, mxb);
-  }
+  };
 
   // one pipelined block; J = U mod 4 is compile-time
-  auto block = [&](auto jc, auto guard, int U) __attribute__((always_inline)) {
+  // PINNED (see "Pinned shift" below): no row maximum, no rescale -- the stream keeps the shift it has
+  auto block = [&](auto jc, auto guard, auto pinned, int U) __attribute__((always_inline)) {
     constexpr int J = decltype(jc)::value;
     constexpr bool GUARD = decltype(guard)::value;        // tail iteration: units U+1, U+2 may not exist
+    constexpr bool PINNED = decltype(pinned)::value;
     constexpr int JJ = QG == 2 ? J : (J & 1);             // index inside the tile
     constexpr int SUB = QG == 2 ? (JJ >> 1) : JJ;
     constexpr int A = NS == 2 ? (J & 1) : 0;              // stream of unit U
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
       for (int i = 0; i < NPV; ++i) mfma_hi(vf[i % DT][i / DT], pf_prev[i / DT], o[AP][i % DT]);
     }
     // 1. lazy rescale of stream A for unit U.  mx_next: FOLD ? max(S - m_run) : max(S)
-    {
+    if (!PINNED) {
       const float over = FOLD ? mx_next : mx_next - m_run[A];
       const bool first = FOLD && U < 2;                   // pins the shift to the first block's max
       if (first || !__all(over <= RESCALE_THR)) {
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
       asm volatile("" : "+v"(p0));
       if (!ONES) ls += e0 + e1;
       pk[i >> 2].u[i & 3] = p0;
-      if ((i & 1) && has1) max4((i >> 1) < 2 ? mxa : mxb, S[(J + 1) & 3], i >> 1);
+      if (!PINNED && (i & 1) && has1) max4((i >> 1) < 2 ? mxa : mxb, S[(J + 1) & 3], i >> 1);
     };
     constexpr int NPVS = NS == 2 ? NPV : 0;                // P.V MFMAs still to issue here
     constexpr int NM = NPVS + DK;
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
     // keep the exp/pack work HERE: its only consumer is the P.V in the next block, and LLVM
     // would otherwise sink it across the rescale branch right in front of those MFMAs
     asm volatile("" : "+v"(pf_cur[0]), "+v"(pf_cur[1]));
-    if (has1) {
+    if (!PINNED && has1) {
       mx_next = max_halves(mxa, mxb);
       asm volatile("" : "+v"(mx_next));
     }
@@ -498,34 +499,55 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
   using std::integral_constant;
   using std::false_type;
   using std::true_type;
-  int U = 0;
-  for (; U + 6 <= TU; U += 4) {      // every unit up to U+5 exists: no guards inside
-    if (QG == 1) hand_over((U >> 1) + 1);
-    block(integral_constant<int, 0>{}, false_type{}, U);
-    block(integral_constant<int, 1>{}, false_type{}, U + 1);
-    if (QG == 2) hand_over((U >> 2) + 1); else hand_over((U >> 1) + 2);
-    block(integral_constant<int, 2>{}, false_type{}, U + 2);
-    block(integral_constant<int, 3>{}, false_type{}, U + 3);
-  }
-  {                                  // tail: the last 2 or 4 units
-    if (QG == 1) hand_over((U >> 1) + 1);
-    block(integral_constant<int, 0>{}, true_type{}, U);
-    block(integral_constant<int, 1>{}, true_type{}, U + 1);
-    if (U + 2 < TU) {
+  // Pinned shift.  Softmax is invariant to the shift a row uses, and bf16 / fp32 carry 2^+-127: once a stream has a shift
+  // from its first units (the maximum over their 32 or 64 kv rows), tracking the running maximum only guards against
+  // scores that exceed it by ~2^100 -- which the row's denominator reveals afterwards.  So a pass with PIN = true runs the
+  // first four units with the full max / rescale logic and every later unit with none (8 v_max3, the cross-half exchange,
+  // the compare and the branch: 13 of ~42 VALU instructions per unit, on a kernel whose VALU and matrix pipes are both
+  // ~70 % busy), and the caller checks the denominators: a block in which any row's denominator reached 2^60 (or is not
+  // finite) repeats its work with PIN = false -- the exact online softmax, whatever the scores.  Which path a block takes
+  // depends on its own rows only, so results stay independent of the batch.
+  auto pass = [&](auto pin) __attribute__((always_inline)) {
+    constexpr bool PIN = decltype(pin)::value;
+    start();
+    int U = 0;
+    if (PIN) {                         // (the caller guarantees TU >= 6)
+      if (QG == 1) hand_over((U >> 1) + 1);
+      block(integral_constant<int, 0>{}, false_type{}, false_type{}, U);
+      block(integral_constant<int, 1>{}, false_type{}, false_type{}, U + 1);
       if (QG == 2) hand_over((U >> 2) + 1); else hand_over((U >> 1) + 2);
-      block(integral_constant<int, 2>{}, true_type{}, U + 2);
-      block(integral_constant<int, 3>{}, true_type{}, U + 3);
+      block(integral_constant<int, 2>{}, false_type{}, false_type{}, U + 2);
+      block(integral_constant<int, 3>{}, false_type{}, false_type{}, U + 3);
+      U = 4;
     }
-  }
-  // drain: P.V of the last unit (stream 1; TU is even)
-  {
-    bf16x8 (&pf_last)[2] = pfb;    // the last unit is odd: its block packed into pfb
-    constexpr int AL = NS - 1;
+    for (; U + 6 <= TU; U += 4) {      // every unit up to U+5 exists: no guards inside
+      if (QG == 1) hand_over((U >> 1) + 1);
+      block(integral_constant<int, 0>{}, false_type{}, pin, U);
+      block(integral_constant<int, 1>{}, false_type{}, pin, U + 1);
+      if (QG == 2) hand_over((U >> 2) + 1); else hand_over((U >> 1) + 2);
+      block(integral_constant<int, 2>{}, false_type{}, pin, U + 2);
+      block(integral_constant<int, 3>{}, false_type{}, pin, U + 3);
+    }
+    {                                  // tail: the last 2 or 4 units
+      if (QG == 1) hand_over((U >> 1) + 1);
+      block(integral_constant<int, 0>{}, true_type{}, pin, U);
+      block(integral_constant<int, 1>{}, true_type{}, pin, U + 1);
+      if (U + 2 < TU) {
+        if (QG == 2) hand_over((U >> 2) + 1); else hand_over((U >> 1) + 2);
+        block(integral_constant<int, 2>{}, true_type{}, pin, U + 2);
+        block(integral_constant<int, 3>{}, true_type{}, pin, U + 3);
+      }
+    }
+    // drain: P.V of the last unit (stream 1; TU is even)
+    {
+      bf16x8 (&pf_last)[2] = pfb;    // the last unit is odd: its block packed into pfb
+      constexpr int AL = NS - 1;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[AL][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][0], pf_last[0], o[AL][dt], 0, 0, 0);
+      for (int dt = 0; dt < DT; ++dt) o[AL][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][0], pf_last[0], o[AL][dt], 0, 0, 0);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[AL][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][1], pf_last[1], o[AL][dt], 0, 0, 0);
-  }
+      for (int dt = 0; dt < DT; ++dt) o[AL][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][1], pf_last[1], o[AL][dt], 0, 0, 0);
+    }
+  };
 
   constexpr int dl = D - (DT - 1) * 32;            // pad row D inside the last tile (ONES)
   constexpr int r1 = (dl & 3) + 4 * (dl >> 3);
@@ -551,6 +573,19 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
         }
     }
   };
+  {
+    // (d = 64 keeps the exact pass only: with its 244 registers the two passes' live ranges no longer fit 256)
+    constexpr bool CAN_PIN = D != 64;
+    int redo = 1;
+    if (CAN_PIN && TU >= 6) {
+      pass(true_type{});
+      bool bad = false;
+#pragma unroll
+      for (int a = 0; a < NS; ++a) bad |= !(denom(a) < 0x1p60f);
+      redo = __syncthreads_or(bad ? 1 : 0);        // (also: nobody reads the ring any more)
+    }
+    if (redo) pass(false_type{});
+  }
   if (QG == 2) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) write_out(o[g], 1.0f / denom(g), q_base + g * 32);

@@ -485,6 +485,50 @@ def test_self_attention_online_softmax_rescale(lib):
     assert torch.isfinite(out.float()).all()
 
 
+@pytest.mark.parametrize("d,heads,N", [(40, 8, 1024), (80, 8, 512), (160, 8, 256), (32, 2, 512), (64, 2, 512)])
+@pytest.mark.parametrize("lift", [45.0, 90.0, 200.0])
+def test_self_attention_pinned_shift_and_exact_fallback(lib, d, heads, N, lift):
+    """The fast pass keeps the shift of a stream's first units and checks the denominators afterwards (attn.hip, "Pinned
+    shift").  Keys late in the sequence that beat everything of the first tile by 2^45 stay on the fast pass (probabilities
+    up to 2^45 are as exact in bf16 / fp32 as any other), by 2^90 trip the 2^60 denominator check, by 2^200 overflow to
+    inf -- the latter two must come out of the exact pass; all three must match the fp32 softmax."""
+    B = 2
+    g = torch.Generator().manual_seed(int(lift) + d)
+    Cc = d * heads
+    q = torch.randn(B, N, Cc, generator=g) * 0.3
+    k = torch.randn(B, N, Cc, generator=g)
+    v = torch.randn(B, N, Cc, generator=g)
+    rows = [(0, 7, 3 * N // 4 + 16), (0, 200, 70), (1, N - 1, N - 1), (1, 33, 129)]           # (batch row, query, key)
+    for (b, qi, ki) in rows:
+        for h in range(heads):
+            qh = q[b, qi, h * d:(h + 1) * d]
+            k[b, ki, h * d:(h + 1) * d] = qh * (lift / float(qh @ qh))
+    q, k, v = G.bf(q), G.bf(k), G.bf(v)
+    qk = torch.cat([q, k], dim=-1).contiguous()
+    vt = v.reshape(B * N, Cc).t().contiguous()
+    k_view = qk.reshape(B * N, 2 * Cc)[:, Cc:]
+    outs = []
+    for _ in range(2):
+        out = torch.zeros(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
+        _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * Cc, C.c_void_p(k_view.data_ptr()), 2 * Cc, _lib.ptr(vt),
+                                         B * N, _lib.ptr(out), Cc, B, N, heads, d, None, None, None))
+        G.sync()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.isfinite(outs[0].float()).all()
+    _, want = attn_ref(q.float(), k.float(), v.float(), heads)
+    assert G.rel_err(outs[0].float(), want) < 1.2e-2
+    for (b, qi, ki) in rows:                                                       # the rows the spikes own
+        assert G.max_err(outs[0][b, qi].float(), want[b, qi]) < 3e-2
+    # a block's path depends on its own rows only: the second batch row alone gives the same bits
+    out1 = torch.zeros(1, N, Cc, dtype=torch.bfloat16, device=G.dev())
+    qk1, vt1 = qk[1:].contiguous(), v[1].reshape(N, Cc).t().contiguous()
+    _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk1), 2 * Cc, C.c_void_p(qk1.reshape(N, 2 * Cc)[:, Cc:].data_ptr()), 2 * Cc,
+                                     _lib.ptr(vt1), N, _lib.ptr(out1), Cc, 1, N, heads, d, None, None, None))
+    G.sync()
+    assert torch.equal(out1[0], outs[0][1])
+
+
 @pytest.mark.parametrize("d,heads,N", [(32, 2, 256), (40, 8, 1024), (64, 2, 64), (80, 8, 256), (160, 8, 64)])
 def test_cross_attention_p2p(lib, d, heads, N):
     g = torch.Generator().manual_seed(d * 3 + N)
