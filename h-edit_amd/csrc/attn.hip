@@ -225,7 +225,17 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
 
   // ---- fragment addressing
   // K-tile row read by lane ql for S^T row ql of a half tile (see header): kv_perm
-  const int kv_perm = 16 * (ql >> 4) + 8 * ((ql >> 2) & 1) + 4 * ((ql >> 3) & 1) + (ql & 3);
+  // PV16 (d = 40): P.V on v_mfma_f32_16x16x32_bf16 -- O^T as 16-row tiles, 48 rows (40 + the ones row + pad) instead of
+  // 64: six MFMAs of 16 cycles instead of four of 32 per unit, three b128 V^T reads instead of four.  Its B operand
+  // wants lane l = 32 hi + 16 g + i to hold, for the 16 queries of group g', the 8 consecutive kv of block 2 hi + g.
+  // The lane owns query 16 g + i with the blocks r = 0..7 and r = 8..15 of its S^T column; with the K rows permuted so
+  // that block c of half hi is kv block 2 hi + c, one v_permlane16_swap per packed dword (block 0 of the g = 1 lanes
+  // against block 1 of the g = 0 lanes) leaves "the block for queries 0..15" in the first and "the block for queries
+  // 16..31" in the second register set of every lane.
+  constexpr bool PV16 = D == 40 && QG == 2 && NS == 2;
+  constexpr int DT16 = (D + 16) / 16;                   // 16-row tiles of O^T, the ones row included
+  const int kv_perm = PV16 ? 16 * ((ql >> 2) & 1) + 8 * (ql >> 4) + 4 * ((ql >> 3) & 1) + (ql & 3)
+                           : 16 * (ql >> 4) + 8 * ((ql >> 2) & 1) + 4 * ((ql >> 3) & 1) + (ql & 3);
   // byte offset (inside a stage) of the K fragment (sub, ks): the swizzle only touches the low
   // bits of the chunk index, so NPAR per-lane bases + compile-time offsets cover every ks
   constexpr int RS = C::DCH * 16;                       // K row stride
@@ -249,8 +259,15 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
   auto v_addr = [&](int sub, int dt, int half) __attribute__((always_inline)) {
     return v_lane[sub][half] + dt * 4096;      // v_swz(dt*32 + ql) == v_swz(ql)
   };
+  // PV16: A fragment of tile dt = row 16 dt + (lane & 15), the 8 kv of block lane >> 4 (one b128)
+  int v16_lane[2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+    v16_lane[sub] = C::K_BYTES + (lane & 15) * 128 + (((sub * 4 + (lane >> 4)) ^ v_swz(lane & 15)) * 16);
 
   f32x16 o[NS][DT];
+  f32x4 o16[NS][2][DT16];                               // PV16: [stream][16-query half][tile]
+  bf16x8 vf16[DT16];
   float m_run[NS], l_run[NS];
   const int ntiles = p.N / 64;
   const int TU = ntiles * C::UT;
@@ -302,6 +319,11 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
     qf[g][KS_P] = x.v;
   };
   auto read_vf = [&](const char* st, int sub) __attribute__((always_inline)) {
+    if constexpr (PV16) {
+#pragma unroll
+      for (int dt = 0; dt < DT16; ++dt) vf16[dt] = *reinterpret_cast<const bf16x8*>(st + v16_lane[sub] + dt * 2048);
+      return;
+    }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       vf[dt][0] = *reinterpret_cast<const bf16x8*>(st + v_addr(sub, dt, 0));
@@ -337,7 +359,13 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
       for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[a][t][r] = 0.f;
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+        for (int t = 0; t < DT16; ++t) o16[a][gq][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int t = 0; t < DT16; ++t) vf16[t] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     if (FOLD) {
 #pragma unroll
       for (int g = 0; g < QG; ++g) set_q_shift(g, 0.f);
@@ -381,7 +409,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
     auto mfma_hi = [&](const bf16x8& x, const bf16x8& y, f32x16& acc) __attribute__((always_inline)) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
     };
-    constexpr int NPV = 2 * DT;
+    constexpr int NPV = PV16 ? 2 * DT16 : 2 * DT;
     // with a single stream the P.V of unit U-1 (formed against the old maximum) has to be
     // accumulated before the rescale for unit U
     if (NS == 1) {
@@ -408,10 +436,19 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
           m_run[A] = m_new;
         }
         l_run[A] *= alpha;
+        if constexpr (PV16) {      // this lane's accumulators belong to queries 16 g' + (lane & 15): their owners' factors
+#pragma unroll
+          for (int gq = 0; gq < 2; ++gq) {
+            const float al = __shfl(alpha, (lane & 32) + 16 * gq + (lane & 15), 64);
+#pragma unroll
+            for (int dt = 0; dt < DT16; ++dt) o16[A][gq][dt] *= al;
+          }
+        } else {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[A][dt][r] *= alpha;
+        }
       }
     }
     const bool has2 = !GUARD || U + 2 < TU;
@@ -455,7 +492,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
         }
       } else {
         const int i = sl - qk_before;                      // index among the P.V MFMAs
-        mfma_hi(vf[i % DT][i / DT], pf_prev[i / DT], o[AP][i % DT]);
+        if constexpr (PV16)
+          o16[AP][i / DT16][i % DT16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf16[i % DT16], pf_prev[i / DT16], o16[AP][i / DT16][i % DT16], 0, 0, 0);
+        else
+          mfma_hi(vf[i % DT][i / DT], pf_prev[i / DT], o[AP][i % DT]);
         // V^T fragments of unit U (kept for the pair when QG == 2) once the last P.V is issued
         if (i == NPVS - 1 && (QG == 1 || (JJ & 1) == 0)) read_vf(st_cur, SUB);
       }
@@ -464,6 +504,14 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
     }
     if (NS == 1 && (QG == 1 || (JJ & 1) == 0)) read_vf(st_cur, SUB);
     if (!ONES) l_run[A] += ls;
+    if constexpr (PV16) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(pk[0].u[w], pk[1].u[w], false, false);
+        pk[0].u[w] = sw[0];
+        pk[1].u[w] = sw[1];
+      }
+    }
     pf_cur[0] = pk[0].v;
     pf_cur[1] = pk[1].v;
     // keep the exp/pack work HERE: its only consumer is the P.V in the next block, and LLVM
@@ -542,16 +590,28 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
     {
       bf16x8 (&pf_last)[2] = pfb;    // the last unit is odd: its block packed into pfb
       constexpr int AL = NS - 1;
+      if constexpr (PV16) {
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+          for (int dt = 0; dt < DT16; ++dt)
+            o16[AL][gq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf16[dt], pf_last[gq], o16[AL][gq][dt], 0, 0, 0);
+      } else {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) o[AL][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][0], pf_last[0], o[AL][dt], 0, 0, 0);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) o[AL][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][1], pf_last[1], o[AL][dt], 0, 0, 0);
+      }
     }
   };
 
   constexpr int dl = D - (DT - 1) * 32;            // pad row D inside the last tile (ONES)
   constexpr int r1 = (dl & 3) + 4 * (dl >> 3);
   constexpr int h1 = (dl >> 2) & 1;
+  // PV16: row D of O^T is row D % 16 of tile D / 16 = register D % 4 of the lanes with lane >> 4 == (D % 16) / 4
+  auto denom16 = [&](int a, int gq) __attribute__((always_inline)) {
+    return __shfl(o16[a][gq][D / 16][D % 4], 16 * ((D % 16) / 4) + (lane & 15), 64);
+  };
   auto denom = [&](int a) __attribute__((always_inline)) {
     if (ONES) return __shfl(o[a][DT - 1][ONES ? r1 : 0], ql + 32 * h1, 64);
     return l_run[a] + __shfl_xor(l_run[a], 32, 64);
@@ -581,12 +641,36 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
       pass(true_type{});
       bool bad = false;
 #pragma unroll
-      for (int a = 0; a < NS; ++a) bad |= !(denom(a) < 0x1p60f);
+      for (int a = 0; a < NS; ++a) {
+        if constexpr (PV16) bad |= !(denom16(a, 0) < 0x1p60f) || !(denom16(a, 1) < 0x1p60f);
+        else bad |= !(denom(a) < 0x1p60f);
+      }
       redo = __syncthreads_or(bad ? 1 : 0);        // (also: nobody reads the ring any more)
     }
     if (redo) pass(false_type{});
   }
-  if (QG == 2) {
+  if constexpr (PV16) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int gq = 0; gq < 2; ++gq) {
+        const float inv = 1.0f / denom16(g, gq);
+        const int q_row = qblk * (128 * QG) + wave * (32 * QG) + g * 32 + gq * 16 + (lane & 15);
+        if (q_row < p.N) {
+          bf16_t* op = p.out + ((long)b * p.N + q_row) * p.ldo + h * D;
+#pragma unroll
+          for (int dt = 0; dt < DT16; ++dt) {
+            const int d0 = dt * 16 + 4 * (lane >> 4);
+            if (d0 < D) {
+              uint2 w;
+              w.x = pack_bf16x2(o16[g][gq][dt][0] * inv, o16[g][gq][dt][1] * inv);
+              w.y = pack_bf16x2(o16[g][gq][dt][2] * inv, o16[g][gq][dt][3] * inv);
+              *reinterpret_cast<uint2*>(op + d0) = w;
+            }
+          }
+        }
+      }
+  } else if (QG == 2) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) write_out(o[g], 1.0f / denom(g), q_base + g * 32);
   } else {
