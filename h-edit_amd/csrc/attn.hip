@@ -911,7 +911,130 @@ int launch_cross(const CrossAttnParams& p, hipStream_t st) {
   return HEDIT_OK;
 }
 
+// ============================================================================ materialised probabilities
+// The slow path behind hedit_unet_set_attn_hook: a controller written in the host language sees (and may rewrite) the
+// attention probabilities the way the reference's processor hands them over (ptp_utils.py:98-106: `attention_probs`
+// [batch * heads][queries][keys], softmax done, before the product with V).  Two plain kernels, fp32 probabilities in HBM,
+// no MFMA: this path exists for protocol coverage, the edits that matter run inside the fused kernels above.
+//
+// probs: one block = 16 queries of one (batch row, head).  Scores in log2 units (Q is pre-scaled), softmax over the keys
+// in three passes over the block's own 16 rows of the output.
+__global__ __launch_bounds__(256) void attn_probs_kernel(AttnProbsParams p) {
+  __shared__ float qs[16][168];
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh % p.heads;
+  const int q0 = blockIdx.x * 16, tid = threadIdx.x;
+  for (int i = tid; i < 16 * p.d; i += 256) {
+    const int r = i / p.d, c = i % p.d;
+    const int q = q0 + r;
+    qs[r][c] = q < p.N ? bf16_to_f32(p.q[((long)b * p.N + q) * p.ldq + h * p.d + c]) : 0.f;
+  }
+  __syncthreads();
+  float* out = p.probs + ((long)bh * p.N + q0) * p.M;
+  const int rows = min(16, p.N - q0);
+  for (int m = tid; m < p.M; m += 256) {
+    const bf16_t* kp = p.k + ((long)b * p.kstride + m) * p.ldk + h * p.d;
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int c = 0; c < p.d; c += 8) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(kp + c);
+      const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float kv = __uint_as_float((j & 1) ? (w[j >> 1] & 0xffff0000u) : (w[j >> 1] << 16));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += qs[r][c + j] * kv;
+      }
+    }
+    for (int r = 0; r < rows; ++r) out[(long)r * p.M + m] = acc[r];
+  }
+  __syncthreads();
+  // softmax of row r by wave r % 4 (base 2: the scores carry log2 e)
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int r = wave; r < rows; r += 4) {
+    float* row = out + (long)r * p.M;
+    float mx = -3.0e38f;
+    for (int m = lane; m < p.M; m += 64) mx = fmaxf(mx, row[m]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int m = lane; m < p.M; m += 64) {
+      const float e = exp2f(row[m] - mx);
+      row[m] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float inv = 1.0f / sum;
+    for (int m = lane; m < p.M; m += 64) row[m] *= inv;
+  }
+}
+
+// apply: out[q][h*d + dd] = sum_m probs[bh][q][m] * V^T[h*d + dd][b*kstride + m]; one block = 16 queries of one (b, h),
+// the keys in chunks of 64 through LDS.
+__global__ __launch_bounds__(256) void attn_apply_kernel(AttnProbsParams p) {
+  constexpr int CH = 64;
+  __shared__ float ps[16][CH + 1];
+  __shared__ float vs[160][CH + 1];
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh % p.heads;
+  const int q0 = blockIdx.x * 16, tid = threadIdx.x;
+  const int rows = min(16, p.N - q0), d = p.d;
+  const int nout = 16 * d;                     // (query, channel) pairs of the block: thread t owns t, t + 256, ...
+  float acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+  const float* pin = p.probs + ((long)bh * p.N + q0) * p.M;
+  for (int m0 = 0; m0 < p.M; m0 += CH) {
+    const int mc = min(CH, p.M - m0);
+    for (int i = tid; i < 16 * CH; i += 256) {
+      const int r = i / CH, c = i % CH;
+      ps[r][c] = (r < rows && c < mc) ? pin[(long)r * p.M + m0 + c] : 0.f;
+    }
+    for (int i = tid; i < d * CH; i += 256) {
+      const int r = i / CH, c = i % CH;
+      vs[r][c] = c < mc ? bf16_to_f32(p.vt[(long)(h * d + r) * p.ldvt + (long)b * p.kstride + m0 + c]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int o = tid + i * 256;
+      if (o < nout) {
+        const int r = o / d, c = o % d;
+        float a = acc[i];
+        for (int m = 0; m < CH; ++m) a += ps[r][m] * vs[c][m];
+        acc[i] = a;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const int o = tid + i * 256;
+    if (o < nout) {
+      const int r = o / d, c = o % d;
+      if (r < rows) p.out[((long)b * p.N + q0 + r) * p.ldo + h * d + c] = f32_to_bf16(acc[i]);
+    }
+  }
+}
+
 }  // namespace
+
+int attn_probs_launch(const AttnProbsParams& p, hipStream_t st) {
+  ARG_CHECK(p.d % 8 == 0 && p.d <= 160, "attn_probs: head dim must be a multiple of 8, at most 160");
+  ARG_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0, "attn_probs: strides");
+  ARG_CHECK(p.M > 0 && p.N > 0 && p.M <= p.kstride, "attn_probs: extents");
+  hipLaunchKernelGGL(attn_probs_kernel, dim3(cdiv(p.N, 16), p.B * p.heads), dim3(256), 0, st, p);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+int attn_apply_launch(const AttnProbsParams& p, hipStream_t st) {
+  ARG_CHECK(p.d % 8 == 0 && p.d <= 160, "attn_apply: head dim must be a multiple of 8, at most 160");
+  ARG_CHECK(p.M > 0 && p.N > 0 && p.M <= p.kstride, "attn_apply: extents");
+  hipLaunchKernelGGL(attn_apply_kernel, dim3(cdiv(p.N, 16), p.B * p.heads), dim3(256), 0, st, p);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
 
 int self_attn_launch(const SelfAttnParams& p, hipStream_t st) {
   ARG_CHECK(p.N % 64 == 0, "self_attn: N must be a multiple of 64");

@@ -113,7 +113,15 @@ int hedit_step_style(const float* e_u_src, const float* e_c_src, const float* e_
 int hedit_local_blend(float* const* h_maps, int n_maps, int heads, const float* alpha_layers,
                       const int32_t* enabled, float* xt, int n_img, int C, int H, int W, float th, void* stream) try {
   ARG_CHECK(h_maps && alpha_layers && xt, "local_blend args");
-  return local_blend_launch(const_cast<const float* const*>(h_maps), n_maps, heads, alpha_layers, enabled, xt, n_img, C, H, W, th, S(stream));
+  return local_blend_launch(const_cast<const float* const*>(h_maps), n_maps, heads, alpha_layers, nullptr, enabled, xt, n_img, C, H, W, th,
+                            0.f, S(stream));
+} catch (...) { return hedit_abi_catch(); }
+
+int hedit_local_blend_sub(float* const* h_maps, int n_maps, int heads, const float* alpha_layers, const float* substruct_layers,
+                          const int32_t* enabled, float* xt, int n_img, int C, int H, int W, float th, float th_sub, void* stream) try {
+  ARG_CHECK(h_maps && alpha_layers && substruct_layers && xt, "local_blend_sub args");
+  return local_blend_launch(const_cast<const float* const*>(h_maps), n_maps, heads, alpha_layers, substruct_layers, enabled, xt, n_img, C,
+                            H, W, th, th_sub, S(stream));
 } catch (...) { return hedit_abi_catch(); }
 
 int hedit_axis_mix(const float* in, float* out, const int32_t* idx, const float* val, int nnz, int64_t outer, int n_in, int n_out, int inner,
@@ -316,6 +324,27 @@ int hedit_k_cross_attn(const void* q, int ldq, const void* k, int ldk, const voi
   p.singles = plan->singles; p.n_single = plan->n_single;
   p.store = store;
   return cross_attn_launch(p, S(stream));
+} catch (...) { return hedit_abi_catch(); }
+
+int hedit_k_attn_probs(const void* q, int ldq, const void* k, int ldk, float* probs, int B, int N, int M, int kstride,
+                       int heads, int d, void* stream) try {
+  ARG_CHECK(q && k && probs, "attn_probs args");
+  AttnProbsParams p{};
+  p.q = reinterpret_cast<const bf16_t*>(q); p.ldq = ldq;
+  p.k = reinterpret_cast<const bf16_t*>(k); p.ldk = ldk;
+  p.probs = probs; p.B = B; p.N = N; p.M = M; p.kstride = kstride; p.heads = heads; p.d = d;
+  return attn_probs_launch(p, S(stream));
+} catch (...) { return hedit_abi_catch(); }
+
+int hedit_k_attn_apply(const float* probs, const void* vt, int64_t ldvt, void* out, int ldo, int B, int N, int M,
+                       int kstride, int heads, int d, void* stream) try {
+  ARG_CHECK(probs && vt && out, "attn_apply args");
+  AttnProbsParams p{};
+  p.probs = const_cast<float*>(probs);
+  p.vt = reinterpret_cast<const bf16_t*>(vt); p.ldvt = (long)ldvt;
+  p.out = reinterpret_cast<bf16_t*>(out); p.ldo = ldo;
+  p.B = B; p.N = N; p.M = M; p.kstride = kstride; p.heads = heads; p.d = d;
+  return attn_apply_launch(p, S(stream));
 } catch (...) { return hedit_abi_catch(); }
 
 int hedit_k_pack_conv3x3(const float* w, void* out, int O, int I, void* stream) try {

@@ -186,6 +186,20 @@ struct CrossAttnParams {
 };
 int cross_attn_launch(const CrossAttnParams& p, hipStream_t st);
 
+// materialised probabilities (the host-language controller hook, hedit_unet_set_attn_hook): probs = softmax(Q K^T) as
+// fp32 [B*heads][N][M] (reference layout: ptp_utils.py:98), then out = probs . V.  kstride = rows per batch item of K / V^T
+// (N for self-attention, HEDIT_CTXP for the context), M = the keys that count (N or 77).
+struct AttnProbsParams {
+  const bf16_t* q; int ldq;     // [B*N][ldq] pre-scaled by scale*log2(e)
+  const bf16_t* k; int ldk;     // [B*kstride][ldk]
+  const bf16_t* vt; long ldvt;  // [heads*d][B*kstride]
+  float* probs;                 // [B*heads][N][M]
+  bf16_t* out; int ldo;         // [B*N][ldo]
+  int B, N, M, kstride, heads, d;
+};
+int attn_probs_launch(const AttnProbsParams& p, hipStream_t st);
+int attn_apply_launch(const AttnProbsParams& p, hipStream_t st);
+
 // ---------------------------------------------------------------- step.hip
 struct StepCoef {
   float sqrt_ab_t, sqrt_1m_ab_t;     // of the current timestep t
@@ -215,8 +229,8 @@ int step_style_launch(const float* e_u_src, const float* e_c_src, const float* e
 // out[o][i][x] = sum_j val[i][j] in[o][idx[i][j]][x] over a [outer][n_in][inner] fp32 tensor (tables [n_out][nnz])
 int axis_mix_launch(const float* in, float* out, const int* idx, const float* val, int nnz, long outer, int n_in, int n_out, int inner,
                     hipStream_t st);
-int local_blend_launch(const float* const* maps, int n_maps, int heads, const float* alpha_layers,
-                       const int* enabled, float* xt, int n_img, int C, int H, int W, float th, hipStream_t st);
+int local_blend_launch(const float* const* maps, int n_maps, int heads, const float* alpha_layers, const float* alpha_sub,
+                       const int* enabled, float* xt, int n_img, int C, int H, int W, float th, float th_sub, hipStream_t st);
 
 // ---------------------------------------------------------------- pnet.hip ("precise" fp32-quality building blocks)
 // ops of the fused element-wise stage that produces a split-bf16 GEMM operand (and of act_launch)

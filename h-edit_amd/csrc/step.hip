@@ -120,17 +120,20 @@ struct BlendMaps { const float* p[8]; };
 
 // LocalBlend: word-selected mean of the 16x16 cross maps -> 3x3 max-pool -> nearest upsample ->
 // /max -> threshold -> OR(src, tar) -> x_e = x_o + mask (x_e - x_o).  One workgroup per image.
+// alpha_sub (optional): the substruct_words layers of LocalBlend (ptp_classes.py:28-38,64-68) -- a second word mask, not
+// pooled, thresholded with th_sub, whose complement is multiplied into the blend mask.
 __global__ __launch_bounds__(256) void local_blend_kernel(BlendMaps maps, int n_maps, int heads, const float* __restrict__ alpha,
-                                                          const int* __restrict__ enabled, float* __restrict__ xt, int n_img,
-                                                          int C, int H, int W, float th) {
+                                                          const float* __restrict__ alpha_sub, const int* __restrict__ enabled,
+                                                          float* __restrict__ xt, int n_img, int C, int H, int W, float th,
+                                                          float th_sub) {
   __shared__ float m[2][256];
   __shared__ float pooled[2][256];
+  __shared__ float sub[2][256];
   __shared__ float red[4];
-  __shared__ float mxs[2];
+  __shared__ float mxs[2], mxsub[2];
   const int img = blockIdx.x, p = threadIdx.x;
   if (enabled && !enabled[img]) return;     // this image has no LocalBlend
-  const float* al = alpha + (long)img * 2 * HEDIT_MAXW;
-  for (int s = 0; s < 2; ++s) {
+  auto word_mean = [&](const float* al, int s) {
     float acc = 0.f;
     for (int l = 0; l < n_maps; ++l) {
       const float* base = maps.p[l] + (((long)img * 2 + s) * heads) * 256 * HEDIT_MAXW;
@@ -140,7 +143,11 @@ __global__ __launch_bounds__(256) void local_blend_kernel(BlendMaps maps, int n_
         for (int h = 0; h < heads; ++h) acc += base[((long)h * 256 + p) * HEDIT_MAXW + n] * a;
       }
     }
-    m[s][p] = acc / (float)(n_maps * heads);
+    return acc / (float)(n_maps * heads);
+  };
+  for (int s = 0; s < 2; ++s) {
+    m[s][p] = word_mean(alpha + (long)img * 2 * HEDIT_MAXW, s);
+    sub[s][p] = alpha_sub ? word_mean(alpha_sub + (long)img * 2 * HEDIT_MAXW, s) : 0.f;
   }
   __syncthreads();
   const int py = p >> 4, px = p & 15;
@@ -160,13 +167,23 @@ __global__ __launch_bounds__(256) void local_blend_kernel(BlendMaps maps, int n_
     __syncthreads();
     if (p == 0) mxs[s] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
+    if (alpha_sub) {
+      v = wave_max(sub[s][p]);
+      if ((p & 63) == 0) red[p >> 6] = v;
+      __syncthreads();
+      if (p == 0) mxsub[s] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      __syncthreads();
+    }
   }
   float* xo = xt + (long)img * C * H * W;            // xt is [2][n_img][C][H][W]
   float* xe = xt + ((long)n_img + img) * C * H * W;
   for (int i = p; i < H * W; i += 256) {
     const int y = i / W, x = i - y * W;
     const int sp = ((y * 16) / H) * 16 + (x * 16) / W;
-    const bool on = (pooled[0][sp] / mxs[0] > th) || (pooled[1][sp] / mxs[1] > th);
+    bool on = (pooled[0][sp] / mxs[0] > th) || (pooled[1][sp] / mxs[1] > th);
+    // (an all-zero layer -- no substruct words for this prompt -- is 0 / 0 in the reference: NaN > th is false)
+    if (alpha_sub)
+      on = on && !((mxsub[0] > 0.f && sub[0][sp] / mxsub[0] > th_sub) || (mxsub[1] > 0.f && sub[1][sp] / mxsub[1] > th_sub));
     if (!on) {
       for (int ch = 0; ch < C; ++ch) xe[(long)ch * H * W + i] = xo[(long)ch * H * W + i];
     } else {
@@ -267,12 +284,13 @@ int step_update_launch(const float* e_u_src, const float* e_c_src, const float* 
   return HEDIT_OK;
 }
 
-int local_blend_launch(const float* const* maps, int n_maps, int heads, const float* alpha_layers,
-                       const int* enabled, float* xt, int n_img, int C, int H, int W, float th, hipStream_t st) {
+int local_blend_launch(const float* const* maps, int n_maps, int heads, const float* alpha_layers, const float* alpha_sub,
+                       const int* enabled, float* xt, int n_img, int C, int H, int W, float th, float th_sub, hipStream_t st) {
   ARG_CHECK(n_maps >= 1 && n_maps <= 8, "local_blend: 1..8 maps");
   BlendMaps bm;
   for (int i = 0; i < 8; ++i) bm.p[i] = i < n_maps ? maps[i] : nullptr;
-  hipLaunchKernelGGL(local_blend_kernel, dim3(n_img), dim3(256), 0, st, bm, n_maps, heads, alpha_layers, enabled, xt, n_img, C, H, W, th);
+  hipLaunchKernelGGL(local_blend_kernel, dim3(n_img), dim3(256), 0, st, bm, n_maps, heads, alpha_layers, alpha_sub, enabled, xt, n_img, C, H,
+                     W, th, th_sub);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }

@@ -86,6 +86,10 @@ struct hedit_unet {
   struct ProfRec { int kind; double flops, bytes; int e0, e1; int m = 0, n = 0, k = 0, tag = 0; };
   std::vector<ProfRec> prof_recs;
   size_t prof_next = 0;
+  // host-language attention controller (hedit_unet_set_attn_hook): when set, every attention layer materialises its
+  // probabilities, hands them to the hook and multiplies whatever comes back with V (attn.hip, slow path)
+  hedit_attn_hook_fn hook = nullptr;
+  void* hook_user = nullptr;
 };
 
 namespace {
@@ -239,6 +243,8 @@ struct Fwd {
   int store_idx = 0;
   int tblock = 0;            // transformer blocks visited so far in this call (MasaCtrl / PnP layer gates)
   int rblock = 0;            // ResNet blocks visited so far (PnP feature injection)
+  int place = 0;             // 0 down, 1 mid, 2 up: where the transformer block being executed sits (the hook's argument)
+  int hook_layer = 0;        // attention layers handed to the hook so far in this call
   bool dry() const { return ar.dry; }
 };
 
@@ -381,6 +387,28 @@ int resblock(Fwd& f, const Res& r, const bf16_t* x, int H, int W, bf16_t** out, 
   return HEDIT_OK;
 }
 
+// One attention layer through the host-language controller: probabilities to HBM, the hook (which may rewrite them in
+// place, on the launch stream), then probabilities . V.  Reference: ptp_utils.py:98-106.
+int hooked_attention(Fwd& f, const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* vt, long ldvt, bf16_t* out, int ldo,
+                     int N, int Mk, int kstride, int heads, int d, int is_cross) {
+  AttnProbsParams ap{};
+  ap.q = q; ap.ldq = ldq; ap.k = k; ap.ldk = ldk; ap.vt = vt; ap.ldvt = ldvt; ap.out = out; ap.ldo = ldo;
+  ap.B = f.B; ap.N = N; ap.M = Mk; ap.kstride = kstride; ap.heads = heads; ap.d = d;
+  TRY(aalloc(f, &ap.probs, (size_t)f.B * heads * N * Mk));
+  const int layer = f.hook_layer++;
+  if (!f.dry()) {
+    TRY(attn_probs_launch(ap, f.st));
+    const int rc = f.h->hook(f.h->hook_user, ap.probs, f.B * heads, N, Mk, is_cross, f.place, layer, f.st);
+    if (rc != 0) {
+      hedit_set_error("unet: the attention hook failed at layer " + std::to_string(layer) + " (code " + std::to_string(rc) + ")");
+      return HEDIT_ERR_ARG;
+    }
+    TRY(attn_apply_launch(ap, f.st));
+  }
+  f.ar.free(ap.probs);
+  return HEDIT_OK;
+}
+
 // x [M][C] -> *out [M][C] (allocated here; x is NOT freed)
 int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** out, bf16_t* dst = nullptr, int ldd = 0) {
   const int C = a.C, N = H * W, B = f.B, heads = f.h->cfg.heads, d = C / heads;
@@ -438,8 +466,12 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
                     ? pl->qk_src : nullptr;
     sp.kv_src = (pl && pl->kv_src && f.tblock >= pl->kv_first_block) ? pl->kv_src : nullptr;
     ++f.tblock;
-    ProfScope ps(f, PK_SELF_ATTN, 4.0 * B * (double)N * N * C, 8.0 * M * C);      // q, k, v^T read, out written
-    RUN(f, self_attn_launch(sp, f.st));
+    if (f.h->hook) {
+      TRY(hooked_attention(f, sp.q, sp.ldq, sp.k, sp.ldk, sp.vt, sp.ldvt, ao, C, N, N, N, heads, d, 0));
+    } else {
+      ProfScope ps(f, PK_SELF_ATTN, 4.0 * B * (double)N * N * C, 8.0 * M * C);      // q, k, v^T read, out written
+      RUN(f, self_attn_launch(sp, f.st));
+    }
   }
   f.ar.free(qk);
   f.ar.free(vt);
@@ -484,8 +516,12 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
       cp.n_pairs = 0; cp.singles = f.h->iota; cp.n_single = B;
     }
     if (stored_layer) f.store_idx++;
-    ProfScope ps(f, PK_CROSS_ATTN, 4.0 * B * (double)N * HEDIT_MAXW * C, 4.0 * M * C + 4.0 * MC * C);
-    RUN(f, cross_attn_launch(cp, f.st));
+    if (f.h->hook) {
+      TRY(hooked_attention(f, cp.q, cp.ldq, cp.k, cp.ldk, cp.vt, cp.ldvt, ao, C, N, HEDIT_MAXW, HEDIT_CTXP, heads, d, 1));
+    } else {
+      ProfScope ps(f, PK_CROSS_ATTN, 4.0 * B * (double)N * HEDIT_MAXW * C, 4.0 * M * C + 4.0 * MC * C);
+      RUN(f, cross_attn_launch(cp, f.st));
+    }
   }
   f.ar.free(q2);
   f.ar.free(k2);
@@ -598,6 +634,7 @@ int forward_impl(hedit_unet* h, const float* x, float t, const float* ctx, int B
       cur = y;
       if (blk.has_attn) {
         bf16_t* z;
+        f.place = 0;
         TRY(transformer(f, blk.attn[j], cur, H, W, &z));
         f.ar.free(cur);
         cur = z;
@@ -618,6 +655,7 @@ int forward_impl(hedit_unet* h, const float* x, float t, const float* ctx, int B
   {
     bf16_t *y, *z, *w;
     TRY(resblock(f, h->mid_res[0], cur, H, W, &y));
+    f.place = 1;
     TRY(transformer(f, h->mid_attn, y, H, W, &z));
     f.ar.free(y);
     TRY(resblock(f, h->mid_res[1], z, H, W, &w));
@@ -661,6 +699,7 @@ int forward_impl(hedit_unet* h, const float* x, float t, const float* ctx, int B
         TRY(resblock(f, blk.res[j], cat, H, W, &y));
         f.ar.free(cat);
         bf16_t* z;
+        f.place = 2;
         TRY(transformer(f, blk.attn[j], y, H, W, &z, dst, ldd));
         f.ar.free(y);
         cur = z;
@@ -924,6 +963,7 @@ int hedit_unet_forward(hedit_unet* h, const float* x, float t, const float* ctx,
     hedit_set_error("UNet has " + std::to_string(hedit_unet_missing(h)) + " unloaded parameters");
     return HEDIT_ERR_STATE;
   }
+  ARG_CHECK(!(h->hook && plan && plan->mode > 0), "an attention hook excludes the in-kernel edits of a plan (pass plan = NULL)");
   if (plan && plan->mode > 0) {
     ARG_CHECK(plan->n_pairs >= 0 && plan->n_pairs + plan->n_single > 0, "plan rows");
     ARG_CHECK(plan->n_pairs == 0 || (plan->pair_src && plan->pair_tar && plan->mixT && plan->bvec), "plan tables");
@@ -1014,6 +1054,13 @@ static void store_layers(const hedit_unet* h, int height, int width, std::vector
     if (i != c.n_levels - 1) { H *= 2; W *= 2; }
   }
 }
+
+int hedit_unet_set_attn_hook(hedit_unet* h, hedit_attn_hook_fn fn, void* user) try {
+  ARG_CHECK(h, "unet handle");
+  h->hook = fn;
+  h->hook_user = fn ? user : nullptr;
+  return HEDIT_OK;
+} catch (...) { return hedit_abi_catch(); }
 
 int hedit_unet_num_store_layers(const hedit_unet* h, int height, int width) try {
   if (!h) return 0;

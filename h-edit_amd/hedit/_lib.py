@@ -63,6 +63,7 @@ _SIGS = {
     "hedit_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int,
                                      C.c_int, C.POINTER(P2PPlan), C.c_void_p, C.c_void_p, C.c_size_t,
                                      C.c_void_p]),
+    "hedit_unet_set_attn_hook": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hedit_unet_num_store_layers": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "hedit_unet_store_layer_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                               C.POINTER(C.c_int)]),
@@ -85,6 +86,8 @@ _SIGS = {
                                    C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "hedit_local_blend": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "hedit_local_blend_sub": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "hedit_ddpm_create": (C.c_int, [C.POINTER(DdpmCfg), C.POINTER(C.c_void_p)]),
     "hedit_ddpm_destroy": (None, [C.c_void_p]),
     "hedit_ddpm_num_params": (C.c_int, [C.c_void_p]),
@@ -190,6 +193,10 @@ _SIGS = {
     "hedit_k_cross_attn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(P2PPlan), C.c_void_p,
                                      C.c_void_p]),
+    "hedit_k_attn_probs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_void_p]),
+    "hedit_k_attn_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_void_p]),
     "hedit_k_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "hedit_k_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 }

@@ -209,8 +209,20 @@ class HEditEngine:
         x_prev = torch.empty_like(xt)
         off = None
 
+        foreign = controller is not None and not hasattr(controller, "_plan")
+        if foreign:
+            # a host-language controller (reference protocol, ptp_classes.py:91-108) sees the reference's batch: one image,
+            # rows [null, null, src, tar] -- it slices attn[h // 2:] and reshapes by its own batch_size
+            if n != 1 or fuse_src_pass or reuse_orig_eps:
+                raise ValueError("a foreign controller runs one image at a time, without fuse_src_pass / reuse_orig_eps "
+                                 "(it sees the reference's 4-row batch)")
+            if not callable(controller):
+                raise TypeError("a foreign controller must be callable as controller(attn, is_cross, place_in_unet, save_attn)")
+
         def p2p_pass(x_in, t, save):
             rows = x_in.shape[0]
+            if foreign:
+                return self.unet.forward_hooked(x_in, t, ctx_edit, controller, save)
             # controller=None: the reference's processors then leave every attention map alone (ptp_utils.py:98-101)
             plan = controller._plan(self.unet, rows, x_in.shape[2], x_in.shape[3], save) if controller is not None else None
             e = self.unet.forward_raw(x_in, t, ctx_edit5 if rows == 5 * n else ctx_edit, plan)

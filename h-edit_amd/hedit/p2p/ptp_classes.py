@@ -37,8 +37,6 @@ WPAD = 96
 class LocalBlend:
     def __init__(self, prompts, num_steps, words, substruct_words=None, start_blend=0.2, th=(.3, .3),
                  tokenizer=None, device=None):
-        if substruct_words is not None:
-            raise NotImplementedError("substruct_words is unused by the h-Edit drivers")
         self.max_num_words = MAX_NUM_WORDS
         alpha_layers = torch.zeros(len(prompts), 1, 1, 1, 1, self.max_num_words)
         for i, (prompt, words_) in enumerate(zip(prompts, words)):
@@ -48,6 +46,15 @@ class LocalBlend:
                 ind = ptp_utils.get_word_inds(prompt, word, tokenizer)
                 alpha_layers[i, :, :, :, :, ind] = 1
         self.substruct_layers = None
+        if substruct_words is not None:          # ptp_classes.py:28-38: a second word mask, cut out of the blend mask
+            sub = torch.zeros(len(prompts), 1, 1, 1, 1, self.max_num_words)
+            for i, (prompt, words_) in enumerate(zip(prompts, substruct_words)):
+                if isinstance(words_, str):
+                    words_ = [words_]
+                for word in words_:
+                    ind = ptp_utils.get_word_inds(prompt, word, tokenizer)
+                    sub[i, :, :, :, :, ind] = 1
+            self.substruct_layers = sub.to(device) if device is not None else sub
         self.alpha_layers = alpha_layers.to(device) if device is not None else alpha_layers
         self.start_blend = int(start_blend * num_steps)
         self.counter = 0
@@ -72,24 +79,36 @@ def _blend_launch(x_t, maps, blends, n_img):
                              "ptp_classes.py:59-62)")
     heads = maps[0].numel() // (n_img * 2 * 256 * MAX_NUM_WORDS)
     alpha = torch.zeros(n_img, 2, MAX_NUM_WORDS)
+    sub = torch.zeros(n_img, 2, MAX_NUM_WORDS)
     enabled = torch.zeros(n_img, dtype=torch.int32)
     th = None
+    has_sub = False
     for i, lb in enumerate(blends):
         if lb is not None:
             alpha[i] = lb.alpha_layers.reshape(2, MAX_NUM_WORDS).cpu()
+            if lb.substruct_layers is not None:
+                sub[i] = lb.substruct_layers.reshape(2, MAX_NUM_WORDS).cpu()
+                has_sub = True
             enabled[i] = 1
-            if th is not None and float(lb.th[0]) != th:
-                raise ValueError("LocalBlend thresholds differ inside one lock-step batch (the blend kernel takes one)")
-            th = float(lb.th[0])
-    th = 0.3 if th is None else th
+            if th is not None and (float(lb.th[0]), float(lb.th[1])) != th:
+                raise ValueError("LocalBlend thresholds differ inside one lock-step batch (the blend kernel takes one pair)")
+            th = (float(lb.th[0]), float(lb.th[1]))
+    th = (0.3, 0.3) if th is None else th
     alpha = alpha.to(x_t.device)
     enabled = enabled.to(x_t.device)
     arr = (C.c_void_p * len(maps))(*[m.data_ptr() for m in maps])
     _, Cc, H, W = x_t.shape
-    _lib.check(lib.hedit_local_blend(arr, len(maps), heads, _lib.ptr(alpha), _lib.ptr(enabled),
-                                     _lib.ptr(x_t), n_img, Cc, H, W, C.c_float(th), _lib.cur_stream()))
-    # alpha / enabled are consumed by a stream-ordered kernel: keep them alive on the tensor
-    x_t._hedit_keep = (alpha, enabled)
+    if has_sub:
+        # images of the batch without substruct words carry an all-zero layer: their mean map is 0, 0 / 0 is never > th
+        sub = sub.to(x_t.device)
+        _lib.check(lib.hedit_local_blend_sub(arr, len(maps), heads, _lib.ptr(alpha), _lib.ptr(sub), _lib.ptr(enabled),
+                                             _lib.ptr(x_t), n_img, Cc, H, W, C.c_float(th[0]), C.c_float(th[1]),
+                                             _lib.cur_stream()))
+    else:
+        _lib.check(lib.hedit_local_blend(arr, len(maps), heads, _lib.ptr(alpha), _lib.ptr(enabled),
+                                         _lib.ptr(x_t), n_img, Cc, H, W, C.c_float(th[0]), _lib.cur_stream()))
+    # alpha / sub / enabled are consumed by a stream-ordered kernel: keep them alive on the tensor
+    x_t._hedit_keep = (alpha, sub, enabled)
 
 
 class AttentionControl(abc.ABC):

@@ -4,7 +4,9 @@ Mirrors the parts of text-guided/p2p/ptp_utils.py that are on the h-Edit path:
 P2PCrossAttnProcessor (:31-122), register_attention_control (:277-295), get_word_inds (:297-315),
 update_alpha_time_word (:318-328), get_time_words_attention_alpha (:331-349).  The attention body
 of the processor is NOT here: it runs inside the HIP kernels (csrc/attn.hip); the processor object
-only tells the UNet which controller drives the edit and where the layer sits.
+only tells the UNet which controller drives the edit and where the layer sits.  A controller that is not
+one of hedit's (any callable with the reference's signature) is called through the executor's hook on
+materialised probabilities (hedit/unet.py::forward_hooked).
 """
 import torch
 
@@ -17,8 +19,9 @@ class P2PCrossAttnProcessor:
         self.place_in_unet = place_in_unet
 
     def __call__(self, *a, **k):
-        raise RuntimeError("P2PCrossAttnProcessor is executed inside the HIP attention kernels; "
-                           "it cannot be called from Python")
+        raise RuntimeError("the attention body of P2PCrossAttnProcessor is the HIP kernels (fused), or the executor's hook "
+                           "path for a host-language controller (hedit.unet.UNet2DConditionModel.forward_hooked); the "
+                           "processor object itself is a marker and cannot be called")
 
 
 def register_attention_control(model, controller):

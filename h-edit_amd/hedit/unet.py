@@ -9,7 +9,12 @@ diffusers state_dict key names for weights.
 
 The attention processors are markers: the Prompt-to-Prompt edit itself runs inside the HIP
 attention kernels, driven by a per-call plan compiled from the registered controller
-(hedit/p2p/ptp_classes.py).  Unknown processors / controllers raise -- there is no eager path.
+(hedit/p2p/ptp_classes.py).  A controller that is NOT one of hedit's (any object callable as the
+reference's ``controller(attention_probs, is_cross, place_in_unet, save_attn)``,
+p2p/ptp_utils.py:98-106, p2p/ptp_classes.py:91-108) is served by the hook path of the executor
+(``hedit_unet_set_attn_hook``): every attention layer materialises its probabilities, the controller
+sees and may rewrite them in place, the executor multiplies what comes back with V.  Slow (fp32
+probabilities through HBM), same protocol.
 """
 import ctypes as C
 import hashlib
@@ -179,8 +184,13 @@ class UNet2DConditionModel:
                 raise KeyError(f"unknown attention processor name {k}")
             if not hasattr(p, "controller"):
                 raise TypeError(
-                    f"{type(p).__name__}: only hedit processors are supported -- the P2P edit runs "
-                    "inside the HIP attention kernels, arbitrary Python processors cannot be hooked")
+                    f"{type(p).__name__}: a processor is identified by its .controller (None = plain attention, a hedit "
+                    "controller = in-kernel edit, any other callable = hooked through hedit_unet_set_attn_hook); processor "
+                    "objects that re-implement the attention body itself cannot be run -- the body is the HIP kernels")
+            c = p.controller
+            if c is not None and not hasattr(c, "_plan") and not callable(c):
+                raise TypeError(f"{type(c).__name__}: a foreign controller must be callable as "
+                                "controller(attention_probs, is_cross, place_in_unet, save_attn)")
             self._procs[k] = p
 
     def _controller(self):
@@ -270,6 +280,41 @@ class UNet2DConditionModel:
             _lib.cur_stream()))
         return out
 
+    _HOOK_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
+
+    def forward_hooked(self, sample, t, ctx, controller, save_attn=True, out=None):
+        """One UNet call with a foreign (host-language) controller: ``controller(attention_probs, is_cross,
+        place_in_unet, save_attn)`` is called once per attention layer, in execution order, with the reference's tensor
+        (fp32 [batch * heads, queries, keys], a fresh tensor per layer like the reference's, so a controller may keep it);
+        in-place changes go into the product with V, the return value is ignored (ptp_utils.py:100-106)."""
+        B, _, H, W = sample.shape
+        state = {"exc": None}
+        places = ("down", "mid", "up")
+
+        def cb(_user, probs, bh, nq, nk, is_cross, place, _layer, _stream):
+            try:
+                off = int(probs) - self._ws.data_ptr()
+                view = self._ws[off:off + bh * nq * nk * 4].view(torch.float32).view(bh, nq, nk)
+                attn = view.clone()
+                controller(attn, bool(is_cross), places[place], save_attn)
+                view.copy_(attn)
+                return 0
+            except BaseException as e:      # noqa: BLE001  (must not unwind through the C frames)
+                state["exc"] = e
+                return 1
+
+        fn = self._HOOK_T(cb)
+        _lib.check(self._lib.hedit_unet_set_attn_hook(self._h, C.cast(fn, C.c_void_p), None))
+        try:
+            try:
+                return self.forward_raw(sample, t, ctx, None, out)      # (the workspace is sized with the hook set)
+            except _lib.HipError:
+                if state["exc"] is not None:
+                    raise state["exc"]
+                raise
+        finally:
+            _lib.check(self._lib.hedit_unet_set_attn_hook(self._h, None, None))
+
     def forward(self, sample, timestep=None, encoder_hidden_states=None, cross_attention_kwargs=None,
                 return_dict=True):
         kw = dict(cross_attention_kwargs or {})
@@ -292,6 +337,8 @@ class UNet2DConditionModel:
             # an attention editor registered on the UNet (MasaCtrl: regiter_attention_editor_diffusers; Plug-and-Play:
             # register_attention_control_efficient / register_conv_control_efficient)
             controller = getattr(self, "_attention_editor", None)
+        if controller is not None and not hasattr(controller, "_plan"):
+            return UNetOutput(sample=self.forward_hooked(sample, t, ctx, controller, save_attn))
         plan = None
         if controller is not None:
             plan = controller._plan(self, sample.shape[0], sample.shape[2], sample.shape[3], save_attn)

@@ -130,6 +130,17 @@ size_t hedit_unet_workspace_bytes(hedit_unet* h, int B, int height, int width);
 int hedit_unet_forward(hedit_unet* h, const float* x, float t, const float* ctx, int B, int height,
                        int width, const hedit_p2p_plan* plan, float* eps_out, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* Host-language attention controller -- the reference's hook point, text-guided/p2p/ptp_utils.py:98-106
+ * (`self.controller(attention_probs, is_cross, self.place_in_unet, save_attn)` between the softmax and the product with V).
+ * With a hook set, every attention layer of hedit_unet_forward writes its probabilities to HBM as fp32
+ * [batch_heads = B * heads][n_query][n_key] (batch-major like `head_to_batch_dim`; n_key = 77 for the context), calls
+ * fn -- which may rewrite them in place with work queued on `stream` -- and multiplies the result with V.  place: 0 down,
+ * 1 mid, 2 up; layer counts the calls of one forward.  fn returns 0, anything else aborts the forward.  The in-kernel
+ * edits of the plan are NOT applied on this path (pass plan = NULL or a mode-0 plan); fn = NULL restores the fused kernels.
+ * hedit_unet_workspace_bytes accounts for the probabilities while a hook is set. */
+typedef int (*hedit_attn_hook_fn)(void* user, float* probs, int batch_heads, int n_query, int n_key, int is_cross, int place,
+                                  int layer, void* stream);
+int hedit_unet_set_attn_hook(hedit_unet* h, hedit_attn_hook_fn fn, void* user);
 /* number of cross-attention layers with <= 32*32 tokens (= plan.n_store) and their geometry */
 int hedit_unet_num_store_layers(const hedit_unet* h, int height, int width);
 int hedit_unet_store_layer_info(const hedit_unet* h, int height, int width, int i, int* tokens,
@@ -191,6 +202,11 @@ int hedit_axis_mix(const float* in, float* out, const int32_t* idx, const float*
 int hedit_local_blend(float* const* h_maps, int n_maps, int heads, const float* alpha_layers,
                       const int32_t* enabled, float* xt, int n_img, int C, int H, int W, float th,
                       void* stream);
+/* the same with LocalBlend's substruct_words (ptp_classes.py:28-38,64-68): substruct_layers [n_img][2][77] marks the words
+ * whose (un-pooled) map, thresholded with th_sub = th[1], is cut out of the blend mask */
+int hedit_local_blend_sub(float* const* h_maps, int n_maps, int heads, const float* alpha_layers,
+                          const float* substruct_layers, const int32_t* enabled, float* xt, int n_img, int C, int H,
+                          int W, float th, float th_sub, void* stream);
 
 /* ---- image autoencoder (SD-1.x AutoencoderKL): the steps either side of the editing loop ---------
  * replaces `model.vae.encode(image).latent_dist.mode()` (text-guided/main_p2p.py:159; also
@@ -324,6 +340,12 @@ int hedit_k_self_attn(const void* q, int ldq, const void* k, int ldk, const void
 int hedit_k_cross_attn(const void* q, int ldq, const void* k, int ldk, const void* vt, int64_t ldvt,
                        void* out, int ldo, int B, int N, int heads, int d,
                        const hedit_p2p_plan* plan, float* store, void* stream);
+/* the two kernels of the hook path: probs = softmax2(q k^T) as fp32 [B*heads][N][M] (q pre-scaled by scale * log2 e;
+ * k: [B*kstride][ldk], the first M rows of every batch item count), then out = probs . v (vt: [heads*d][B*kstride]) */
+int hedit_k_attn_probs(const void* q, int ldq, const void* k, int ldk, float* probs, int B, int N, int M, int kstride,
+                       int heads, int d, void* stream);
+int hedit_k_attn_apply(const float* probs, const void* vt, int64_t ldvt, void* out, int ldo, int B, int N, int M,
+                       int kstride, int heads, int d, void* stream);
 int hedit_k_pack_conv3x3(const float* w_oihw, void* out, int O, int I, void* stream);
 int hedit_k_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 

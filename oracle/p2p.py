@@ -169,26 +169,41 @@ def equalizer(text, words, values, tok):
 
 
 # --------------------------------------------------------------------------- LocalBlend
+def _word_layers(prompts, words, tok):
+    al = torch.zeros(len(prompts), 1, 1, 1, 1, MAXW)
+    for i, (p, ws) in enumerate(zip(prompts, words)):
+        if isinstance(ws, str):
+            ws = [ws]
+        for w in ws:
+            al[i, :, :, :, :, word_inds(p, w, tok)] = 1
+    return al
+
+
 class LocalBlend:
-    def __init__(self, prompts, num_steps, words, tok, start_blend=0.2, th=(0.3, 0.3)):
-        al = torch.zeros(len(prompts), 1, 1, 1, 1, MAXW)
-        for i, (p, ws) in enumerate(zip(prompts, words)):
-            if isinstance(ws, str):
-                ws = [ws]
-            for w in ws:
-                al[i, :, :, :, :, word_inds(p, w, tok)] = 1
-        self.alpha_layers = al
+    """ptp_classes.py:17-72.  sub_words = the reference's substruct_words (:28-38): a second word mask, un-pooled and
+    thresholded with th[1], whose complement multiplies the blend mask (:64-68)."""
+
+    def __init__(self, prompts, num_steps, words, tok, start_blend=0.2, th=(0.3, 0.3), sub_words=None):
+        self.alpha_layers = _word_layers(prompts, words, tok)
+        self.sub_layers = None if sub_words is None else _word_layers(prompts, sub_words, tok)
         self.start_blend = int(start_blend * num_steps)
         self.counter = 0
         self.th = th
 
-    def mask(self, maps, x):
-        m = (maps * self.alpha_layers).sum(-1).mean(1)          # (2,1,16,16)
-        m = F.max_pool2d(m, (3, 3), (1, 1), padding=(1, 1))
+    def _mask(self, maps, layers, pool, x):
+        m = (maps * layers).sum(-1).mean(1)                      # (2,1,16,16)
+        if pool:
+            m = F.max_pool2d(m, (3, 3), (1, 1), padding=(1, 1))
         m = F.interpolate(m, size=x.shape[2:])                   # nearest
         m = m / m.max(2, keepdim=True)[0].max(3, keepdim=True)[0]
-        m = m.gt(self.th[0])
-        return (m[:1] + m).float()                               # OR with the source mask
+        m = m.gt(self.th[0 if pool else 1])
+        return m[:1] + m                                         # OR with the source mask
+
+    def mask(self, maps, x):
+        m = self._mask(maps, self.alpha_layers, True, x)
+        if self.sub_layers is not None:
+            m = m * ~self._mask(maps, self.sub_layers, False, x)
+        return m.float()
 
     def __call__(self, x, store):
         self.counter += 1

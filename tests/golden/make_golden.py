@@ -235,6 +235,32 @@ def gen_local_blend(ref, out):
     np.savez_compressed(os.path.join(out, "g5_local_blend.npz"), **d)
 
 
+def gen_local_blend_sub(ref, out):
+    """LocalBlend with substruct_words (ptp_classes.py:28-38,64-68), the reference's class called directly (its
+    make_controller never passes them)."""
+    from helpers.tiny import make_tiny_model, PROMPT_PAIRS, LOCAL_BLEND_SUB_CASES, hash_uniform, hash_normal
+    d = {}
+    T = 10
+    for ci, (pi, words, sub, th) in enumerate(LOCAL_BLEND_SUB_CASES):
+        model = make_tiny_model(T)
+        src, tar = PROMPT_PAIRS[pi][:2]
+        lb = ref.pc.LocalBlend([src, tar], T, words, substruct_words=sub, th=th, tokenizer=model.tokenizer, device=model.device)
+        heads = 2
+        five = [hash_uniform((2 * heads, 256, 77), 3100 + ci * 10 + i) ** 6 for i in range(5)]
+        big = torch.zeros(2 * heads, 1024, 77)
+        store = {"down_cross": [big, big, five[0], five[1]], "up_cross": [five[2], five[3], five[4], big]}
+        x = hash_normal((2, 4, 64, 64), 3600 + ci)
+        lb.counter = 5
+        y = lb(x.clone(), store)
+        assert torch.equal(y[0], x[0])
+        d[f"c{ci}_y"] = npy(y[1]).astype(np.float32)
+        lb0 = ref.pc.LocalBlend([src, tar], T, words, th=th, tokenizer=model.tokenizer, device=model.device)
+        lb0.counter = 5
+        y0 = lb0(x.clone(), store)
+        d[f"c{ci}_cut_pixels"] = np.asarray(int((y0[1] != y[1]).any(0).sum()))      # how much the substruct mask removed
+    np.savez_compressed(os.path.join(out, "g16_local_blend_sub.npz"), **d)
+
+
 # --------------------------------------------------------------------------- G6 processor
 def gen_processor(ref, out):
     from helpers.tiny import TinyAttention, make_tiny_model, PROMPT_PAIRS, hash_normal
@@ -793,6 +819,8 @@ def main():
         return gen_face(HERE)
     if "--only-pnp" in sys.argv:
         return gen_pnp(import_reference(), HERE)
+    if "--only-local-blend-sub" in sys.argv:
+        return gen_local_blend_sub(import_reference(), HERE)
     if "--only-masactrl" in sys.argv:
         return gen_masactrl(import_reference(), HERE)
     ref = import_reference()
@@ -800,6 +828,7 @@ def main():
     gen_scheduler(ref, out)
     gen_controller(ref, out)
     gen_local_blend(ref, out)
+    gen_local_blend_sub(ref, out)
     gen_processor(ref, out)
     gen_loops(ref, out)
     gen_ddim(ref, out)

@@ -539,3 +539,11 @@ def make_oracle_sd_model(config, num_steps, seed=0, text_layers=2, out_scale=0.3
     m.text_encoder = ClipTextEncoder(dim=config["cross_attention_dim"], layers=text_layers, heads=4, seed=seed + 7)
     m.vae = None
     return m, sd
+
+# LocalBlend with substruct_words: (pair, blend words, substruct words, th) -- shared by tests/golden/make_golden.py
+# (g16_local_blend_sub.npz, from the reference's class) and the tests
+LOCAL_BLEND_SUB_CASES = [
+    (0, (("lizard",), ("lizard",)), (("branch",), ("branch",)), (0.3, 0.3)),
+    (1, (("van",), ("van",)), (("surfboards",), ("flowers",)), (0.3, 0.2)),
+    (3, (("cat",), ("cat", "sculpture")), (("mirror",), ("mirror",)), (0.25, 0.4)),
+]

@@ -641,6 +641,29 @@ def test_step_kernels_match_reference_vectors(lib, golden_dir):
             assert G.max_err(out[i], want) < 1e-4 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_local_blend_substruct_words_match_reference_vectors(lib, golden_dir, ci):
+    """hedit's LocalBlend(substruct_words=...) -> hedit_local_blend_sub against the reference's class (g16)."""
+    import os
+    from helpers.tiny import LOCAL_BLEND_SUB_CASES, PROMPT_PAIRS, WordTokenizer, hash_normal, hash_uniform
+    from hedit.p2p.ptp_classes import LocalBlend
+    g = np.load(os.path.join(golden_dir, "g16_local_blend_sub.npz"))
+    pi, words, sub, th = LOCAL_BLEND_SUB_CASES[ci]
+    src, tar = PROMPT_PAIRS[pi][:2]
+    tok = WordTokenizer(split_long_words_at=6)
+    lb = LocalBlend([src, tar], 10, words, substruct_words=sub, th=th, tokenizer=tok, device=G.dev())
+    heads = 2
+    five = [G.f32(hash_uniform((2 * heads, 256, 77), 3100 + ci * 10 + i) ** 6) for i in range(5)]
+    big = torch.zeros(2 * heads, 1024, 77, device=G.dev())
+    store = {"down_cross": [big, big, five[0], five[1]], "up_cross": [five[2], five[3], five[4], big]}
+    x = hash_normal((2, 4, 64, 64), 3600 + ci)
+    lb.counter = 5
+    y = lb(G.f32(x), store)
+    G.sync()
+    assert torch.equal(y[0].cpu(), x[0])
+    assert G.max_err(y[1], torch.from_numpy(g[f"c{ci}_y"])) < 1e-6
+
+
 @pytest.mark.parametrize("pi", [0, 1, 3])
 def test_local_blend_matches_reference_vectors(lib, golden_dir, pi):
     import os

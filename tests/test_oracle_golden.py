@@ -157,6 +157,29 @@ def test_local_blend(golden_dir, pi):
         close(y[1], g[f"p{pi}_y_counter{counter}"], 1e-6)
 
 
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_local_blend_substruct_words(golden_dir, ci):
+    """LocalBlend(substruct_words=...) (ptp_classes.py:28-38,64-68) against the reference's class (g16)."""
+    from helpers.tiny import LOCAL_BLEND_SUB_CASES
+    from oracle import p2p as OP
+    g = _npz(golden_dir, "g16_local_blend_sub.npz")
+    pi, words, sub, th = LOCAL_BLEND_SUB_CASES[ci]
+    T = 10
+    model = make_tiny_model(T)
+    src, tar = PROMPT_PAIRS[pi][:2]
+    lb = OP.LocalBlend([src, tar], T, words, model.tokenizer, th=th, sub_words=sub)
+    heads = 2
+    five = [hash_uniform((2 * heads, 256, 77), 3100 + ci * 10 + i) ** 6 for i in range(5)]
+    big = torch.zeros(2 * heads, 1024, 77)
+    store = {"down_cross": [big, big, five[0], five[1]], "up_cross": [five[2], five[3], five[4], big]}
+    x = hash_normal((2, 4, 64, 64), 3600 + ci)
+    lb.counter = 5
+    y = lb(x.clone(), store)
+    assert torch.equal(y[0], x[0])
+    close(y[1], g[f"c{ci}_y"], 1e-6)
+    assert int(g[f"c{ci}_cut_pixels"]) > 0
+
+
 # --------------------------------------------------------------------------- G6 processor
 def test_processor(golden_dir):
     g = _npz(golden_dir, "g6_processor.npz")
