@@ -537,6 +537,54 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* __restrict_
   }
 }
 
+// Small images (HW < 1024: the 16 x 16 and 8 x 8 levels), ONE launch: a block owns one (image, group) -- at most 256
+// pixels x 80 channels = 40 KB of bf16 pairs, parked in LDS --, sums it in a fixed order (thread-sequential over its
+// strided pairs, butterfly over the wave, waves 0..3 in order: a function of the image alone, like every norm here) and
+// normalises from LDS.  Three launches (partials, finalize, apply) became one; at one image per call that is 60 launches
+// of a UNet pass.
+__global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int HW, int C, int G, float eps, int silu, float* __restrict__ stats) {
+  extern __shared__ uint32_t gs_pairs[];
+  __shared__ float red[8];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / G, ppp = cpg / 2;                 // bf16 pairs per pixel of this group
+  const int npair = HW * ppp;
+  const uint32_t* xin = reinterpret_cast<const uint32_t*>(x + (long)b * HW * C + g * cpg);
+  float s = 0.f, q = 0.f;
+  for (int i = tid; i < npair; i += 256) {
+    const int pix = i / ppp, j = i - pix * ppp;
+    const uint32_t u = xin[(long)pix * (C / 2) + j];
+    gs_pairs[i] = u;
+    const float a = __uint_as_float(u << 16), c = __uint_as_float(u & 0xffff0000u);
+    s += a; s += c;
+    q += a * a; q += c * c;
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s; red[(tid >> 6) * 2 + 1] = q; }
+  __syncthreads();
+  s = ((red[0] + red[2]) + red[4]) + red[6];
+  q = ((red[1] + red[3]) + red[5]) + red[7];
+  const float n = (float)HW * (float)cpg;
+  const float m = s / n;
+  float var = q / n - m * m;
+  var = var < 0.f ? 0.f : var;
+  const float rstd = rsqrtf(var + eps);
+  if (stats && tid == 0) *reinterpret_cast<float2*>(stats + ((long)b * G + g) * 2) = make_float2(m, rstd);
+  uint32_t* yout = reinterpret_cast<uint32_t*>(y + (long)b * HW * C + g * cpg);
+  for (int i = tid; i < npair; i += 256) {
+    const int pix = i / ppp, j = i - pix * ppp;
+    const uint32_t u = gs_pairs[i];
+    const int c0 = g * cpg + 2 * j;
+    const float sc0 = rstd * gamma[c0], sc1 = rstd * gamma[c0 + 1];
+    float a = __uint_as_float(u << 16) * sc0 + (beta[c0] - m * sc0);
+    float c = __uint_as_float(u & 0xffff0000u) * sc1 + (beta[c0 + 1] - m * sc1);
+    if (silu) { a = silu_f(a); c = silu_f(c); }
+    yout[(long)pix * (C / 2) + j] = pack_bf16x2(a, c);
+  }
+}
+
 // Pixel slabs per image for the statistics pass.  A function of (HW, C) only -- never of the batch -- so that the
 // fp32 summation order of an image's statistics, and with it every bit of the normalised output, is the same
 // whether the image is evaluated alone or in a batch of 120 (the sampler's reconstruction invariant rests on it).
@@ -563,6 +611,12 @@ int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float
                      int C, int G, float eps, int silu, float* ws, hipStream_t st, float* stats) {
   ARG_CHECK(C % 8 == 0 && C % G == 0 && G <= 64, "groupnorm: C % 8, C % G, G <= 64");
   ARG_CHECK(C / 8 <= 256 * GN_MAXV, "groupnorm: C too large");
+  // small images: one launch (a choice by (HW, C, G) only, never by the batch)
+  if (HW < 1024 && (C / G) % 2 == 0 && (size_t)HW * (C / G) * 2 <= 60 * 1024) {
+    hipLaunchKernelGGL(gn_small_kernel, dim3(G, B), dim3(256), (size_t)HW * (C / G) * 2, st, x, y, gamma, beta, HW, C, G, eps, silu, stats);
+    LAUNCH_CHECK();
+    return HEDIT_OK;
+  }
   const int nslab = gn_nslab(B, HW, C);
   float* part = ws;
   float* ss = ws + (size_t)B * nslab * 64 * 2;
