@@ -121,6 +121,22 @@ def test_sd15_unet_forward_full_size():
     assert err < TOL_SD, err
     assert len(hip.unet.attn_processors) == 32
     assert sum(int(torch.tensor(s).prod()) for s in hip.unet.param_shapes.values()) == 859520964
+    # Where the error comes from: the same fp32 oracle with bf16 STORAGE emulated -- weights rounded to bf16 and the output
+    # of every leaf module (conv, linear, norm) rounded to bf16, arithmetic still fp32 -- lands as far from the fp32 result
+    # as the HIP path does.  I.e. the tolerance above is the price of BASELINE's bf16 tensors, not of the kernels; the
+    # fused chains (fp32 intermediates in registers) can only be on the better side of it.  Measured on MI355X / this seed:
+    # HIP 1.5e-2 (full) against 1.6e-2 for the emulation.
+    with torch.no_grad():
+        for p_ in om.unet.parameters():
+            p_.copy_(p_.to(torch.bfloat16).float())
+        hooks = [m.register_forward_hook(lambda m_, i_, o_: o_.to(torch.bfloat16).float() if isinstance(o_, torch.Tensor) else o_)
+                 for m in om.unet.modules() if len(list(m.children())) == 0]
+        emu = om.unet(x.to(torch.bfloat16).float(), torch.tensor(481), encoder_hidden_states=ctx.to(torch.bfloat16).float()).sample
+        for h_ in hooks:
+            h_.remove()
+    e_store = G.rel_err(G.f32(emu), want)
+    print(f"sd15 eps error vs fp32 oracle: HIP {err:.3e}, bf16-storage emulation of the oracle {e_store:.3e}")
+    assert err < 1.5 * e_store, (err, e_store)
 
 
 def test_tiny_unet_rectangular_latent(tiny):
