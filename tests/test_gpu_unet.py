@@ -125,7 +125,7 @@ def test_sd15_unet_forward_full_size():
     # of every leaf module (conv, linear, norm) rounded to bf16, arithmetic still fp32 -- lands as far from the fp32 result
     # as the HIP path does.  I.e. the tolerance above is the price of BASELINE's bf16 tensors, not of the kernels; the
     # fused chains (fp32 intermediates in registers) can only be on the better side of it.  Measured on MI355X / this seed:
-    # HIP 1.5e-2 (full) against 1.6e-2 for the emulation.
+    # HIP 1.16e-2 against 1.10e-2 for the emulation.
     with torch.no_grad():
         for p_ in om.unet.parameters():
             p_.copy_(p_.to(torch.bfloat16).float())
