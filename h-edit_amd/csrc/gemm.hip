@@ -1058,6 +1058,11 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
 #undef DISPATCH
   if (rc != HEDIT_OK) return rc;
   if (splits > 1) {
+    if (p.ln_out && p.ln_done && !p.raw_f32 && p.ldc == p.N && splitk_reduce_ln_supported(p.N)) {
+      *p.ln_done = 1;
+      return splitk_reduce_ln_launch(p.partial, p.splits, p.bias, p.residual, p.ldr, p.C, p.ln_out, p.ln_gamma, p.ln_beta, p.M, p.N,
+                                     p.ln_eps, st);
+    }
     long total = (long)p.M * (p.N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p);
     LAUNCH_CHECK();

@@ -25,6 +25,12 @@ struct GemmParams {
                          // Downsample2D(padding=0): taps at rows 2oy .. 2oy+2)
   float* raw_f32;        // if set: write the plain fp32 products [M][N] here (no bias / residual / bf16 C)
   int chunk_kt;          // canonical K-chunking (gemm_canonical_chunk), in K-tiles of 64; 0 = one plain chain
+  // optional: the consumer is LayerNorm(C) -> ln_out.  gemm_launch honours it ONLY when the launch is split-K (the reduce
+  // pass then normalises too, one launch less) and reports it through *ln_done; otherwise the caller normalises itself
+  const float *ln_gamma, *ln_beta;
+  bf16_t* ln_out;
+  float ln_eps;
+  int* ln_done;
 };
 #ifndef GEMM_NOMINAL_BATCH
 #define GEMM_NOMINAL_BATCH 4   // the canonical chunking is sized for this many rows of the batch dimension
@@ -105,6 +111,12 @@ int groupnorm_affine_launch(const bf16_t* x, const float* gamma, const float* be
                             float* ws, hipStream_t st, const float** ss_out);   // *ss_out: [B][C] float2 (scale, shift), inside ws
 int layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, long rows,
                      int C, float eps, hipStream_t st);
+// reduce + LayerNorm in one launch behind a split-K GEMM whose output feeds a LayerNorm (small batches): out = the GEMM's
+// bf16 result (sum of the fp32 slabs in order + bias, rounded, + residual, rounded -- splitk_reduce_kernel's arithmetic), y = LayerNorm(out)
+// by the kernel layernorm_launch would pick.  Same bits as the two launches.
+bool splitk_reduce_ln_supported(int C);
+int splitk_reduce_ln_launch(const float* partial, int splits, const float* bias, const bf16_t* residual, int ldr, bf16_t* out,
+                            bf16_t* y, const float* gamma, const float* beta, long rows, int C, float eps, hipStream_t st);
 int geglu_launch(const bf16_t* x, bf16_t* y, long rows, int inner, hipStream_t st);
 // y [rows][ca+cb] = [a | b]; a == nullptr: the left part is already in place, only b is copied
 int concat_launch(const bf16_t* a, int ca, const bf16_t* b, int cb, bf16_t* y, long rows, hipStream_t st);

@@ -263,10 +263,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 // 128-byte line per load), a wave normalises 8 rows, and the two reductions stay inside the 8-lane
 // groups.  Same arithmetic order per row as layernorm_kernel up to the reduction tree.
 constexpr int LNN_MAXV = 5;
-template <int LANES>     // 8 / 16 / 32 lanes per row, up to LNN_MAXV 16-byte chunks per lane (C = 320 / 640 / 1280: five each)
-__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+// RED: the rows do not exist yet -- they are the sum of split-K slabs (+ bias, rounded, + residual, rounded: the arithmetic
+// of gemm.hip's splitk_reduce_kernel, element for element).  The kernel then forms each 16-byte piece itself, writes it
+// to `x` (the GEMM's output, which the residual stream keeps) and normalises it: one launch instead of reduce +
+// LayerNorm behind a small split-K GEMM, same bits.
+struct LnReduce {
+  const float* partial;      // [splits][rows][C]
+  int splits;
+  const float* bias;         // [C] or null
+  const bf16_t* residual;    // [rows][ldr] or null
+  int ldr;
+};
+template <int LANES, bool RED = false>     // 8 / 16 / 32 lanes per row, up to LNN_MAXV 16-byte chunks per lane (C = 320 / 640 / 1280: five each)
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               long rows, int C, float eps) {
+                                                               long rows, int C, float eps, LnReduce rd) {
   const int l8 = threadIdx.x & (LANES - 1);
   const long row = (long)blockIdx.x * (256 / LANES) + threadIdx.x / LANES;
   const bool live = row < rows;
@@ -276,7 +287,34 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const bf16_t* __r
 #pragma unroll
   for (int v = 0; v < LNN_MAXV; ++v) {
     if (v < NV && live) {
-      uint4 u = *reinterpret_cast<const uint4*>(x + row * C + (l8 + v * LANES) * 8);
+      uint4 u;
+      if constexpr (RED) {
+        const int n = (l8 + v * LANES) * 8;
+        uint32_t w[4];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+          for (int sp = 0; sp < rd.splits; ++sp)
+            a += *reinterpret_cast<const f32x4*>(rd.partial + ((long)sp * rows + row) * C + n + half * 4);
+          f32x4 b = {0.f, 0.f, 0.f, 0.f};
+          if (rd.bias) b = *reinterpret_cast<const f32x4*>(rd.bias + n + half * 4);
+          a = a + b;
+          uint32_t o0 = pack_bf16x2(a[0], a[1]), o1 = pack_bf16x2(a[2], a[3]);
+          if (rd.residual) {
+            const uint2 r = *reinterpret_cast<const uint2*>(rd.residual + row * rd.ldr + n + half * 4);
+            o0 = pack_bf16x2(bf16_to_f32((bf16_t)(o0 & 0xffff)) + bf16_to_f32((bf16_t)(r.x & 0xffff)),
+                             bf16_to_f32((bf16_t)(o0 >> 16)) + bf16_to_f32((bf16_t)(r.x >> 16)));
+            o1 = pack_bf16x2(bf16_to_f32((bf16_t)(o1 & 0xffff)) + bf16_to_f32((bf16_t)(r.y & 0xffff)),
+                             bf16_to_f32((bf16_t)(o1 >> 16)) + bf16_to_f32((bf16_t)(r.y >> 16)));
+          }
+          w[half * 2] = o0;
+          w[half * 2 + 1] = o1;
+        }
+        u = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4*>(x + row * C + n) = u;
+      } else {
+        u = *reinterpret_cast<const uint4*>(x + row * C + (l8 + v * LANES) * 8);
+      }
       unpack8(u, f[v]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += f[v][j];
@@ -668,23 +706,48 @@ int groupnorm_affine_launch(const bf16_t* x, const float* gamma, const float* be
   return HEDIT_OK;
 }
 
+// (one selection for both forms: the fused form must normalise with the very kernel the separate launch would use)
+static int ln_narrow_lanes(int C) {
+  if (C % 64 == 0 && C / 64 <= LNN_MAXV) return 8;
+  if (C % 128 == 0 && C / 128 <= LNN_MAXV) return 16;     // C = 640
+  if (C % 256 == 0 && C / 256 <= LNN_MAXV) return 32;     // C = 1280
+  return 0;
+}
+
+bool splitk_reduce_ln_supported(int C) { return C % 8 == 0 && ln_narrow_lanes(C) != 0; }
+
+// out = bf16(sum of slabs + bias) (+ residual), y = LayerNorm(out): see LnReduce
+int splitk_reduce_ln_launch(const float* partial, int splits, const float* bias, const bf16_t* residual, int ldr, bf16_t* out,
+                            bf16_t* y, const float* gamma, const float* beta, long rows, int C, float eps, hipStream_t st) {
+  const int lanes = ln_narrow_lanes(C);
+  ARG_CHECK(lanes != 0 && splits >= 1, "splitk_reduce_ln: unsupported row width");
+  const LnReduce rd{partial, splits, bias, residual, ldr};
+  if (lanes == 8) hipLaunchKernelGGL((layernorm_narrow_kernel<8, true>), dim3(cdiv(rows, 32)), dim3(256), 0, st, out, y, gamma, beta, rows, C, eps, rd);
+  else if (lanes == 16) hipLaunchKernelGGL((layernorm_narrow_kernel<16, true>), dim3(cdiv(rows, 16)), dim3(256), 0, st, out, y, gamma, beta, rows, C, eps, rd);
+  else hipLaunchKernelGGL((layernorm_narrow_kernel<32, true>), dim3(cdiv(rows, 8)), dim3(256), 0, st, out, y, gamma, beta, rows, C, eps, rd);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
 int layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, long rows, int C,
                      float eps, hipStream_t st) {
   ARG_CHECK(C % 8 == 0 && C / 8 <= 64 * LN_MAXV, "layernorm: C");
-  if (C % 64 == 0 && C / 64 <= LNN_MAXV) {     // 8 lanes per row
-    hipLaunchKernelGGL(layernorm_narrow_kernel<8>, dim3(cdiv(rows, 32)), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps);
-    LAUNCH_CHECK();
-    return HEDIT_OK;
-  }
-  if (C % 128 == 0 && C / 128 <= LNN_MAXV) {   // 16 lanes per row (C = 640)
-    hipLaunchKernelGGL(layernorm_narrow_kernel<16>, dim3(cdiv(rows, 16)), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps);
-    LAUNCH_CHECK();
-    return HEDIT_OK;
-  }
-  if (C % 256 == 0 && C / 256 <= LNN_MAXV) {   // 32 lanes per row (C = 1280)
-    hipLaunchKernelGGL(layernorm_narrow_kernel<32>, dim3(cdiv(rows, 8)), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps);
-    LAUNCH_CHECK();
-    return HEDIT_OK;
+  const LnReduce none{};
+  bf16_t* xx = const_cast<bf16_t*>(x);      // (only the reducing form writes it)
+  switch (ln_narrow_lanes(C)) {
+    case 8:      // 8 lanes per row
+      hipLaunchKernelGGL((layernorm_narrow_kernel<8, false>), dim3(cdiv(rows, 32)), dim3(256), 0, st, xx, y, gamma, beta, rows, C, eps, none);
+      LAUNCH_CHECK();
+      return HEDIT_OK;
+    case 16:     // 16 lanes per row (C = 640)
+      hipLaunchKernelGGL((layernorm_narrow_kernel<16, false>), dim3(cdiv(rows, 16)), dim3(256), 0, st, xx, y, gamma, beta, rows, C, eps, none);
+      LAUNCH_CHECK();
+      return HEDIT_OK;
+    case 32:     // 32 lanes per row (C = 1280)
+      hipLaunchKernelGGL((layernorm_narrow_kernel<32, false>), dim3(cdiv(rows, 8)), dim3(256), 0, st, xx, y, gamma, beta, rows, C, eps, none);
+      LAUNCH_CHECK();
+      return HEDIT_OK;
+    default: break;
   }
   hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps);
   LAUNCH_CHECK();

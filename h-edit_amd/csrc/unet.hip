@@ -337,6 +337,23 @@ int linear(Fwd& f, const bf16_t* A, int M, int K, const bf16_t* W, int N, const 
   return run_gemm(f, p, batch_in);
 }
 
+// C = A W^T + bias (+ residual), then y = LayerNorm(C).  Behind a split-K launch (small batches) the reduce pass
+// normalises too; otherwise the LayerNorm is its own launch, as before -- the same bits either way (kernels.h).
+int linear_ln(Fwd& f, const bf16_t* A, int M, int K, const bf16_t* W, int N, const float* bias, const bf16_t* residual, bf16_t* C,
+              const float* g, const float* b, float eps, bf16_t* y) {
+  GemmParams p{};
+  p.A = A; p.W = W; p.M = M; p.N = N; p.K = K; p.lda = K; p.mode = 0;
+  p.bias = bias; p.residual = residual; p.ldr = N; p.C = C; p.ldc = N;
+  int done = 0;
+  p.ln_gamma = g; p.ln_beta = b; p.ln_out = y; p.ln_eps = eps; p.ln_done = &done;
+  TRY(run_gemm(f, p));
+  if (!done) {
+    ProfScope ps(f, PK_NORM, 0.0, 4.0 * M * N);
+    RUN(f, layernorm_launch(C, y, g, b, (long)M, N, eps, f.st));
+  }
+  return HEDIT_OK;
+}
+
 int conv3x3(Fwd& f, const bf16_t* X, int Hin, int Win, int Cin, const bf16_t* W, int Cout, const float* bias,
             const bf16_t* residual, bf16_t* Y, int mode, int ldy = 0) {
   GemmParams p{};
@@ -458,11 +475,10 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
   } else {
     TRY(aalloc(f, &xn, M * C));
     TRY(groupnorm(f, x, xn, a.gn_g, a.gn_b, N, C, 1e-6f, 0));
-    TRY(linear(f, xn, (int)M, C, a.pin, C, a.pin_b, nullptr, t0, C));
-    f.ar.free(xn);
-    // ---- self-attention projections
+    // ---- proj_in, norm1 and the self-attention projections
     TRY(aalloc(f, &tn, M * C));
-    { ProfScope ps(f, PK_NORM, 0.0, 4.0 * M * C); RUN(f, layernorm_launch(t0, tn, a.ln1g, a.ln1b, (long)M, C, 1e-5f, f.st)); }
+    TRY(linear_ln(f, xn, (int)M, C, a.pin, C, a.pin_b, nullptr, t0, a.ln1g, a.ln1b, 1e-5f, tn));
+    f.ar.free(xn);
     TRY(linear(f, tn, (int)M, C, a.w_qk, 2 * C, nullptr, nullptr, qk, 2 * C));
     TRY(linear(f, a.w_v1, C, C, tn, (int)M, nullptr, nullptr, vt, (int)M, 2));   // V^T = W_v . X^T
     f.ar.free(tn);
@@ -497,10 +513,9 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
     chain_prof(ps, 2, 130);                                                                 // tag 130: attn1.to_out .. attn2.to_q
     RUN(f, lin_chain_launch(lc, f.st));
   } else {
-    TRY(linear(f, ao, (int)M, C, a.w_o1, C, a.o1_b, t0, t1, C));
-    // ---- cross-attention (P2P edits + store happen inside the kernel)
+    // ---- attn1.to_out + residual, norm2; cross-attention (P2P edits + store happen inside the kernel)
     TRY(aalloc(f, &tn, M * C));
-    { ProfScope ps(f, PK_NORM, 0.0, 4.0 * M * C); RUN(f, layernorm_launch(t1, tn, a.ln2g, a.ln2b, (long)M, C, 1e-5f, f.st)); }
+    TRY(linear_ln(f, ao, (int)M, C, a.w_o1, C, a.o1_b, t0, t1, a.ln2g, a.ln2b, 1e-5f, tn));
     TRY(linear(f, tn, (int)M, C, a.w_q2, C, nullptr, nullptr, q2, C));
     f.ar.free(tn);
   }
@@ -557,13 +572,11 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
     return HEDIT_OK;
   }
   TRY(aalloc(f, &t2, M * C));
-  TRY(linear(f, ao, (int)M, C, a.w_o2, C, a.o2_b, t1, t2, C));
+  // ---- attn2.to_out + residual, norm3, GEGLU feed-forward
+  TRY(aalloc(f, &tn, M * C));
+  TRY(linear_ln(f, ao, (int)M, C, a.w_o2, C, a.o2_b, t1, t2, a.ln3g, a.ln3b, 1e-5f, tn));
   f.ar.free(ao);
   f.ar.free(t1);
-
-  // ---- GEGLU feed-forward
-  TRY(aalloc(f, &tn, M * C));
-  { ProfScope ps(f, PK_NORM, 0.0, 4.0 * M * C); RUN(f, layernorm_launch(t2, tn, a.ln3g, a.ln3b, (long)M, C, 1e-5f, f.st)); }
   TRY(aalloc(f, &gf, M * 4 * C));
   {
     GemmParams gp{};

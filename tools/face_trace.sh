@@ -1,8 +1,8 @@
 #!/bin/bash
 # Kernel trace of the face workload (configs[3]) restricted to the loop: per-kernel table, busy / span, and where the
-# idle time between dispatches sits.  tools/face_trace.sh [faces]   -> gpurun_out/r03/face_*  (run on the GPU box)
+# idle time between dispatches sits.  tools/face_trace.sh [faces]   -> gpurun_out/$ROUND_TAG/face_* (default r04)  (run on the GPU box)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r03
+O=$R/gpurun_out/${ROUND_TAG:-r04}
 N=${1:-32}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
