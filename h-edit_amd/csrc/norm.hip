@@ -631,8 +631,12 @@ int gn_nslab(int B, int HW, int C) {
   const int CV = C / 8;
   const int R = CV <= 256 ? 256 / CV : 1;
   int n = HW / (R * 8);         // >= 8 rows per thread
-  int cap = HW / 1024;          // 32 slabs up to 128 x 128 pixels, 128 for the VAE's 512 x 512
-  cap = cap < 32 ? 32 : (cap > 128 ? 128 : cap);
+  // 32 slabs up to 64 x 64 pixels (the SD UNet's shapes), 64 from 128 x 128, 128 for the VAE's 512 x 512.  More is not
+  // better: every block of the apply pass folds all slabs of its image, and at 256 slabs for 256 x 256 that fold cost more
+  // than the statistics pass gained (8 faces: 101 -> 148 us; tools/gn_bench.py, gpurun_out/r04/gn_bench.txt)
+  int cap = HW / 256;
+  cap = cap < 32 ? 32 : (cap > 64 ? 64 : cap);
+  if (HW >= 512 * 512) cap = 128;
   if (n > cap) n = cap;
   if (n < 1) n = 1;
   return n;

@@ -11,6 +11,7 @@ db=$(find /tmp/p_face -name "*.db" | head -1)
 if [ -n "$db" ]; then
   python $R/tools/rocpd_stats.py $db --loop > $O/face_n${N}_kernel_stats.txt
   python $R/tools/rocpd_stats.py $db --loop --gaps > $O/face_n${N}_gaps.txt
+  python $R/tools/rocpd_stats.py $db --loop --by-grid > $O/face_n${N}_kernel_stats_by_grid.txt
   head -12 $O/face_n${N}_kernel_stats.txt; head -45 $O/face_n${N}_gaps.txt
 fi
 rm -rf /tmp/p_face
