@@ -5,7 +5,7 @@ ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 mkdir -p /tmp/hedit_variants
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result"
 /opt/rocm/bin/hipcc $F -c $ROOT/tools/experiments/xffn.hip -o /tmp/hedit_variants/xffn.o
-/opt/rocm/bin/hipcc $F -c $ROOT/tools/experiments/lintile.hip -o /tmp/hedit_variants/lintile.o
+/opt/rocm/bin/hipcc $F -DLINTILE_C=${LINTILE_C:-640} -c $ROOT/tools/experiments/lintile.hip -o /tmp/hedit_variants/lintile.o
 /opt/rocm/bin/hipcc $F -c $ROOT/tools/experiments/xffn_api.hip -o /tmp/hedit_variants/xffn_api.o
 OBJS=""
 for u in gemm ffn linchain norm attn step grad pnet unet vae ddpm irse lpips vit c_api; do OBJS="$OBJS $ROOT/h-edit_amd/build/$u.o"; done

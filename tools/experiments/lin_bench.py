@@ -1,6 +1,6 @@
 """The projection chains around the attentions of the 320-channel level at the bench's shape: csrc/lintile.hip (64-row tile in
 LDS, weight slices from L2 into registers, two blocks per CU) against csrc/linchain.hip (rows in registers, weights through
-LDS) on the same operands: time per launch, algorithmic TFLOP/s and GB/s, difference.  tools/experiments/build_xffn.sh, then on the GPU box: python tools/experiments/lin_bench.py [rows=120] [reps=20]"""
+LDS) on the same operands: time per launch, algorithmic TFLOP/s and GB/s, difference.  LINTILE_C=320 tools/experiments/build_xffn.sh (lintile.hip builds for one channel count), then on the GPU box: python tools/experiments/lin_bench.py [rows=120] [reps=20]"""
 import math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))

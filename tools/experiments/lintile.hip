@@ -4,6 +4,12 @@
 // 410 for the two-layer chain and 899 against 611 for the four-layer one at M = 491 520 -- with 80 KB of LDS per block there is
 // no room to stage the next tile, two blocks per CU do not hide five dependent memory round trips per tile, and smaller tiles
 // pay for it in weight traffic (every block streams every weight).
+// The same at the 640-channel level (the default build, LINTILE_C = 640; -DLINTILE_C=320 for the above): 64-row tile = all 160 KB
+// of LDS with its staging buffer, ONE block per CU, rolled k loop.  Correct on the first run (1.7e-3 / 2.3e-3 against fp32), and
+// again no win: 346 us against the 384 us of the three launches the two-layer chain replaces, 789 us against ~715 for the
+// four-layer one (tools/experiments/lin_bench640.py, gpurun_out/r04/lin640.txt).  The k loops are ~36 us of a 105 us tile; the rest
+// is tile I/O, LayerNorm and four staged outputs with nothing to overlap them -- what linchain.hip's hand-pipelined schedule
+// buys at C = 320 and what a C = 640 version would have to rebuild inside an LDS that the tile alone fills.
 //
 // The token-local projections AROUND the two attentions of a BasicTransformerBlock at the C = 320 level of the SD UNet (what
 // linchain.hip computes; oracle/sd_unet.py: Transformer2DModel.norm / proj_in, BasicTransformerBlock norm1 / attn1.to_q|k|v,
@@ -43,7 +49,11 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
-constexpr int TC = 320;                  // channels
+#ifndef LINTILE_C
+#define LINTILE_C 640
+#endif
+constexpr int TC = LINTILE_C;            // channels: 320 (the experiment of DESIGN.md 5.0 item 2) or 640
+constexpr int TBPC = TC <= 320 ? 2 : 1;  // blocks per CU (LDS: two tiles per block)
 constexpr int TBM = 64;                  // rows per tile
 constexpr int TNW = 4;                   // waves = column slices
 constexpr int TWN = TC / TNW;            // 80 output columns per wave
@@ -54,10 +64,12 @@ constexpr int TSET = TNW * TNI * 1024;   // stream bytes per k-step (20 KB)
 constexpr int TROW = TC * 2;             // bytes per activation row
 constexpr int TTILE = TBM * TROW;        // 40960
 constexpr int TX_OFF = 0, TB_OFF = TTILE;
-constexpr int TLDS = 2 * TTILE;          // 80 KB: two blocks per CU
+constexpr int TLDS = 2 * TTILE;          // 80 KB at C = 320 (two blocks per CU), 160 KB at C = 640
 constexpr int TCPR = TC / 8;             // 16-byte chunks per row
 constexpr int TIO = TBM * TCPR / 256;    // chunks per thread and tile
-static_assert(2 * TLDS <= 160 * 1024, "two blocks per CU");
+constexpr int TPART = TC <= 320 ? 1 : 2, TIOP = TIO / TPART;
+static_assert(TBPC * TLDS <= 160 * 1024, "LDS per CU");
+constexpr int TDIVM = (1 << 18) / TCPR + 1;      // q / TCPR == (q * TDIVM) >> 18 for q < TBM * TCPR
 static_assert(TBM * TCPR % 256 == 0 && TKS % 2 == 0, "tile chunks divide over the block; double-buffered weight sets");
 
 // w [C][C] fp32 -> layer `layer` of the stream: [layer][k-step][wave][fragment j][lane] 16 bytes = W[80 wave + 16 j + (lane & 15)]
@@ -100,7 +112,7 @@ __device__ __forceinline__ int tswz(int m, int c) { return m * TROW + (((c & ~7)
 
 // NPOST: layers behind the LayerNorm (1: attn2.to_q; 3: q, k, v^T).  GNIN: GroupNorm'd input, no residual, v^T transposed.
 template <int NPOST, bool GNIN>
-__global__ __launch_bounds__(256, 2) void lin_tile_kernel(TileParams p) {
+__global__ __launch_bounds__(256, TBPC) void lin_tile_kernel(TileParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,25 +162,35 @@ __global__ __launch_bounds__(256, 2) void lin_tile_kernel(TileParams p) {
       for (int i = 0; i < TMI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(smem + TX_OFF + ((xrd[i] ^ ((ks & 1) << 6)) + (ks >> 1) * 128));
     };
     read_x(xa, 0);
-    tstatic_for<TKS>([&](auto ks_) {
-      constexpr int ks = decltype(ks_)::value;
-      load_set(std::integral_constant<int, (ks + 1) & 1>{});       // (behind the last k-step of a layer: the next layer's / tile's first)
-      // every asm MFMA opens with s_nop 1: the compiler parks weight sets in AGPRs across the epilogues and copies them back
-      // (v_accvgpr_read) right in front of their first use, and it pads no hazard for an instruction inside asm -- without
-      // the wait states the first MFMA behind such a copy reads the PREVIOUS fragment (seen: rows 0-15 of every tile wrong
-      // in column blocks 1-4 of the layer behind the LayerNorm)
-      bf16x8 (&xc)[TMI] = (ks & 1) ? xb : xa;
-      bf16x8 (&xn)[TMI] = (ks & 1) ? xa : xb;
-      if constexpr (ks + 1 < TKS) read_x(xn, ks + 1);
+    // one k-step: request the next weight set, read the next activation fragments, TNI x TMI MFMAs.  FIRST: the accumulators
+    // start from the inline constant 0.  Every asm MFMA opens with s_nop 1: the compiler parks weight sets in AGPRs across
+    // the epilogues and copies them back (v_accvgpr_read) right in front of their first use, and it pads no hazard for an
+    // instruction inside asm -- without the wait states the first MFMA behind such a copy reads the PREVIOUS fragment.
+    auto k_step = [&](auto par_, auto first_, int ks) __attribute__((always_inline)) {
+      constexpr int par = decltype(par_)::value;
+      constexpr bool first = decltype(first_)::value;
+      load_set(std::integral_constant<int, par ^ 1>{});            // (behind the last k-step of a layer: the next layer's / tile's first)
+      bf16x8 (&xc)[TMI] = par ? xb : xa;
+      bf16x8 (&xn)[TMI] = par ? xa : xb;
+      if (ks + 1 < TKS) read_x(xn, ks + 1);
 #pragma unroll
       for (int j = 0; j < TNI; ++j)
 #pragma unroll
         for (int i = 0; i < TMI; ++i) {
-          if constexpr (ks == 0) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc[j][i]) : "v"(wr[ks & 1][j]), "a"(xc[i]));
-          else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j][i]) : "v"(wr[ks & 1][j]), "a"(xc[i]));
+          if constexpr (first) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc[j][i]) : "v"(wr[par][j]), "a"(xc[i]));
+          else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j][i]) : "v"(wr[par][j]), "a"(xc[i]));
         }
       __builtin_amdgcn_sched_barrier(0);
-    });
+    };
+    // (the first pair peeled, the rest a rolled loop of pairs: fully unrolled, the four layers of the C = 640 form are
+    //  3 200 MFMAs of straight-line code, more than the instruction cache holds)
+    k_step(std::integral_constant<int, 0>{}, std::true_type{}, 0);
+    k_step(std::integral_constant<int, 1>{}, std::false_type{}, 1);
+#pragma unroll 1
+    for (int ks = 2; ks < TKS; ks += 2) {
+      k_step(std::integral_constant<int, 0>{}, std::false_type{}, ks);
+      k_step(std::integral_constant<int, 1>{}, std::false_type{}, ks + 1);
+    }
     // the accumulators of the last asm MFMAs become readable by the VALU
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
@@ -185,28 +207,29 @@ __global__ __launch_bounds__(256, 2) void lin_tile_kernel(TileParams p) {
 #endif
   auto io_rc = [&](int t, int& r, int& c) __attribute__((always_inline)) {
     const int q = opaque(t * 256) + tid;
-    r = (q * 6554) >> 18;                         // q / 40 for q < 2560
+    r = (q * TDIVM) >> 18;                        // q / TCPR
     c = q - r * TCPR;
   };
-  auto load_tile = [&](const bf16_t* src, long ld, int row0, u32x4 (&buf)[TIO]) __attribute__((always_inline)) {
+  // (the tile moves in TPART pieces of TIOP chunks per thread: a whole 64 x 640 tile is 80 registers per thread and spilled)
+  auto load_tile = [&](const bf16_t* src, long ld, int row0, u32x4 (&buf)[TIOP], int t0) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rs = rsrc(src, ld, TC);
     const int ld2 = opaque((int)ld * 2);
 #pragma unroll
-    for (int t = 0; t < TIO; ++t) {
+    for (int t = 0; t < TIOP; ++t) {
       int r, c;
-      io_rc(t, r, c);
+      io_rc(t0 + t, r, c);
       buf[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((row0 + r) * ld2 + c * 16), 0, 0));
     }
 #else
-    (void)src; (void)ld; (void)row0; (void)buf;
+    (void)src; (void)ld; (void)row0; (void)buf; (void)t0;
 #endif
   };
-  auto put_tile = [&](int tile_off, const u32x4 (&buf)[TIO]) __attribute__((always_inline)) {
+  auto put_tile = [&](int tile_off, const u32x4 (&buf)[TIOP], int t0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < TIO; ++t) {
+    for (int t = 0; t < TIOP; ++t) {
       int r, c;
-      io_rc(t, r, c);
+      io_rc(t0 + t, r, c);
       *reinterpret_cast<u32x4*>(smem + tile_off + tswz(r, c)) = buf[t];
     }
   };
@@ -251,15 +274,17 @@ __global__ __launch_bounds__(256, 2) void lin_tile_kernel(TileParams p) {
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row0 = tile * TBM;
     // ================================================================ the tile's input rows -> X (GroupNorm on the way), residual rows -> B
-    {
-      u32x4 ba[TIO];
-      load_tile(p.a, p.lda, row0, ba);
-      if constexpr (GNIN) {
-        // x * scale + shift with the (scale, shift) pairs of the row's image, [image][C][2] fp32 (L2-resident, 2.5 KB per image)
 #pragma unroll
-        for (int t = 0; t < TIO; ++t) {
+    for (int part = 0; part < TPART; ++part) {
+      const int t0 = part * TIOP;
+      u32x4 ba[TIOP];
+      load_tile(p.a, p.lda, row0, ba, t0);
+      if constexpr (GNIN) {
+        // x * scale + shift with the (scale, shift) pairs of the row's image, [image][C][2] fp32 (L2-resident)
+#pragma unroll
+        for (int t = 0; t < TIOP; ++t) {
           int r, c;
-          io_rc(t, r, c);
+          io_rc(t0 + t, r, c);
           int row = row0 + r;
           row = row < p.M ? row : p.M - 1;
           const f32x4* ss = reinterpret_cast<const f32x4*>(p.gn_ss + ((long)(row / p.rows_per_image) * TC + c * 8) * 2);
@@ -277,11 +302,11 @@ __global__ __launch_bounds__(256, 2) void lin_tile_kernel(TileParams p) {
           }
           ba[t] = (u32x4){pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])};
         }
-        put_tile(TX_OFF, ba);
+        put_tile(TX_OFF, ba, t0);
       } else {
-        put_tile(TX_OFF, ba);                       // (one tile's worth of registers at a time: 128 VGPRs beside the 128 AGPRs)
-        load_tile(p.r1, p.ldr1, row0, ba);
-        put_tile(TB_OFF, ba);
+        put_tile(TX_OFF, ba, t0);
+        load_tile(p.r1, p.ldr1, row0, ba, t0);
+        put_tile(TB_OFF, ba, t0);
       }
     }
     __syncthreads();
@@ -418,7 +443,7 @@ int launch_tile(const TileParams& k, hipStream_t st) {
   int cus = 0;
   if (int rc = hedit_cu_count(&cus)) return rc;
   const int ntiles = cdiv(k.M, TBM);
-  hipLaunchKernelGGL((lin_tile_kernel<NPOST, GNIN>), dim3(ntiles < 2 * cus ? ntiles : 2 * cus), dim3(256), TLDS, st, k);
+  hipLaunchKernelGGL((lin_tile_kernel<NPOST, GNIN>), dim3(ntiles < TBPC * cus ? ntiles : TBPC * cus), dim3(256), TLDS, st, k);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }
@@ -435,7 +460,7 @@ int lin_tile_pack_launch(const float* w, int layer, float scale, int layers, bf1
 }
 
 int lin_tile_launch(const LinChainParams& c, hipStream_t st) {
-  ARG_CHECK(c.C == TC, "lin_tile: exists for C = 320");
+  ARG_CHECK(c.C == TC, "lin_tile: built for another channel count");
   ARG_CHECK(c.M > 0 && c.a && c.stream && c.gamma && c.beta && c.bias_pre && c.out_mid && c.out, "lin_tile: null");
   ARG_CHECK(c.lda % 8 == 0 && c.ldmid % 8 == 0 && c.ldo % 8 == 0, "lin_tile: rows must be 16-byte aligned");
   TileParams k{};
