@@ -20,7 +20,11 @@
  *   hedit_step_update       replaces  the three CFG mixes, correction, L1 reconstruction pull with
  *                                     its two .item() syncs, and the x_{t-1} update
  *                                     (p2p_h_edit.py:654-692; twins :317-353, :494-514, :125-147)
+ *   hedit_unet_set_attn_hook  opens   the reference's hook point for a controller written in the host language: the call
+ *                                     `self.controller(attention_probs, is_cross, self.place_in_unet, save_attn)` of
+ *                                     text-guided/p2p/ptp_utils.py:98-106 on materialised probabilities (slow path)
  *   hedit_local_blend       replaces  LocalBlend.__call__/get_mask (p2p/ptp_classes.py:44-72)
+ *   hedit_local_blend_sub   the same  with substruct_words (p2p/ptp_classes.py:28-38,64-68)
  *   hedit_p2p_plan          carries   the per-call edit rule of the registered controller / editor: Prompt-to-Prompt
  *                                     (ptp_classes.py:194-227), MasaCtrl (masactrl/masactrl.py:53-69: kv_src) and
  *                                     Plug-and-Play (plug_n_play/pnp_utils.py:29-154: qk_first_block, feat_src)
