@@ -34,7 +34,26 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
     for (int j = 0; j < 8; ++j) s[v][j] = q[v][j] = 0.f;
   if (active) {
     const bf16_t* xb = x + (long)b * HW * C;
-    for (int p = p0 + r; p < p1; p += R) {
+    int p = p0 + r;
+    if (CV <= 256) {
+      // (the common shape: one 16-byte chunk per thread and pixel.  Four pixels requested before the first is summed -- the
+      //  sums still take the pixels in order, so the bits are those of the plain loop below)
+      auto acc1 = [&](const uint4& u) __attribute__((always_inline)) {
+        float f[8];
+        unpack8(u, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[0][j] += f[j]; q[0][j] += f[j] * f[j]; }
+      };
+      const bf16_t* xc = xb + cv0 * 8;
+      for (; p + 3 * R < p1; p += 4 * R) {
+        const uint4 u0 = *reinterpret_cast<const uint4*>(xc + (long)p * C);
+        const uint4 u1 = *reinterpret_cast<const uint4*>(xc + (long)(p + R) * C);
+        const uint4 u2 = *reinterpret_cast<const uint4*>(xc + (long)(p + 2 * R) * C);
+        const uint4 u3 = *reinterpret_cast<const uint4*>(xc + (long)(p + 3 * R) * C);
+        acc1(u0); acc1(u1); acc1(u2); acc1(u3);
+      }
+    }
+    for (; p < p1; p += R) {
 #pragma unroll
       for (int v = 0; v < GN_MAXV; ++v) {
         int cv = cv0 + v * 256;
@@ -193,8 +212,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const bf16_t* __rest
   const float4 t2 = {sc[4], sh[4], sc[5], sh[5]}, t3 = {sc[6], sh[6], sc[7], sh[7]};
   const bf16_t* xb = x + (long)b * HW * C + cv * 8;
   bf16_t* yb = y + (long)b * HW * C + cv * 8;
-  for (int p = p0 + r; p < p1; p += R) {
-    uint4 u = *reinterpret_cast<const uint4*>(xb + (long)p * C);
+  auto one = [&](const uint4& u, int p) __attribute__((always_inline)) {
     float f[8];
     unpack8(u, f);
     f[0] = f[0] * t0.x + t0.y; f[1] = f[1] * t0.z + t0.w;
@@ -206,7 +224,18 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const bf16_t* __rest
       for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
     }
     *reinterpret_cast<uint4*>(yb + (long)p * C) = pack8(f);
+  };
+  // four pixels requested before the first is touched: with one 16-byte load in flight per thread the pass left the HBM
+  // queue half empty (element-wise arithmetic unchanged)
+  int p = p0 + r;
+  for (; p + 3 * R < p1; p += 4 * R) {
+    const uint4 u0 = *reinterpret_cast<const uint4*>(xb + (long)p * C);
+    const uint4 u1 = *reinterpret_cast<const uint4*>(xb + (long)(p + R) * C);
+    const uint4 u2 = *reinterpret_cast<const uint4*>(xb + (long)(p + 2 * R) * C);
+    const uint4 u3 = *reinterpret_cast<const uint4*>(xb + (long)(p + 3 * R) * C);
+    one(u0, p); one(u1, p + R); one(u2, p + 2 * R); one(u3, p + 3 * R);
   }
+  for (; p < p1; p += R) one(*reinterpret_cast<const uint4*>(xb + (long)p * C), p);
 }
 
 // ------------------------------------------------------------------ LayerNorm: one wave per row
@@ -680,6 +709,13 @@ int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float
     int ns = (int)(4096 / (B > 0 ? B : 1)) + 1;
     const int max_ns = HW / (R * 8) > 0 ? HW / (R * 8) : 1;
     if (ns > max_ns) ns = max_ns;
+    {
+      // pixels per slab a multiple of the 4 R the unrolled loop takes per trip (speed only: the slabs of this pass only
+      // partition the work, the statistics' slabs are gn_nslab's)
+      int pix = HW / ns / (4 * R) * (4 * R);
+      if (pix < 4 * R) pix = 4 * R;
+      ns = (HW + pix - 1) / pix;
+    }
     hipLaunchKernelGGL(gn_apply_rows_kernel, dim3(ns, B), dim3(256), 0, st, x, y, part, gamma, beta, HW, C, G, nslab, eps, silu, ns);
     LAUNCH_CHECK();
     return HEDIT_OK;
