@@ -26,10 +26,6 @@
 #include "kernels.h"
 #include <type_traits>
 
-// Build-time switches, MEASUREMENT ONLY (tools/build_variant.sh; never defined for the product
-// library): SA_NODMA / SA_NOBAR (self-attention loop without its KV-tile DMA / hand-over barrier),
-// SA_NSTG3 (three-stage ring for every head dim).  Results: DESIGN.md section 5, item 6.
-
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // (not HIP's uint4 struct, which SROA handles badly)
