@@ -209,7 +209,8 @@ class HEditEngine:
         x_prev = torch.empty_like(xt)
         off = None
 
-        foreign = controller is not None and not hasattr(controller, "_plan")
+        from .p2p.ptp_classes import runs_in_python
+        foreign = runs_in_python(controller)
         if foreign:
             # a host-language controller (reference protocol, ptp_classes.py:91-108) sees the reference's batch: one image,
             # rows [null, null, src, tar] -- it slices attn[h // 2:] and reshapes by its own batch_size

@@ -121,6 +121,27 @@ class AttentionControl(abc.ABC):
     def num_uncond_att_layers(self):
         return self.num_att_layers if LOW_RESOURCE else 0
 
+    # ---- the reference's Python protocol (ptp_classes.py:81-108), for controllers that ARE Python: a subclass that
+    # overrides forward() -- the reference's extension point -- has no compiled edit tables, so the UNet hands it the
+    # materialised probabilities of every layer through the executor's hook (hedit/unet.py::forward_hooked) and this
+    # __call__ does the reference's slicing and counting.  hedit's own controllers never define forward(): their edit
+    # runs inside the attention kernels (_plan below).
+    def forward(self, attn, is_cross, place_in_unet, save_attn):
+        raise NotImplementedError
+
+    def __call__(self, attn, is_cross, place_in_unet, save_attn):
+        if self.cur_att_layer >= self.num_uncond_att_layers:
+            h = attn.shape[0]
+            attn[h // 2:] = self.forward(attn[h // 2:], is_cross, place_in_unet, save_attn)    # the conditional half only
+        if not save_attn:
+            return attn
+        self.cur_att_layer += 1
+        if self.cur_att_layer == self.num_att_layers + self.num_uncond_att_layers:
+            self.cur_att_layer = 0
+            self.cur_step += 1
+            self.between_steps()
+        return attn
+
     def step_callback(self, x_t):
         return x_t
 
@@ -397,3 +418,14 @@ def get_equalizer(text, word_select, values, tokenizer):
 
 
 from ..utils.utils import load_512  # noqa: E402,F401  (reference: p2p/ptp_classes.py:351-373)
+
+
+def runs_in_python(controller):
+    """True for a controller the UNet has to call layer by layer on materialised probabilities: anything that is not one
+    of hedit's (no _plan), and a subclass of AttentionControl that overrides the reference's forward()."""
+    if controller is None:
+        return False
+    if not hasattr(controller, "_plan"):
+        return True
+    fwd = getattr(type(controller), "forward", None)
+    return isinstance(controller, AttentionControl) and fwd is not None and fwd is not AttentionControl.forward

@@ -188,7 +188,7 @@ class UNet2DConditionModel:
                     "controller = in-kernel edit, any other callable = hooked through hedit_unet_set_attn_hook); processor "
                     "objects that re-implement the attention body itself cannot be run -- the body is the HIP kernels")
             c = p.controller
-            if c is not None and not hasattr(c, "_plan") and not callable(c):
+            if c is not None and not hasattr(c, "_plan") and not callable(c):      # (hedit's own are callable too)
                 raise TypeError(f"{type(c).__name__}: a foreign controller must be callable as "
                                 "controller(attention_probs, is_cross, place_in_unet, save_attn)")
             self._procs[k] = p
@@ -337,7 +337,8 @@ class UNet2DConditionModel:
             # an attention editor registered on the UNet (MasaCtrl: regiter_attention_editor_diffusers; Plug-and-Play:
             # register_attention_control_efficient / register_conv_control_efficient)
             controller = getattr(self, "_attention_editor", None)
-        if controller is not None and not hasattr(controller, "_plan"):
+        from .p2p.ptp_classes import runs_in_python
+        if runs_in_python(controller):
             return UNetOutput(sample=self.forward_hooked(sample, t, ctx, controller, save_attn))
         plan = None
         if controller is not None:

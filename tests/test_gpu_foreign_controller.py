@@ -210,6 +210,69 @@ def test_sampling_loop_with_a_foreign_controller(tiny):
     assert G.rel_err(e_f, e_n) < 1.2e-1
 
 
+def test_subclass_with_a_python_forward_runs_through_the_hook(tiny):
+    """The reference's extension point: subclass AttentionControl, override forward() (ptp_classes.py:81-108).  hedit's base
+    class does the reference's slicing (conditional half only) and counting; a subclass WITHOUT forward() stays on the fused path."""
+    from hedit.p2p.ptp_classes import AttentionControl, EmptyControl, runs_in_python
+    from hedit.p2p.ptp_utils import register_attention_control
+    hip, om, _ = tiny
+
+    class SwapCross(AttentionControl):
+        """target rows take the source rows' cross maps (what AttentionReplace does with an identity mapper and alpha = 1)"""
+
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+            self.steps_seen = 0
+
+        def forward(self, attn, is_cross, place_in_unet, save_attn):
+            self.seen.append((tuple(attn.shape), is_cross, place_in_unet))
+            if is_cross:
+                h = attn.shape[0] // 2
+                attn = attn.clone()
+                attn[h:] = attn[:h]
+            return attn
+
+        def between_steps(self):
+            self.steps_seen += 1
+
+    c = SwapCross()
+    assert runs_in_python(c) and not runs_in_python(EmptyControl()) and not runs_in_python(None)
+    x, ctx = _inputs(4, TINY_CONFIG, 31)
+    x[2], x[3] = x[0], x[1]
+    heads = TINY_CONFIG["attention_head_dim"]
+    try:
+        register_attention_control(hip, c)
+        got = hip.unet(G.f32(x), 201, encoder_hidden_states=G.f32(ctx)).sample
+        G.sync()
+    finally:
+        _plain(hip)
+    assert len(c.seen) == 22 and all(s[0][0] == 2 * heads for s in c.seen)            # the conditional half: [src, tar] x heads
+    assert (c.cur_step, c.cur_att_layer, c.steps_seen) == (1, 0, 1)
+    # the same edit on the oracle's reference-shaped processor path
+    from oracle import p2p as OP
+
+    class OSwap:
+        num_att_layers = -1
+
+        def __call__(self, probs, is_cross, place, save_attn):
+            if is_cross:
+                h = probs.shape[0]
+                q = h // 4
+                probs[3 * q:] = probs[2 * q:3 * q]
+            return probs
+
+    oc = OSwap()
+    OP.register(om, oc)
+    try:
+        with torch.no_grad():
+            want = om.unet(x, torch.tensor(201), encoder_hidden_states=ctx).sample
+    finally:
+        from oracle.sd_unet import PlainProcessor
+        om.unet.set_attn_processor({k: PlainProcessor() for k in om.unet.attn_processors})
+    assert G.rel_err(got, want) < 2.5e-2
+
+
 def test_a_failing_controller_surfaces_and_the_hook_is_released(tiny, lib):
     hip, _, _ = tiny
     from hedit.p2p.ptp_utils import register_attention_control
