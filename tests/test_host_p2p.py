@@ -205,3 +205,49 @@ def test_word_tokenizer_stable_ids_survive_collisions():
         assert prescan_prompts(b, recs) == 30 and prescan_prompts(c, list(reversed(recs))) == 30
         assert [b.encode(p) for p in prompts] == [c.encode(p) for p in reversed(prompts)][::-1]
     assert prescan_prompts(object(), recs) == 0                                 # real tokenizers: untouched
+
+
+def test_python_controller_protocol_of_the_base_class():
+    """A subclass of hedit's AttentionControl that overrides the reference's forward() (ptp_classes.py:81-108) is a Python
+    controller: the base class's __call__ hands forward() the conditional half only, writes its result back in place and
+    counts layers / steps like the reference; the oracle's controller (pinned on the reference's in g4) counts the same
+    call sequence the same way."""
+    from hedit.p2p.ptp_classes import AttentionControl, AttentionStore, EmptyControl, runs_in_python
+    from oracle import p2p as OP
+
+    class Halve(AttentionControl):
+        def __init__(self):
+            super().__init__()
+            self.calls, self.between = [], 0
+
+        def forward(self, attn, is_cross, place_in_unet, save_attn):
+            self.calls.append((tuple(attn.shape), is_cross, place_in_unet))
+            return attn * 0.5 if is_cross else attn
+
+        def between_steps(self):
+            self.between += 1
+
+    c = Halve()
+    assert runs_in_python(c) and runs_in_python(lambda *a: None)
+    assert not runs_in_python(EmptyControl()) and not runs_in_python(AttentionStore()) and not runs_in_python(None)
+    c.num_att_layers = 3
+    probs = hash_probs((8, 16, 77), 5)
+    before = probs.clone()
+    for i, (is_cross, place) in enumerate(((True, "down"), (False, "mid"), (True, "up"))):
+        ret = c(probs, is_cross, place, True)
+        assert ret is probs
+        assert c.cur_att_layer == (i + 1) % 3
+    assert c.cur_step == 1 and c.between == 1
+    assert [s[0] for s in c.calls] == [(4, 16, 77)] * 3                      # the conditional half
+    assert torch.equal(probs[:4], before[:4])                               # the unconditional half is never touched
+    assert torch.allclose(probs[4:], before[4:] * 0.25)                      # two cross layers, each halved in place
+    # save_attn=False: the edit applies, the counters stand still (ptp_classes.py:100-101)
+    c(probs, True, "down", False)
+    assert (c.cur_step, c.cur_att_layer) == (1, 0) and len(c.calls) == 4
+    # the oracle's controller counts the same way on the same call sequence
+    oc = OP.Controller("store")
+    oc.num_att_layers = 3
+    p2 = before.clone()
+    for is_cross, place in ((True, "down"), (False, "mid"), (True, "up")):
+        oc(p2, is_cross, place, True)
+    assert (oc.cur_step, oc.cur_att_layer) == (1, 0)
