@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
 import torch
 from hedit import _lib
+if os.environ.get("HEDIT_LIB_VARIANT"):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"lib_{os.environ['HEDIT_LIB_VARIANT']}.so.bin")
 lib = _lib.lib()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)

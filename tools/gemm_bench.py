@@ -6,6 +6,8 @@ import ctypes as C
 import torch
 from hedit import _lib
 
+if os.environ.get("HEDIT_LIB_VARIANT"):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"lib_{os.environ['HEDIT_LIB_VARIANT']}.so.bin")
 lib = _lib.lib()
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
