@@ -527,6 +527,8 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
   auto hand_over = [&](int tn) __attribute__((always_inline)) {
     if (tn < ntiles) {
       if (C::PD == 2 && tn + 1 < ntiles) {
+        // (test twin of the schedule, tests/test_gpu_ring_hazard.py: everything in flight lands before the barrier)
+        if (p.test_flags & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // tile tn has landed when at most the DMAs of tile tn+1 are outstanding
         if (my_dma == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else if (my_dma == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
     // (d = 64 keeps the exact pass only: with its 244 registers the two passes' live ranges no longer fit 256)
     constexpr bool CAN_PIN = D != 64;
     int redo = 1;
-    if (CAN_PIN && TU >= 6) {
+    if (CAN_PIN && TU >= 6 && !(p.test_flags & 2)) {
       pass(true_type{});
       bool bad = false;
 #pragma unroll
@@ -1032,7 +1034,9 @@ int attn_apply_launch(const AttnProbsParams& p, hipStream_t st) {
   return HEDIT_OK;
 }
 
-int self_attn_launch(const SelfAttnParams& p, hipStream_t st) {
+int self_attn_launch(const SelfAttnParams& p_in, hipStream_t st) {
+  SelfAttnParams p = p_in;
+  p.test_flags = hedit_test_flags();       // 0 outside tests/test_gpu_ring_hazard.py
   ARG_CHECK(p.N % 64 == 0, "self_attn: N must be a multiple of 64");
   ARG_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldvt % 8 == 0 && p.ldo % 4 == 0, "self_attn: strides");
   switch (p.d) {

@@ -31,6 +31,10 @@ int hedit_abi_catch() noexcept {
   return HEDIT_ERR_STATE;
 }
 
+#include <atomic>
+static std::atomic<int> g_test_flags{0};
+int hedit_test_flags() { return g_test_flags.load(std::memory_order_relaxed); }
+
 namespace {
 std::mutex g_dev_mu;
 std::set<std::pair<const void*, int>> g_lds_set;      // (kernel, device) pairs whose dynamic-LDS limit was raised
@@ -253,6 +257,12 @@ int hedit_k_lin_chain(const void* a, int64_t lda, const void* r1, int64_t ldr1, 
   c.M = M; c.C = C; c.gn_ss = gn_ss; c.rows_per_image = rows_per_image;
   c.out_q = reinterpret_cast<bf16_t*>(out_q); c.ldq = (long)ldq; c.out_k = reinterpret_cast<bf16_t*>(out_k); c.ldk = (long)ldk;
   return lin_chain_launch(c, S(stream));
+} catch (...) { return hedit_abi_catch(); }
+
+int hedit_test_set_flags(int flags) try {
+  ARG_CHECK(flags >= 0 && flags <= 3, "hedit_test_set_flags: bit 0 drained ring waits, bit 1 exact self-attention pass");
+  g_test_flags.store(flags, std::memory_order_relaxed);
+  return HEDIT_OK;
 } catch (...) { return hedit_abi_catch(); }
 
 int hedit_k_lin_chain_sched(const void* a, int64_t lda, const void* r1, int64_t ldr1, const float* gn_ss, int rows_per_image,

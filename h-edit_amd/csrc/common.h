@@ -22,6 +22,11 @@ int hedit_abi_catch() noexcept;
 // behind a mutex; a launch pays one hipGetDevice and a small lookup.
 int hedit_dyn_lds(const void* kernel, int bytes);      // HEDIT_OK, or HEDIT_ERR_HIP with the message set
 int hedit_cu_count(int* cus);                          // CUs of the CURRENT device
+// Test switch (hedit_test_set_flags in include/hedit.h; tests/test_gpu_ring_hazard.py): bit 0 = the kernels with counted
+// vmcnt rings (igemm, ffn_chain, self_attn) run their DRAINED twin -- every ring wait vmcnt(0) --, bit 1 = self-attention
+// takes the exact online-softmax pass only (no pinned-shift pass).  0 in every product path; never read on a device.
+int hedit_test_flags();
+inline bool hedit_test_drained() { return (hedit_test_flags() & 1) != 0; }
 #define HEDIT_OK 0
 #define HEDIT_ERR_ARG (-1)
 #define HEDIT_ERR_HIP (-2)

@@ -243,7 +243,9 @@ __device__ __forceinline__ void gelu_ops(Gelu8& g, const f32x16& Se, const f32x1
   static_for<HI - LO>([&](auto k) { gelu_op<LO + decltype(k)::value>(g, Se, So); });
 }
 
-template <bool PRE, bool POST>
+// DRAIN: the test twin of the wait schedule (tests/test_gpu_ring_hazard.py) -- every ring hand-over waits vmcnt(0) lgkmcnt(0)
+// and every in-iteration fragment wait lgkmcnt(0); same arithmetic, same order.
+template <bool PRE, bool POST, bool DRAIN = false>
 __global__ __launch_bounds__(256, 1) void ffn_chain_kernel(ChainKernelParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256, 1) void ffn_chain_kernel(ChainKernelParams p) 
   int frag_rd = lane * 16;                   // LDS address of this lane's 16 bytes in fragment 0 of the current bank
   int bias_rd = BIAS_OFF + hi * 64;          // accumulator start of the NEXT FF1 pair to be fetched
   auto boundary = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"((AHEAD - 2) * PPW), "n"(LEAD) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"(DRAIN ? 0 : (AHEAD - 2) * PPW), "n"(DRAIN ? 0 : LEAD) : "memory");
   };
   // LDS offset of the fragment MFMA j of an iteration uses.  Linear layer: stored in MFMA order.  Feed-forward (MFMA
   // order: two FF1 k-steps, one FF2 output block, ten times): FF1 k-steps 0..19, then the FF2 blocks.
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(256, 1) void ffn_chain_kernel(ChainKernelParams p) 
     static_for<CNT>([&](auto b_) {
       constexpr int b = decltype(b_)::value;
       constexpr int jg = IDX * NB + b;
-      if constexpr (b % 3 == 0) __builtin_amdgcn_s_waitcnt(0xC07F | ((LEAD - 3) << 8));
+      if constexpr (b % 3 == 0) __builtin_amdgcn_s_waitcnt(0xC07F | ((DRAIN ? 0 : LEAD - 3) << 8));
       mfma_l(O[jg % FNB], fr[b], Xn[jg / FNB]);
       if constexpr (b + LEAD < CNT) fr[b + LEAD] = rd(base, false, b + LEAD);
       else pre[b + LEAD - CNT] = rd(nbase, NEXT_FF, b + LEAD - CNT);
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(256, 1) void ffn_chain_kernel(ChainKernelParams p) 
       constexpr int b = decltype(b_)::value;
       // one counted wait per three MFMAs instead of the compiler's one per MFMA: the fragments of bundles b .. b+2 have
       // arrived when at most the LEAD - 3 youngest LDS reads are outstanding (s_waitcnt lgkmcnt only: vmcnt / expcnt at max)
-      if constexpr (b % 3 == 0) __builtin_amdgcn_s_waitcnt(0xC07F | ((LEAD - 3) << 8));
+      if constexpr (b % 3 == 0) __builtin_amdgcn_s_waitcnt(0xC07F | ((DRAIN ? 0 : LEAD - 3) << 8));
       if constexpr (b % 3 < 2) {
         constexpr int ks = 2 * (b / 3) + b % 3;
         if constexpr (F1) {
@@ -637,6 +639,12 @@ int ffn_pack_bias_launch(const float* b1, float* out, hipStream_t st) {
 
 template <bool PRE, bool POST>
 static int launch_chain(const ChainKernelParams& k, hipStream_t st) {
+  if (hedit_test_drained()) {
+    if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&ffn_chain_kernel<PRE, POST, true>), LDS_TOTAL)) return rc;
+    hipLaunchKernelGGL((ffn_chain_kernel<PRE, POST, true>), dim3(cdiv(k.M, BLOCK_ROWS)), dim3(256), LDS_TOTAL, st, k);
+    LAUNCH_CHECK();
+    return HEDIT_OK;
+  }
   if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&ffn_chain_kernel<PRE, POST>), LDS_TOTAL)) return rc;
   hipLaunchKernelGGL((ffn_chain_kernel<PRE, POST>), dim3(cdiv(k.M, BLOCK_ROWS)), dim3(256), LDS_TOTAL, st, k);
   LAUNCH_CHECK();

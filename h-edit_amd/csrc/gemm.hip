@@ -58,7 +58,10 @@ struct Smem {
 // and restart from zero -- which is bit for bit what the split-K path computes (one chunk per slab, slabs
 // added in order by splitk_reduce_kernel).  The result of a layer therefore does not depend on whether a
 // launch was large enough to skip the split, i.e. not on the batch.
-template <int BM, int BN, int MODE, bool CHUNK>
+// DRAIN (tests/test_gpu_ring_hazard.py only): every counted wait of the operand rings becomes vmcnt(0) -- same arithmetic in
+// the same order, but nothing in LDS is read while any DMA of the wave is in flight.  Its output is the reference the
+// product schedule (DRAIN = false) must reproduce bit for bit under memory load (the protocol that found round 3's race).
+template <int BM, int BN, int MODE, bool CHUNK, bool DRAIN = false>
 __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = BM * 2;       // threads: 4 or 8 waves, each owning a 64 x BN/2 sub-tile
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     w_fire(1, 1);
     a_prep(1, 0, asrc); a_fire(1, 0, asrc);
     w_fire(2, 2);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * W_CH + 2) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DRAIN ? 0 : (2 * W_CH + 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     read_a(0, 0, 0, xa);
     read_w(0, 0, wa);
@@ -413,10 +416,10 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       __builtin_amdgcn_s_setprio(0);
       if (steady) {
         // my DMAs of K-tile j+1 have landed: only the slot issued during K-tile j-1 may still be in flight
-        if (col == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(W_CH) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(W_CH + 2) : "memory");
+        if (col == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (W_CH)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (W_CH + 2)) : "memory");
       } else if (col == 0) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(W_CH + 2) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (W_CH + 2)) : "memory");
       } else if (col == 1) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
@@ -495,8 +498,8 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
     };
     for (int t = 0; t < 3 && t < nk; ++t) issue_glds(kt_begin + t, t);
     if (nk > 0) {
-      if (nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
-      else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      if (nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DRAIN ? 0 : (2 * NDMA)) : "memory");
+      else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DRAIN ? 0 : (NDMA)) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       read_frags(0, 0, xa, wa);
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
         __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);      // pointer arithmetic
       }
       __builtin_amdgcn_s_setprio(0);
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (NDMA)) : "memory");
       __builtin_amdgcn_s_setprio(1);
       read_frags(nx, 0, xa, wa);
       fire_dma(cur, nsrc);
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       mfmas(xa, wa);
       __builtin_amdgcn_s_setprio(0);
       if (j + 1 < nk) {
-        if (j + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA) : "memory");
+        if (j + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (NDMA)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         read_frags(nx, 0, xa, wa);
       }
@@ -868,8 +871,18 @@ template <int BM, int BN, int MODE, bool CHUNK>
 int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
   using S = Smem<BM, BN>;
   constexpr int LDS = (MODE == 4 || MODE == 5) ? S::RS_TOTAL : S::TOTAL;
-  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK>), LDS)) return rc;
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), splits);
+  // (only the loops with counted waits have a drained twin: the two-stage loop waits vmcnt(0) as it is)
+  constexpr bool COUNTED = MODE == 4 || MODE == 5 || S::STAGES == 3;
+  if constexpr (COUNTED) {
+    if (hedit_test_drained()) {
+      if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK, true>), LDS)) return rc;
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, CHUNK, true>), grid, dim3(BM * 2), LDS, st, p);
+      LAUNCH_CHECK();
+      return HEDIT_OK;
+    }
+  }
+  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK>), LDS)) return rc;
   hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, CHUNK>), grid, dim3(BM * 2), LDS, st, p);
   LAUNCH_CHECK();
   return HEDIT_OK;

@@ -177,6 +177,7 @@ struct SelfAttnParams {
   int B, N, heads, d;
   const int* qk_src;            // [B] batch index whose q,k are used (P2P self-replace) or null
   const int* kv_src;            // [B] batch index whose k,v are used (MasaCtrl mutual self-attention) or null
+  int test_flags;               // hedit_test_flags() at launch (0 in the product): bit 0 drained ring waits, bit 1 exact pass only
 };
 int self_attn_launch(const SelfAttnParams& p, hipStream_t st);
 

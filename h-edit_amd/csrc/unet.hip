@@ -624,6 +624,9 @@ int forward_impl(hedit_unet* h, const float* x, float t, const float* ctx, int B
   RUN(f, ctx_pad_launch(ctx, ctxb, B, c.cross_attention_dim, st));
   f.ctxb = ctxb;
   {
+    // attn2 keys / values of ALL transformer blocks, two launches; they stay live for the whole pass (the blocks read
+    // their column / row slice): 2 * B * 80 * ctx_n * 2 bytes of workspace = 4 MB per batch row for SD-1.5 (ctx_n = 12480),
+    // 0.48 GB at the bench's 120 rows, accounted for by hedit_unet_workspace_bytes like every other arena allocation
     const int MC = B * HEDIT_CTXP;
     bf16_t *k2a, *vt2a;
     TRY(aalloc(f, &k2a, (size_t)MC * h->ctx_n));
@@ -898,6 +901,11 @@ int hedit_unet_create(const hedit_unet_cfg* cfg, hedit_unet** out) try {
     h->iota = dalloc<int32_t>(h, IOTA);
     if (h->iota && hipMemcpy(h->iota, v.data(), IOTA * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) h->iota = nullptr;
     h->iota_cap = h->iota ? IOTA : 0;
+  }
+  if (h->ctx_next != h->ctx_n) {      // every block must have taken exactly its slice of the stacked attn2.to_k / to_v matrices
+    hedit_set_error("internal: stacked context-projection plan mismatch");
+    delete h;
+    return HEDIT_ERR_STATE;
   }
   if (toff != total) {
     hedit_set_error("internal: time-embedding plan mismatch");

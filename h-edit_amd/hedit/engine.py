@@ -219,6 +219,11 @@ class HEditEngine:
                                  "(it sees the reference's 4-row batch)")
             if not callable(controller):
                 raise TypeError("a foreign controller must be callable as controller(attn, is_cross, place_in_unet, save_attn)")
+        # (decided before the first -- slow, hooked -- sampler step: a plain callable without the reference's step_callback
+        #  is a controller that does nothing between steps, not an AttributeError after the first step)
+        step_cb = getattr(controller, "step_callback", None) if controller is not None else None
+        if step_cb is not None and not callable(step_cb):
+            raise TypeError("controller.step_callback must be callable as step_callback(x_t) -> x_t")
 
         def p2p_pass(x_in, t, save):
             rows = x_in.shape[0]
@@ -298,8 +303,8 @@ class HEditEngine:
                     x_k = new
 
             xt = torch.cat([x_orig, x_k]).contiguous()
-            if controller is not None:
-                xt = controller.step_callback(xt)
+            if step_cb is not None:
+                xt = step_cb(xt)
         return xt[n:].clone(), xt[:n].clone()
 
     # ------------------------------------------------------------------ Plug-and-Play loop

@@ -81,7 +81,7 @@ def _blend_launch(x_t, maps, blends, n_img):
     alpha = torch.zeros(n_img, 2, MAX_NUM_WORDS)
     sub = torch.zeros(n_img, 2, MAX_NUM_WORDS)
     enabled = torch.zeros(n_img, dtype=torch.int32)
-    th = None
+    th0 = th1 = None
     has_sub = False
     for i, lb in enumerate(blends):
         if lb is not None:
@@ -90,10 +90,14 @@ def _blend_launch(x_t, maps, blends, n_img):
                 sub[i] = lb.substruct_layers.reshape(2, MAX_NUM_WORDS).cpu()
                 has_sub = True
             enabled[i] = 1
-            if th is not None and (float(lb.th[0]), float(lb.th[1])) != th:
-                raise ValueError("LocalBlend thresholds differ inside one lock-step batch (the blend kernel takes one pair)")
-            th = (float(lb.th[0]), float(lb.th[1]))
-    th = (0.3, 0.3) if th is None else th
+            if th0 is not None and float(lb.th[0]) != th0:
+                raise ValueError("LocalBlend thresholds differ inside one lock-step batch (the blend kernel takes one value)")
+            th0 = float(lb.th[0])
+            if lb.substruct_layers is not None:      # th[1] is read for images with substruct words only
+                if th1 is not None and float(lb.th[1]) != th1:
+                    raise ValueError("LocalBlend substruct thresholds differ inside one lock-step batch")
+                th1 = float(lb.th[1])
+    th = (0.3 if th0 is None else th0, 0.3 if th1 is None else th1)
     alpha = alpha.to(x_t.device)
     enabled = enabled.to(x_t.device)
     arr = (C.c_void_p * len(maps))(*[m.data_ptr() for m in maps])
@@ -253,6 +257,28 @@ class AttentionStore(AttentionControl):
             for b in self._state.bufs:
                 b.zero_()
 
+    # ---- the reference's Python protocol, for SUBCLASSES that override forward() and call super().forward(...) (the
+    # reference's extension idiom, ptp_classes.py:135-150): such a controller runs on the hook path, where nothing
+    # compiles a plan, so the store has to be kept here.  On the fused path forward() is never called and step_store
+    # stays empty (the kernels accumulate into _PlanState.bufs), which makes between_steps() a no-op there.
+    def forward(self, attn, is_cross, place_in_unet, save_attn=True):
+        if save_attn and attn.shape[1] <= 32 ** 2:
+            # the tensor itself, not a copy: an edit applied to it afterwards is what gets accumulated, as in the reference
+            self.step_store[f"{place_in_unet}_{'cross' if is_cross else 'self'}"].append(attn)
+        return attn
+
+    def between_steps(self):
+        if not any(self.step_store.values()):
+            return
+        if not self.attention_store:
+            self.attention_store = self.step_store
+        else:
+            for key, maps in self.step_store.items():
+                acc = self.attention_store[key]
+                for i, m in enumerate(maps):
+                    acc[i] += m
+        self.step_store = self.get_empty_store()
+
     # ---- plan protocol
     def _members(self):
         return [self]
@@ -308,6 +334,24 @@ class AttentionControlEdit(AttentionStore, abc.ABC):
             x_t = self.local_blend(x_t, self.attention_store)
         return x_t
 
+    def forward(self, attn, is_cross, place_in_unet, save_attn):
+        """The reference's per-layer edit on a materialised map (ptp_classes.py:202-227), for subclasses that extend it
+        through super().forward(...) on the hook path.  attn: the conditional half [source heads | target heads] of one
+        layer, edited in place."""
+        super().forward(attn, is_cross, place_in_unet, save_attn)
+        lo, hi = self.num_self_replace
+        if not is_cross and not (lo <= self.cur_step < hi):
+            return attn
+        heads = attn.shape[0] // self.batch_size
+        src, tar = attn[:heads], attn[heads:]
+        if is_cross:
+            a = self.cross_replace_alpha[self.cur_step].to(device=attn.device, dtype=attn.dtype)[0]       # (1, 1, 77)
+            mixed = self.replace_cross_attention(src, tar[None])[0]
+            tar.copy_(mixed * a + (1 - a) * tar)
+        elif attn.shape[1] <= 32 ** 2:               # self maps above 32 x 32 keep the target's own attention
+            tar.copy_(src)
+        return attn
+
     def _self_window(self):
         return self.num_self_replace
 
@@ -330,6 +374,12 @@ class AttentionControlEdit(AttentionStore, abc.ABC):
         return A_s, b_s
 
 
+def _like(table, ref):
+    """A host-side table on the device / dtype of the map it is applied to (the tables live on the CPU: the fused path only
+    ever reads them there, the hook path applies them to device tensors)."""
+    return table.to(device=ref.device, dtype=ref.dtype)
+
+
 class AttentionReplace(AttentionControlEdit):
     def __init__(self, prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend=None,
                  tokenizer=None, device=None):
@@ -337,7 +387,7 @@ class AttentionReplace(AttentionControlEdit):
         self.mapper = seq_aligner.get_replacement_mapper(prompts, self.tokenizer)
 
     def replace_cross_attention(self, attn_base, att_replace):
-        return torch.einsum("hpw,bwn->bhpn", attn_base, self.mapper)
+        return torch.einsum("hpw,bwn->bhpn", attn_base, _like(self.mapper, attn_base))
 
 
 class AttentionRefine(AttentionControlEdit):
@@ -348,8 +398,9 @@ class AttentionRefine(AttentionControlEdit):
         self.alphas = alphas.reshape(alphas.shape[0], 1, 1, alphas.shape[1])
 
     def replace_cross_attention(self, attn_base, att_replace):
-        base = attn_base[:, :, self.mapper].permute(2, 0, 1, 3)
-        return base * self.alphas + att_replace * (1 - self.alphas)
+        base = attn_base[:, :, self.mapper.to(attn_base.device)].permute(2, 0, 1, 3)
+        al = _like(self.alphas, attn_base)
+        return base * al + att_replace * (1 - al)
 
 
 class AttentionReweight(AttentionControlEdit):
@@ -360,10 +411,10 @@ class AttentionReweight(AttentionControlEdit):
         self.prev_controller = controller
 
     def replace_cross_attention(self, attn_base, att_replace):
+        eq = _like(self.equalizer, attn_base)[:, None, None, :]
         if self.prev_controller is not None:
-            attn_base = self.prev_controller.replace_cross_attention(attn_base, att_replace)
-            return attn_base * self.equalizer[:, None, None, :]
-        return attn_base[None, :, :, :] * self.equalizer[:, None, None, :]
+            return self.prev_controller.replace_cross_attention(attn_base, att_replace) * eq
+        return attn_base[None, :, :, :] * eq
 
 
 class ControllerBatch(AttentionStore):
@@ -427,5 +478,8 @@ def runs_in_python(controller):
         return False
     if not hasattr(controller, "_plan"):
         return True
-    fwd = getattr(type(controller), "forward", None)
-    return isinstance(controller, AttentionControl) and fwd is not None and fwd is not AttentionControl.forward
+    if not isinstance(controller, AttentionControl):
+        return False
+    # hedit's own classes keep the reference's forward() only as the base of such subclasses; their edit runs in-kernel
+    own = {AttentionControl.forward, AttentionStore.forward, AttentionControlEdit.forward}
+    return getattr(type(controller), "forward", AttentionControl.forward) not in own

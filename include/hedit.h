@@ -330,6 +330,14 @@ int hedit_k_lin_chain_sched(const void* a, int64_t lda, const void* r1, int64_t 
                             const float* bias_pre, const float* gamma, const float* beta, float eps, const void* w_stream, void* out_mid,
                             int64_t ldmid, void* out_q, int64_t ldq, void* out_k, int64_t ldk, void* out, int64_t ldo, int M, int C,
                             int sched, void* stream);
+/* Test switch (tests/test_gpu_ring_hazard.py), process-wide, 0 by default and in every product path.
+ * bit 0: the kernels whose operand rings are retired by COUNTED s_waitcnt vmcnt(N) -- igemm_kernel's three-stage ring and
+ *        row-sharing 3x3 loop, ffn_chain_kernel, self_attn_kernel -- launch their drained twin: every ring wait is vmcnt(0)
+ *        (and lgkmcnt(0)) in front of its barrier, same arithmetic in the same order.  The product schedule must reproduce
+ *        those bits under any memory load.  (lin_chain_kernel has its own entry above.)
+ * bit 1: self-attention takes the exact online-softmax pass only (no pinned-shift pass) -- the reference bits of the
+ *        denominator-check / redo logic. */
+int hedit_test_set_flags(int flags);
 size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C);
 int hedit_k_groupnorm_affine(const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, void* ws,
                              float* ss_out, void* stream);

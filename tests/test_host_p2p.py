@@ -251,3 +251,78 @@ def test_python_controller_protocol_of_the_base_class():
     for is_cross, place in ((True, "down"), (False, "mid"), (True, "up")):
         oc(p2, is_cross, place, True)
     assert (oc.cur_step, oc.cur_att_layer) == (1, 0)
+
+
+@pytest.mark.parametrize("pi", range(len(PROMPT_PAIRS)))
+def test_subclass_calling_super_forward_reproduces_reference_controller(golden_dir, pi):
+    """The reference's extension idiom -- subclass AttentionStore / AttentionReplace / AttentionRefine / AttentionReweight,
+    override forward() and call super().forward(...) (ptp_classes.py:135-150, 202-227) -- runs on the hook path, where the
+    edit has to happen in Python.  Driven with the call sequence that produced g4 (the reference's own controllers), the
+    edited target rows, the untouched rows, the counters and the stored map must match the reference's."""
+    from hedit.p2p import ptp_classes as PC
+    g = _npz(golden_dir, "g4_controller.npz")
+    info = _json(golden_dir, "g4_controller.json")["pairs"][pi]
+    tok = WordTokenizer(split_long_words_at=6)
+    base = make(PROMPT_PAIRS[pi], 50, info["eq_val"], tok)
+    seen = []
+
+    def fwd(self, attn, is_cross, place_in_unet, save_attn):
+        seen.append((is_cross, place_in_unet))
+        return super(Sub, self).forward(attn, is_cross, place_in_unet, save_attn)
+    Sub = type("Sub", (type(base),), {"forward": fwd})
+    c = base
+    c.__class__ = Sub                         # same tables, the subclass's forward()
+    assert PC.runs_in_python(c) and not PC.runs_in_python(make(PROMPT_PAIRS[pi], 50, info["eq_val"], tok))
+    c.num_att_layers = 4
+    heads = info["heads"]
+    for cur_step in (0, 16, 17, 19, 20, 49):
+        c.cur_step, c.cur_att_layer = cur_step, 0
+        c.step_store, c.attention_store = c.get_empty_store(), {}
+        for li, (is_cross, place, n) in enumerate(info["layers"]):
+            probs = hash_probs((4 * heads, n, 77 if is_cross else n), 100000 + pi * 1000 + cur_step * 10 + li)
+            before = probs.clone()
+            c(probs, is_cross, place, True)
+            want = torch.from_numpy(g[f"p{pi}_s{cur_step}_l{li}_tar"])
+            assert (probs[3 * heads:] - want).abs().max().item() <= 2e-6, (cur_step, li)
+            assert torch.equal(probs[:3 * heads], before[:3 * heads])
+        assert [c.cur_step, c.cur_att_layer] == info["after"][str(cur_step)]
+        assert {k: len(v) for k, v in c.attention_store.items()} == info["store_counts"][str(cur_step)]
+        assert (c.attention_store["down_cross"][0] - torch.from_numpy(g[f"p{pi}_s{cur_step}_store_down_cross0"])).abs().max() <= 2e-6
+    # save_attn=False: the edit applies, nothing is stored, the counters stand still
+    c.cur_step, c.cur_att_layer = 3, 0
+    c.step_store, c.attention_store = c.get_empty_store(), {}
+    probs = hash_probs((4 * heads, 16, 77), 900000 + pi)
+    c(probs, True, "down", False)
+    assert (probs[3 * heads:] - torch.from_numpy(g[f"p{pi}_nosave_tar"])).abs().max().item() <= 2e-6
+    assert [c.cur_step, c.cur_att_layer, sum(len(v) for v in c.step_store.values())] == info["nosave_after"]
+    assert len(seen) == 6 * 4 + 1
+
+
+def test_store_subclass_accumulates_over_steps_like_the_reference():
+    """AttentionStore.forward / between_steps on the hook path: maps of <= 32 x 32 tokens are summed over steps per layer
+    (ptp_classes.py:135-150); the fused path never fills step_store, so between_steps is a no-op there."""
+    from hedit.p2p.ptp_classes import AttentionStore, runs_in_python
+    from oracle import p2p as OP
+
+    class Keep(AttentionStore):
+        def forward(self, attn, is_cross, place_in_unet, save_attn=True):
+            return super().forward(attn, is_cross, place_in_unet, save_attn)
+
+    c, oc = Keep(), OP.Controller("store")
+    assert runs_in_python(c)
+    c.num_att_layers = oc.num_att_layers = 3
+    for step in range(3):
+        for li, (is_cross, place, n) in enumerate(((True, "down", 16), (False, "mid", 40 * 40), (True, "up", 32))):
+            probs = hash_probs((4, n, 77 if is_cross else 8), 7000 + 10 * step + li)
+            p2 = probs.clone()
+            c(probs, is_cross, place, True)
+            oc(p2, is_cross, place, True)
+    assert c.cur_step == oc.cur_step == 3
+    assert {k: len(v) for k, v in c.attention_store.items()} == {k: len(v) for k, v in oc.attention_store.items()}
+    assert len(c.attention_store["mid_self"]) == 0                     # 1600 tokens: above the 32 x 32 limit
+    for k in c.attention_store:
+        for a, b in zip(c.attention_store[k], oc.attention_store[k]):
+            assert torch.equal(a, b)
+    plain = AttentionStore()
+    plain.between_steps()                                              # fused path: nothing in step_store, nothing happens
+    assert plain.attention_store == {}

@@ -1,0 +1,149 @@
+"""CPU (no GPU): audit of the gfx950 ISA of every kernel whose LDS-DMA ring is retired by counted ``s_waitcnt vmcnt(N)``.
+
+Round 3's race was a wait whose count included 19 DMA instructions the compiler had deleted (identical place-holder LDS-DMAs
+are dead stores to LLVM).  A counted wait is only as good as the number of VMEM instructions that really are in the object
+code, so this test compiles the four units to assembly (device pass only, no GPU needed) and checks, per kernel,
+
+  * the number of LDS-DMA instructions against what the source's loop structure issues (nothing merged, nothing dropped),
+  * that the counted waits carry exactly the immediates the source asks for,
+  * that a kernel and its drained test twin (tests/test_gpu_ring_hazard.py, test_gpu_chain_hazard.py) contain the SAME number
+    of DMA instructions and that the twin has no counted ring wait left.
+"""
+import os
+import re
+import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "h-edit_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result", "--cuda-device-only", "-S"]
+UNIT_FLAGS = {"attn": ["-fno-honor-nans"], "ffn": ["-fno-honor-nans"]}          # as h-edit_amd/build.py
+
+
+def _stats(path):
+    cur, out = None, {}
+    for line in open(path):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = m.group(1)
+            out[cur] = {"dma": 0, "waits": {}}
+            continue
+        if cur is None:
+            continue
+        if re.search(r"buffer_load_dwordx4.* lds", line) or "global_load_lds" in line:
+            out[cur]["dma"] += 1
+        m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", line)
+        if m:
+            n = int(m.group(1))
+            out[cur]["waits"][n] = out[cur]["waits"].get(n, 0) + 1
+    return out
+
+
+@pytest.fixture(scope="module")
+def isa():
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    tmp = tempfile.mkdtemp(prefix="hedit_isa_")
+
+    def cc(unit):
+        out = os.path.join(tmp, unit + ".s")
+        r = subprocess.run([HIPCC] + FLAGS + UNIT_FLAGS.get(unit, []) + ["-o", out, os.path.join(SRC, unit + ".hip")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return unit, _stats(out)
+    with ThreadPoolExecutor(4) as ex:
+        return dict(ex.map(cc, ["gemm", "ffn", "attn", "linchain"]))
+
+
+def _igemm(isa):
+    out = {}
+    for name, st in isa["gemm"].items():
+        m = re.search(r"igemm_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
+        if m:
+            bm, bn, mode, chunk, drain = (int(v) for v in m.groups())
+            out[(bm, bn, mode, chunk, drain)] = st
+    return out
+
+
+def test_igemm_rings_issue_every_dma_the_waits_count(isa):
+    ks = _igemm(isa)
+    seen_ring = seen_rs = 0
+    for (bm, bn, mode, chunk, drain), st in ks.items():
+        if bm != 256 or bn > 160 or drain:
+            continue
+        w_ch = (bn // 8 + 7) // 8                    # weight DMA instructions per wave and K-tile (8 waves)
+        counted = {n: c for n, c in st["waits"].items() if n >= w_ch}
+        if mode in (4, 5):
+            # prologue: act(0) 4 | w(0..2) 3 W | act(1) first half 2;  steady 3 tiles: 3 W + 2 halves x 2;  one dummy half past the end
+            assert st["dma"] == (4 + 3 * w_ch + 2) + (3 * w_ch + 4) + 2, ((bm, bn, mode, chunk), st)
+            assert counted == {w_ch: 1, w_ch + 2: 3, 2 * w_ch + 2: 1}, ((bm, bn, mode, chunk), st)
+            seen_rs += 1
+        else:
+            ndma = 4 + w_ch                            # three-stage ring: one K-tile = 4 activation + W_CH weight instructions
+            assert st["dma"] % ndma == 0 and st["dma"] >= 2 * ndma, ((bm, bn, mode, chunk), st)
+            assert counted == {ndma: 3, 2 * ndma: 1}, ((bm, bn, mode, chunk), st)
+            seen_ring += 1
+        twin = ks.get((bm, bn, mode, chunk, 1))
+        assert twin is not None, f"no drained twin of igemm<{bm},{bn},{mode},{chunk}>"
+        assert twin["dma"] == st["dma"], "the drained twin must issue the same DMA instructions"
+        assert not [n for n in twin["waits"] if n >= w_ch], ("drained twin still has a counted ring wait", twin)
+    assert seen_ring >= 12 and seen_rs >= 6
+    # the two-stage loops (128-row tile, 256 x 256 GEGLU tile) wait vmcnt(0) only and have no twin
+    for (bm, bn, mode, chunk, drain), st in ks.items():
+        if bm == 128 or bn == 256:
+            assert not drain
+            assert max(st["waits"]) <= 4, st           # (the compiler's own small waits around the residual loads of the fold)
+
+
+def test_ffn_chain_ring(isa):
+    ks = {}
+    for name, st in isa["ffn"].items():
+        m = re.search(r"ffn_chain_kernelILb([01])ELb([01])ELb([01])E", name)
+        if m:
+            ks[tuple(int(v) for v in m.groups())] = st
+    assert len(ks) == 4
+    for outer in (0, 1):
+        prod, twin = ks[(outer, outer, 0)], ks[(outer, outer, 1)]
+        assert prod["dma"] == twin["dma"] and (prod["dma"] - 1) % 8 == 0        # 8 pieces per wave and iteration + the bias image
+        iters = (prod["dma"] - 1) // 8
+        # hand-over of every iteration but the drained ones: vmcnt((AHEAD - 2) * PPW) = 16
+        assert prod["waits"].get(16, 0) >= iters - 4, prod
+        assert twin["waits"].get(16, 0) < prod["waits"][16] - (iters - 5), twin   # what is left are the compiler's own waits
+
+
+def test_self_attention_ring(isa):
+    seen = 0
+    for name, st in isa["attn"].items():
+        m = re.search(r"self_attn_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name)
+        if not m:
+            continue
+        d = int(m.group(1))
+        ti = 2 * (d // 8)                            # 1 KiB DMA instructions per KV tile (K + V^T)
+        ni = (ti + 3) // 4                           # per wave
+        assert st["dma"] % ni == 0 and st["dma"] >= 2 * ni, (d, st)
+        if d in (32, 40, 64):                        # ring of four, two tiles ahead: the hand-over tolerates one tile = NI
+            assert st["waits"].get(ni, 0) >= 2, (d, st)
+        seen += 1
+    assert seen == 5
+
+
+def test_lin_chain_twins(isa):
+    ks = {}
+    for name, st in isa["linchain"].items():
+        m = re.search(r"lin_chain_kernelILi(\d+)ELb([01])ELb([01])ELb([01])ELi(\d+)E", name)
+        if m:
+            ks[tuple(int(v) for v in m.groups())] = st
+    pairs = 0
+    for key, st in ks.items():
+        if key[-1] != 0:
+            continue
+        twin = ks.get(key[:-1] + (1,))
+        assert twin is not None and twin["dma"] == st["dma"], key
+        assert max(twin["waits"]) <= 3, twin         # drained: only the compiler's waits for its own row loads
+        assert st["waits"].get(12, 0) >= 32, st      # the ring's steady-state window
+        pairs += 1
+    assert pairs >= 3
