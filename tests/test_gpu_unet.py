@@ -121,15 +121,13 @@ def test_sd15_unet_forward_full_size():
     assert err < TOL_SD, err
     assert len(hip.unet.attn_processors) == 32
     assert sum(int(torch.tensor(s).prod()) for s in hip.unet.param_shapes.values()) == 859520964
-    # Where the error comes from: the same fp32 oracle with bf16 STORAGE emulated -- weights rounded to bf16 and the output
-    # of every leaf module (conv, linear, norm) rounded to bf16, arithmetic still fp32 -- lands as far from the fp32 result
-    # as the HIP path does.  I.e. the tolerance above is the price of BASELINE's bf16 tensors, not of the kernels; the
-    # fused chains (fp32 intermediates in registers) can only be on the better side of it.  Measured on MI355X / this seed:
-    # HIP 1.16e-2 against 1.10e-2 for the emulation.
-    # Three storage emulations of the fp32 oracle on the same inputs (arithmetic fp32 throughout), MI355X / this seed:
-    #   bf16 everywhere (weights, leaf outputs AND the residual-stream sums -- the HIP path's storage model)   see print
-    #   bf16 leaves, fp32 residual stream (what keeping t0 / t1 / the skip sums in fp32 would buy)
-    #   fp16 everywhere (same MFMA rate, 3 more mantissa bits)
+    # Where the error comes from: the same fp32 oracle with a STORAGE format emulated -- weights, the output of every leaf module
+    # (conv, linear, norm) and every residual-stream sum rounded, arithmetic still fp32 -- on the same inputs.  Measured on
+    # MI355X / this seed:
+    #   HIP path                                                              1.16e-2
+    #   bf16 everywhere (the HIP path's storage model)                        1.32e-2   <- the tolerance is the price of BASELINE's
+    #   bf16 leaves, fp32 residual stream (t0 / t1 / skip sums kept in fp32)  1.09e-2      bf16 tensors, not of the kernels: the fused
+    #   fp16 everywhere (same MFMA rate, 3 more mantissa bits)                1.72e-3      chains sit on the better side of it
     from oracle import sd_unet as OSU
     w_fp32 = [p_.detach().clone() for p_ in om.unet.parameters()]
 
