@@ -917,20 +917,32 @@ int launch_cross(const CrossAttnParams& p, hipStream_t st) {
 //
 // probs: one block = 16 queries of one (batch row, head).  Scores in log2 units (Q is pre-scaled), softmax over the keys
 // in three passes over the block's own 16 rows of the output.
+// STORE = the fused path's <= 32 x 32 SELF maps (AttentionStore on save_attn passes, ptp_classes.py:135-150): the block's 16
+// score rows live in LDS (M <= 1024: 64 KB), the probabilities of the conditional rows -- pair p's source and target row,
+// the target reading the source's q and k inside the self-replace window (qk_src) -- are ADDED to the store
+// [n_pairs][2][heads][N][M] (the sum over steps the reference's between_steps forms); nothing else is written.
+template <bool STORE>
 __global__ __launch_bounds__(256) void attn_probs_kernel(AttnProbsParams p) {
   __shared__ float qs[16][168];
-  const int bh = blockIdx.y, b = bh / p.heads, h = bh % p.heads;
+  extern __shared__ float sc_rows[];             // STORE: [16][M]
+  const int bh = blockIdx.y, h = bh % p.heads;
+  int b = bh / p.heads;
+  if constexpr (STORE) {
+    const int pair = b >> 1;
+    b = (b & 1) ? p.pair_tar[pair] : p.pair_src[pair];
+  }
+  const int bq = (STORE && p.qk_src) ? p.qk_src[b] : b;        // whose q and k this row attends with
   const int q0 = blockIdx.x * 16, tid = threadIdx.x;
   for (int i = tid; i < 16 * p.d; i += 256) {
     const int r = i / p.d, c = i % p.d;
     const int q = q0 + r;
-    qs[r][c] = q < p.N ? bf16_to_f32(p.q[((long)b * p.N + q) * p.ldq + h * p.d + c]) : 0.f;
+    qs[r][c] = q < p.N ? bf16_to_f32(p.q[((long)bq * p.N + q) * p.ldq + h * p.d + c]) : 0.f;
   }
   __syncthreads();
-  float* out = p.probs + ((long)bh * p.N + q0) * p.M;
+  float* out = STORE ? sc_rows : p.probs + ((long)bh * p.N + q0) * p.M;
   const int rows = min(16, p.N - q0);
   for (int m = tid; m < p.M; m += 256) {
-    const bf16_t* kp = p.k + ((long)b * p.kstride + m) * p.ldk + h * p.d;
+    const bf16_t* kp = p.k + ((long)bq * p.kstride + m) * p.ldk + h * p.d;
     float acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -964,7 +976,12 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(AttnProbsParams p) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float inv = 1.0f / sum;
-    for (int m = lane; m < p.M; m += 64) row[m] *= inv;
+    if constexpr (STORE) {
+      float* acc_row = p.probs + ((long)bh * p.N + q0 + r) * p.M;
+      for (int m = lane; m < p.M; m += 64) acc_row[m] += row[m] * inv;
+    } else {
+      for (int m = lane; m < p.M; m += 64) row[m] *= inv;
+    }
   }
 }
 
@@ -1021,7 +1038,18 @@ int attn_probs_launch(const AttnProbsParams& p, hipStream_t st) {
   ARG_CHECK(p.d % 8 == 0 && p.d <= 160, "attn_probs: head dim must be a multiple of 8, at most 160");
   ARG_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0, "attn_probs: strides");
   ARG_CHECK(p.M > 0 && p.N > 0 && p.M <= p.kstride, "attn_probs: extents");
-  hipLaunchKernelGGL(attn_probs_kernel, dim3(cdiv(p.N, 16), p.B * p.heads), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(attn_probs_kernel<false>, dim3(cdiv(p.N, 16), p.B * p.heads), dim3(256), 0, st, p);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+// p.probs = the store [n_pairs][2][heads][N][M] (accumulated into), p.B = n_pairs
+int attn_self_store_launch(const AttnProbsParams& p, hipStream_t st) {
+  ARG_CHECK(p.d % 8 == 0 && p.d <= 160 && p.ldq % 8 == 0 && p.ldk % 8 == 0, "attn_self_store: head dim / strides");
+  ARG_CHECK(p.M > 0 && p.N > 0 && p.M <= 1024 && p.M <= p.kstride && p.pair_src && p.pair_tar && p.probs, "attn_self_store: extents");
+  const int lds = 16 * p.M * (int)sizeof(float);
+  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&attn_probs_kernel<true>), lds)) return rc;
+  hipLaunchKernelGGL(attn_probs_kernel<true>, dim3(cdiv(p.N, 16), 2 * p.B * p.heads), dim3(256), lds, st, p);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }

@@ -209,8 +209,11 @@ struct AttnProbsParams {
   float* probs;                 // [B*heads][N][M]
   bf16_t* out; int ldo;         // [B*N][ldo]
   int B, N, M, kstride, heads, d;
+  // attn_self_store_launch only: the rows that are materialised (pair p: pair_src[p], pair_tar[p]) and whose q / k they use
+  const int *pair_src, *pair_tar, *qk_src;
 };
 int attn_probs_launch(const AttnProbsParams& p, hipStream_t st);
+int attn_self_store_launch(const AttnProbsParams& p, hipStream_t st);
 int attn_apply_launch(const AttnProbsParams& p, hipStream_t st);
 
 // ---------------------------------------------------------------- step.hip

@@ -251,6 +251,7 @@ struct Fwd {
   const bf16_t* k2_all = nullptr;    // [B*80][ctx_n]: attn2 keys of every block (columns ctx_off .. ctx_off + C)
   const bf16_t* vt2_all = nullptr;   // [ctx_n][B*80]: attn2 values, transposed
   int store_idx = 0;
+  int store_self_idx = 0;
   int tblock = 0;            // transformer blocks visited so far in this call (MasaCtrl / PnP layer gates)
   int rblock = 0;            // ResNet blocks visited so far (PnP feature injection)
   int place = 0;             // 0 down, 1 mid, 2 up: where the transformer block being executed sits (the hook's argument)
@@ -497,6 +498,18 @@ int transformer(Fwd& f, const Attn& a, const bf16_t* x, int H, int W, bf16_t** o
     } else {
       ProfScope ps(f, PK_SELF_ATTN, 4.0 * B * (double)N * N * C, 8.0 * M * C);      // q, k, v^T read, out written
       RUN(f, self_attn_launch(sp, f.st));
+    }
+    // the reference's store also keeps the <= 32 x 32 self maps; on request (plan.h_store_self) they are materialised for the
+    // conditional rows beside the fused kernel, which never forms them
+    if (N <= 1024) {
+      if (pl && pl->mode == 2 && pl->h_store_self && f.store_self_idx < pl->n_store_self && !f.h->hook) {
+        AttnProbsParams ap{};
+        ap.q = sp.q; ap.ldq = sp.ldq; ap.k = sp.k; ap.ldk = sp.ldk; ap.probs = pl->h_store_self[f.store_self_idx];
+        ap.B = pl->n_pairs; ap.N = N; ap.M = N; ap.kstride = N; ap.heads = heads; ap.d = d;
+        ap.pair_src = pl->pair_src; ap.pair_tar = pl->pair_tar; ap.qk_src = sp.qk_src;
+        RUN(f, attn_self_store_launch(ap, f.st));
+      }
+      f.store_self_idx++;
     }
   }
   f.ar.free(qk);

@@ -40,7 +40,8 @@ class P2PPlan(C.Structure):
                 ("qk_src", C.c_void_p), ("mixT", C.c_void_p), ("bvec", C.c_void_p),
                 ("h_store", C.POINTER(C.c_void_p)), ("n_store", C.c_int),
                 ("kv_src", C.c_void_p), ("kv_first_block", C.c_int),
-                ("qk_first_block", C.c_int), ("qk_max_tokens", C.c_int), ("feat_src", C.c_void_p), ("feat_resblock", C.c_int)]
+                ("qk_first_block", C.c_int), ("qk_max_tokens", C.c_int), ("feat_src", C.c_void_p), ("feat_resblock", C.c_int),
+                ("h_store_self", C.POINTER(C.c_void_p)), ("n_store_self", C.c_int)]
 
 
 class StepCoef(C.Structure):

@@ -214,6 +214,14 @@ class _PlanState:
         for (tok, place), buf in zip(self.layers, self.bufs):
             view = buf.reshape(2 * heads, tok, MAX_NUM_WORDS) if n == 1 else buf.reshape(n, 2 * heads, tok, MAX_NUM_WORDS)
             store[f"{place}_cross"].append(view)
+        # the <= 32 x 32 SELF maps the reference's store also keeps (ptp_classes.py:135-150): nothing on the h-Edit path reads
+        # them and they are 67 MB per image and 32 x 32 layer, so they are kept on request only (store_self_maps)
+        self.self_bufs, self.h_store_self = [], None
+        if any(getattr(m, "store_self_maps", False) for m in members):
+            self.self_bufs = [torch.zeros(n, 2, heads, tok, tok, dtype=torch.float32, device=dev) for tok, _ in self.layers]
+            self.h_store_self = (C.c_void_p * len(self.self_bufs))(*[b.data_ptr() for b in self.self_bufs])
+            for (tok, place), buf in zip(self.layers, self.self_bufs):
+                store[f"{place}_self"].append(buf.reshape(2 * heads, tok, tok) if n == 1 else buf.reshape(n, 2 * heads, tok, tok))
         self.attention_store = store
 
     def plan(self, cur_step, self_window, save_attn, edit=True):
@@ -231,15 +239,25 @@ class _PlanState:
         p.bvec = self.bvec[s].data_ptr()
         p.h_store = C.cast(self.h_store, C.POINTER(C.c_void_p))
         p.n_store = len(self.bufs)
+        if self.h_store_self is not None:
+            p.h_store_self = C.cast(self.h_store_self, C.POINTER(C.c_void_p))
+            p.n_store_self = len(self.self_bufs)
         return p
 
 
 class AttentionStore(AttentionControl):
-    def __init__(self):
+    # hedit extension: True = the fused path also keeps the <= 32 x 32 SELF maps ("down_self" / "mid_self" / "up_self"), as the
+    # reference's store does (ptp_classes.py:135-150).  Off by default: no driver reads them, 67 MB per image and 32 x 32 layer.
+    # Set on the instance (or the class) before the first UNet pass.
+    store_self_maps = False
+
+    def __init__(self, store_self_maps=None):
         super().__init__()
         self.step_store = self.get_empty_store()
         self.attention_store = {}
         self._state = None
+        if store_self_maps is not None:
+            self.store_self_maps = bool(store_self_maps)
 
     @staticmethod
     def get_empty_store():
@@ -254,7 +272,7 @@ class AttentionStore(AttentionControl):
         self.step_store = self.get_empty_store()
         self.attention_store = {}
         if self._state is not None:
-            for b in self._state.bufs:
+            for b in self._state.bufs + self._state.self_bufs:
                 b.zero_()
 
     # ---- the reference's Python protocol, for SUBCLASSES that override forward() and call super().forward(...) (the

@@ -102,6 +102,12 @@ typedef struct {
   int qk_first_block, qk_max_tokens;
   const int32_t* feat_src;  /* [B] */
   int feat_resblock;
+  /* The reference's AttentionStore also keeps the SELF maps of the layers with <= 32*32 tokens (ptp_classes.py:135-150).
+   * Nothing on the h-Edit path reads them, so the fused path stores them only on request: HOST array of n_store_self
+   * device pointers, one per such self-attention layer in call order, each [n_pairs][2][heads][N][N] fp32, accumulated
+   * on mode-2 passes (post-edit: inside the self window the target row's map is the source's).  NULL = off. */
+  float* const* h_store_self;
+  int n_store_self;
 } hedit_p2p_plan;
 
 typedef struct {

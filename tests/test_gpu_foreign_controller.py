@@ -164,6 +164,58 @@ def test_reference_protocol_controller_matches_the_in_kernel_edit(tiny, pi, cur_
             assert G.rel_err(a, b) < 2e-2
 
 
+@pytest.mark.parametrize("pi,cur_step", [(0, 0), (2, 1), (3, 5)])
+def test_fused_path_keeps_the_self_maps_on_request(tiny, pi, cur_step):
+    """store_self_maps = True: the fused path materialises the <= 32 x 32 SELF maps of the conditional rows beside the flash
+    kernel and accumulates them like the reference's AttentionStore (ptp_classes.py:135-150): same keys, counts, shapes and
+    values as the CPU oracle's store over two passes (the second adds to the first: between_steps), post-edit inside the
+    self-replace window (the target row's map is the source's); eps is untouched, bit for bit."""
+    from oracle import p2p as OP
+    from hedit.p2p import ptp_controller_utils as PCU
+    from hedit.p2p.ptp_utils import register_attention_control
+    hip, om, _ = tiny
+    src, tar, blend, is_replace = PROMPT_PAIRS[pi]
+    T = 10
+    bw = ((blend[0],), (blend[1],)) if blend else None
+    eq = {"words": (blend[1],), "values": (2.0,)} if blend else None
+    mk = lambda: PCU.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=bw, equilizer_params=eq, num_steps=T,    # noqa: E731
+                                     tokenizer=hip.tokenizer, device=hip.device)
+    hc, plain = mk(), mk()
+    hc.store_self_maps = True
+    oc = OP.make_controller([src, tar], is_replace, 0.4, 0.35, blend_word=bw, eq_params=eq, num_steps=T, tok=om.tokenizer)
+    x, ctx = _inputs(4, TINY_CONFIG, 177 + pi)
+    x[2], x[3] = x[0], x[1]
+    try:
+        register_attention_control(hip, plain)
+        plain.cur_step = cur_step
+        base = [hip.unet(G.f32(x), t, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"save_attn": True}).sample.clone()
+                for t in (401, 381)]
+        register_attention_control(hip, hc)
+        hc.cur_step = cur_step
+        got = [hip.unet(G.f32(x), t, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"save_attn": True}).sample.clone()
+               for t in (401, 381)]
+        G.sync()
+        OP.register(om, oc)
+        oc.cur_step = cur_step
+        with torch.no_grad():
+            for t in (401, 381):
+                om.unet(x, torch.tensor(t), encoder_hidden_states=ctx, cross_attention_kwargs={"save_attn": True})
+    finally:
+        _plain(hip)
+        from oracle.sd_unet import PlainProcessor
+        om.unet.set_attn_processor({k: PlainProcessor() for k in om.unet.attn_processors})
+    assert all(torch.equal(a, b) for a, b in zip(got, base))               # storing never changes the evaluation
+    assert hc.cur_step == oc.cur_step == cur_step + 2
+    assert all(len(plain.attention_store[k]) == 0 for k in ("down_self", "mid_self", "up_self"))
+    n_self = 0
+    for key in ("down_cross", "mid_cross", "up_cross", "down_self", "mid_self", "up_self"):
+        assert len(hc.attention_store[key]) == len(oc.attention_store[key]), key
+        for a, b in zip(hc.attention_store[key], oc.attention_store[key]):
+            assert tuple(a.shape) == tuple(b.shape) and G.rel_err(a, b) < 2e-2, (key, G.rel_err(a, b))
+            n_self += key.endswith("self")
+    assert n_self == 11                                                     # every transformer block of the tiny UNet is <= 32 x 32
+
+
 def test_sampling_loop_with_a_foreign_controller(tiny):
     """h_Edit_p2p_implicit end to end with the reference-protocol controller hooked (LocalBlend through step_callback on
     the maps the hook stored) against the same loop with hedit's in-kernel controller."""
