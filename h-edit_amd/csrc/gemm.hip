@@ -946,7 +946,10 @@ int gemm_canonical_chunk(int M_nom, int N_nom, int K) {
   const int bn = gemm_pick_bn(N_nom);
   const long tiles = (long)cdiv(M_nom, BM0) * cdiv(N_nom, bn);
   const int kt = K / BK;
-  if (tiles >= 256 || kt < 8) return 0;
+  // (contractions shorter than 24 K-tiles stay one chain: splitting K <= 1472 buys a handful of rows less than the reduce launch
+  //  and the fold's second accumulator set cost -- one image 9.46 -> 9.23 ms per UNet call, 120 rows -0.3 %, 20 rows -0.5 % against
+  //  a threshold of 8; 48 gives the one-image gain back: gpurun_out/r05/kt12.txt)
+  if (tiles >= 256 || kt < 24) return 0;
   int s = (int)((256 + tiles - 1) / tiles);     // one block per CU at the nominal batch
   int max_s = kt / 4;                            // keep >= 4 K-tiles per chunk
   if (s > max_s) s = max_s;
