@@ -38,12 +38,15 @@ constexpr int BK = 64;
 // BM = 128: 256 threads (2x2 waves), 2 LDS stages, 2 blocks per CU.
 // BM = 256: 512 threads (4x2 waves), 3 LDS stages (LDS-DMA only), 1 block per CU: 28 % less
 //           operand traffic per MFMA and two K-tiles in flight.
-template <int BM, int BN>
+// DEEP (BM = 128 only): the three-stage ring of the 256-row tile for the 128-row tile, ONE block per CU -- for launches with at most
+//           one block per CU, where the two-stage loop has nothing to overlap its DMA round trip with (a K-tile is 0.17 us of MFMA
+//           work behind a ~1 us request): two K-tiles in flight instead of one.
+template <int BM, int BN, bool DEEP = false>
 struct Smem {
   static constexpr int A_BYTES = BM * BK * 2;
   static constexpr int W_BYTES = BN * BK * 2;
   static constexpr int STAGE = A_BYTES + W_BYTES;
-  static constexpr int STAGES = (BM == 256 && BN <= 160) ? 3 : 2;
+  static constexpr int STAGES = (DEEP || (BM == 256 && BN <= 160)) ? 3 : 2;
   static constexpr int EPI = BM * (BN + 8) * 2;          // the epilogue stages the output tile in the same LDS
   static constexpr int TOTAL = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
   // row-sharing 3x3 conv (kernel mode 4): two activation tiles + a ring of three weight tiles + one zero row per
@@ -61,7 +64,7 @@ struct Smem {
 // DRAIN (tests/test_gpu_ring_hazard.py only): every counted wait of the operand rings becomes vmcnt(0) -- same arithmetic in
 // the same order, but nothing in LDS is read while any DMA of the wave is in flight.  Its output is the reference the
 // product schedule (DRAIN = false) must reproduce bit for bit under memory load (the protocol that found round 3's race).
-template <int BM, int BN, int MODE, bool CHUNK, bool DRAIN = false>
+template <int BM, int BN, int MODE, bool CHUNK, bool DRAIN = false, bool DEEP = false>
 __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = BM * 2;       // threads: 4 or 8 waves, each owning a 64 x BN/2 sub-tile
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   constexpr int A_CH = BM * 8 / NT;                    // 16-byte chunks (or 8-row DMA groups) per thread / wave
   constexpr int W_GROUPS = BN / 8;
   constexpr int W_CH = (W_GROUPS + NW - 1) / NW;       // 8 waves x 3 > 20 groups: the surplus re-loads the last group
-  using S = Smem<BM, BN>;
+  using S = Smem<BM, BN, DEEP>;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -867,23 +870,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   *reinterpret_cast<uint2*>(p.C + (long)m * p.ldc + n) = o;
 }
 
-template <int BM, int BN, int MODE, bool CHUNK>
+template <int BM, int BN, int MODE, bool CHUNK, bool DEEP = false>
 int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
-  using S = Smem<BM, BN>;
+  using S = Smem<BM, BN, DEEP>;
   constexpr int LDS = (MODE == 4 || MODE == 5) ? S::RS_TOTAL : S::TOTAL;
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), splits);
   // (only the loops with counted waits have a drained twin: the two-stage loop waits vmcnt(0) as it is)
   constexpr bool COUNTED = MODE == 4 || MODE == 5 || S::STAGES == 3;
   if constexpr (COUNTED) {
     if (hedit_test_drained()) {
-      if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK, true>), LDS)) return rc;
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, CHUNK, true>), grid, dim3(BM * 2), LDS, st, p);
+      if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK, true, DEEP>), LDS)) return rc;
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, CHUNK, true, DEEP>), grid, dim3(BM * 2), LDS, st, p);
       LAUNCH_CHECK();
       return HEDIT_OK;
     }
   }
-  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK>), LDS)) return rc;
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, CHUNK>), grid, dim3(BM * 2), LDS, st, p);
+  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK, false, DEEP>), LDS)) return rc;
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, CHUNK, false, DEEP>), grid, dim3(BM * 2), LDS, st, p);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }
@@ -917,7 +920,14 @@ int launch_igemm(const GemmParams& p, int splits, hipStream_t st) {
   }
   if (chunk)
     return big ? launch_igemm_impl<256, BN, MODE, true>(p, splits, st) : launch_igemm_impl<128, BN, MODE, true>(p, splits, st);
-  return big ? launch_igemm_impl<256, BN, MODE, false>(p, splits, st) : launch_igemm_impl<128, BN, MODE, false>(p, splits, st);
+  if (big) return launch_igemm_impl<256, BN, MODE, false>(p, splits, st);
+  // a launch with at most one 128-row block per CU: the three-stage ring (Smem DEEP).  A choice by the launch's size, like the tile
+  // shape -- every output element is the same k-ordered MFMA chain either way
+  int cus = 256;
+  if (int rc = hedit_cu_count(&cus)) return rc;
+  const long blocks = (long)cdiv(p.M, 128) * cdiv(p.N, BN) * splits;
+  if (blocks <= cus && p.K / BK >= 3) return launch_igemm_impl<128, BN, MODE, false, true>(p, splits, st);
+  return launch_igemm_impl<128, BN, MODE, false>(p, splits, st);
 }
 
 }  // namespace

@@ -7,7 +7,7 @@ of 20 place-holder DMAs); what found it was tests/test_gpu_chain_hazard.py: the 
 file runs that protocol on the other three rings:
 
   * igemm_kernel (csrc/gemm.hip): the three-stage ring of the 256-row tile (mode 0 / 1, both column tiles, with and
-    without the in-register chunk fold) and the row-sharing 3x3 loop (kernel modes 4 / 5: stride-1 and 2x-upsampled
+    without the in-register chunk fold), the same ring under the 128-row tile for launches of at most one block per CU and the row-sharing 3x3 loop (kernel modes 4 / 5: stride-1 and 2x-upsampled
     gather, 160-column plain, 128-column plain and chunked) -- ``igemm_kernel<..., DRAIN = true>``;
   * ffn_chain_kernel (csrc/ffn.hip): the feed-forward alone and the whole block tail -- ``ffn_chain_kernel<..., true>``;
   * self_attn_kernel (csrc/attn.hip): the head dims whose K / V^T ring runs two tiles ahead (d = 32, 40, 64) -- the
@@ -81,7 +81,7 @@ def _stress(run, launches, hog):
 
 # ------------------------------------------------------------------------------------------------ igemm_kernel
 # (name, mode, M-or-(B, Hin, Win), Cin / K, N, chunks)   chunks: 0 = plain chain, n = canonical-style fold of n chunks in
-# registers (hedit_k_gemm splits = -n); every case is large enough for the 256-row tile (>= 200 tiles, K >= 1024)
+# registers (hedit_k_gemm splits = -n), -n = n split-K slabs; the first twelve are large enough for the 256-row tile (>= 200 tiles, K >= 1024)
 GEMM_CASES = [
     ("ring3 160 plain  FF2 L1", 0, 122880, 2560, 640, 0),
     ("ring3 160 fold   FF2 L1", 0, 122880, 2560, 640, 4),
@@ -95,6 +95,14 @@ GEMM_CASES = [
     ("rowshare-up 160 plain 32->64 320", 3, (40, 32, 32), 320, 320, 0),
     ("rowshare-up 128 fold  16->32 640", 3, (120, 16, 16), 640, 640, 2),
     ("rowshare-up 128 plain 32->64 128", 3, (16, 32, 32), 128, 128, 0),
+    # launches with at most one 128-row block per CU: the three-stage ring of the 128-row tile (Smem DEEP); negative chunks =
+    # that many split-K slabs (the form small batches run the canonical chunking in)
+    ("deep128 160 linear 1280x1280", 0, 1280, 1280, 1280, 0),
+    ("deep128 160 linear 640x640 ragged", 0, 5120 + 40, 640, 640, 0),
+    ("deep128 128 linear", 0, 2048, 1024, 1024, 0),
+    ("deep128 160 conv 16x16 split-K", 1, (2, 16, 16), 1280, 1280, -4),
+    ("deep128 160 stride-2 conv", 2, (5, 32, 32), 640, 640, 0),
+    ("deep128 160 upsampling conv split-K", 3, (2, 8, 8), 1280, 1280, -4),
 ]
 
 
@@ -116,8 +124,8 @@ class Gemm:
         self.W = _bf(torch.randn(N, self.K, generator=g) / math.sqrt(self.K))
         self.bias = torch.randn(N, generator=g).to(DEV)
         self.R = _bf(torch.randn(self.M, N, generator=g))
-        self.splits = -chunks
-        self.ws = torch.empty(max(self.lib.hedit_k_gemm_ws_bytes(self.M, N, self.K, chunks), 16), dtype=torch.uint8, device=DEV)
+        self.splits = -chunks               # hedit_k_gemm: < 0 folded in registers, > 0 split-K slabs + reduce
+        self.ws = torch.empty(max(self.lib.hedit_k_gemm_ws_bytes(self.M, N, self.K, abs(chunks)), 16), dtype=torch.uint8, device=DEV)
 
     def run(self, out=None):
         o = out[0] if out else torch.empty(self.M, self.N, dtype=torch.bfloat16, device=DEV)

@@ -62,20 +62,20 @@ def isa():
 def _igemm(isa):
     out = {}
     for name, st in isa["gemm"].items():
-        m = re.search(r"igemm_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
+        m = re.search(r"igemm_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])E", name)
         if m:
-            bm, bn, mode, chunk, drain = (int(v) for v in m.groups())
-            out[(bm, bn, mode, chunk, drain)] = st
+            out[tuple(int(v) for v in m.groups())] = st          # (BM, BN, MODE, CHUNK, DRAIN, DEEP)
     return out
 
 
 def test_igemm_rings_issue_every_dma_the_waits_count(isa):
     ks = _igemm(isa)
-    seen_ring = seen_rs = 0
-    for (bm, bn, mode, chunk, drain), st in ks.items():
-        if bm != 256 or bn > 160 or drain:
+    seen_ring = seen_rs = seen_deep = 0
+    for (bm, bn, mode, chunk, drain, deep), st in ks.items():
+        if drain or bn > 160 or not (bm == 256 or deep):
             continue
-        w_ch = (bn // 8 + 7) // 8                    # weight DMA instructions per wave and K-tile (8 waves)
+        waves = bm // 32
+        w_ch = (bn // 8 + waves - 1) // waves        # weight DMA instructions per wave and K-tile
         counted = {n: c for n, c in st["waits"].items() if n >= w_ch}
         if mode in (4, 5):
             # prologue: act(0) 4 | w(0..2) 3 W | act(1) first half 2;  steady 3 tiles: 3 W + 2 halves x 2;  one dummy half past the end
@@ -84,17 +84,18 @@ def test_igemm_rings_issue_every_dma_the_waits_count(isa):
             seen_rs += 1
         else:
             ndma = 4 + w_ch                            # three-stage ring: one K-tile = 4 activation + W_CH weight instructions
-            assert st["dma"] % ndma == 0 and st["dma"] >= 2 * ndma, ((bm, bn, mode, chunk), st)
-            assert counted == {ndma: 3, 2 * ndma: 1}, ((bm, bn, mode, chunk), st)
+            assert st["dma"] % ndma == 0 and st["dma"] >= 2 * ndma, ((bm, bn, mode, chunk, deep), st)
+            assert counted == {ndma: 3, 2 * ndma: 1}, ((bm, bn, mode, chunk, deep), st)
             seen_ring += 1
-        twin = ks.get((bm, bn, mode, chunk, 1))
-        assert twin is not None, f"no drained twin of igemm<{bm},{bn},{mode},{chunk}>"
+            seen_deep += deep
+        twin = ks.get((bm, bn, mode, chunk, 1, deep))
+        assert twin is not None, f"no drained twin of igemm<{bm},{bn},{mode},{chunk},deep={deep}>"
         assert twin["dma"] == st["dma"], "the drained twin must issue the same DMA instructions"
         assert not [n for n in twin["waits"] if n >= w_ch], ("drained twin still has a counted ring wait", twin)
-    assert seen_ring >= 12 and seen_rs >= 6
+    assert seen_ring >= 20 and seen_rs >= 6 and seen_deep >= 8
     # the two-stage loops (128-row tile, 256 x 256 GEGLU tile) wait vmcnt(0) only and have no twin
-    for (bm, bn, mode, chunk, drain), st in ks.items():
-        if bm == 128 or bn == 256:
+    for (bm, bn, mode, chunk, drain, deep), st in ks.items():
+        if (bm == 128 and not deep) or bn == 256:
             assert not drain
             assert max(st["waits"]) <= 4, st           # (the compiler's own small waits around the residual loads of the fold)
 
