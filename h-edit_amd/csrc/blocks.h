@@ -174,8 +174,22 @@ struct VF {
   int B;
   hipStream_t st;
   Arena ar;
+  bool gn_fuse = false;   // GroupNorm statistics from the producing convolution's epilogue where the shape allows (gnstat.h)
   bool dry() const { return ar.dry; }
 };
+
+// Producer-side pair statistics (gnstat.h) of a tensor, or of the two halves [a | b] of a skip concatenation; a == nullptr: none
+struct GnStat {
+  const float* a = nullptr;
+  int ca = 0;
+  const float* b = nullptr;
+  int cb = 0;
+};
+// does a convolution output [B * HW][C] carry statistics?  A function of the layer's shape only (never of the batch): the
+// statistics' summation order, like every other one here, must not depend on what shares the launch
+inline bool gn_stats_shape(const VF& f, int HW, int C) {
+  return f.gn_fuse && HW >= 1024 && HW % 128 == 0 && C % 128 == 0 && gemm_pick_bn(C) == 128;
+}
 
 #define RUN(f, expr)            \
   do {                          \
@@ -218,9 +232,11 @@ int linear(VF& f, const bf16_t* A, int M, int K, const bf16_t* W, int N, const f
 }
 
 // mode 1: stride 1; 2: stride 2 with pad (0,1,0,1); 3: on the 2x nearest-upsampled input
+// gn_part: [M / 128][Cout / 2][2] pair statistics of Y (only for shapes gn_stats_shape accepts)
 int conv3x3(VF& f, const bf16_t* X, int Hin, int Win, int Cin, const bf16_t* W, int Cout, const float* bias,
-            const bf16_t* residual, bf16_t* Y, int mode, int ldy = 0) {
+            const bf16_t* residual, bf16_t* Y, int mode, int ldy = 0, float* gn_part = nullptr) {
   GemmParams p{};
+  p.gn_part = gn_part;
   p.mode = mode;
   p.asym = mode == 2 ? 1 : 0;
   p.Hin = Hin; p.Win = Win; p.Cin = Cin;
@@ -252,9 +268,16 @@ int conv_out(VF& f, const bf16_t* x, int H, int W, int C, const bf16_t* w, const
 }
 
 // stats: if non-null, *stats receives a kept [B][G][2] (mean, rstd) buffer for the backward pass
+// xs: producer-side pair statistics of x, if its producer(s) took them
 int groupnorm(VF& f, const bf16_t* x, bf16_t* y, const float* g, const float* b, int HW, int C, int silu,
-              float** stats = nullptr) {
+              float** stats = nullptr, const GnStat* xs = nullptr) {
   float *ws, *sb = nullptr;
+  if (xs && xs->a && !stats && xs->ca + xs->cb == C && (xs->cb == 0 || xs->b) && groupnorm_from_parts_supported(HW, C, f.groups)) {
+    TRY(aalloc(f, &ws, groupnorm_from_parts_ws_bytes(f.B) / sizeof(float)));
+    RUN(f, groupnorm_from_parts_launch(x, y, g, b, f.B, HW, C, f.groups, 1e-6f, silu, xs->a, xs->ca, xs->b, xs->cb, ws, f.st));
+    f.ar.free(ws);
+    return HEDIT_OK;
+  }
   if (stats) {
     TRY(aalloc(f, &sb, (size_t)f.B * 64 * 2));
     *stats = sb;
@@ -286,9 +309,14 @@ struct AttnRec {
 // h = conv1(.) + conv1.bias + temb_proj(silu(temb)), folded into the conv's epilogue bias
 // dst / ldd: write the result into an existing buffer with row stride ldd (the left columns of the next skip
 // concatenation) instead of allocating a contiguous [M][cout] one
+// xs: pair statistics of x (GnStat), if any; ys: if non-null, *ys receives the pair statistics of the output (allocated here,
+// freed by the caller) or nullptr when the shape carries none
 int resblock(VF& f, const VRes& r, const bf16_t* x, int H, int W, bf16_t** out, ResRec* rec = nullptr,
-             const float* temb = nullptr, bf16_t* dst = nullptr, int ldd = 0) {
+             const float* temb = nullptr, bf16_t* dst = nullptr, int ldd = 0, const GnStat* xs = nullptr, float** ys = nullptr) {
   const size_t M = (size_t)f.B * H * W;
+  if (ys) *ys = nullptr;
+  const bool st_out = !rec && gn_stats_shape(f, H * W, r.cout);
+  float* st1 = nullptr;
   bf16_t *a1, *h1, *a2, *sc = nullptr, *y;
   float* bias1 = r.c1b;
   float* tb = nullptr;
@@ -307,13 +335,18 @@ int resblock(VF& f, const VRes& r, const bf16_t* x, int H, int W, bf16_t** out, 
     *rec = ResRec{&r, x, h1, nullptr, nullptr, H, W};
   }
   TRY(aalloc(f, &a1, M * r.cin));
-  TRY(groupnorm(f, x, a1, r.n1g, r.n1b, H * W, r.cin, 1, rec ? &rec->st1 : nullptr));
+  TRY(groupnorm(f, x, a1, r.n1g, r.n1b, H * W, r.cin, 1, rec ? &rec->st1 : nullptr, rec ? nullptr : xs));
   if (!rec) TRY(aalloc(f, &h1, M * r.cout));
-  TRY(conv3x3(f, a1, H, W, r.cin, r.conv1, r.cout, bias1, nullptr, h1, 1));
+  if (st_out) TRY(aalloc(f, &st1, M / 128 * r.cout));
+  TRY(conv3x3(f, a1, H, W, r.cin, r.conv1, r.cout, bias1, nullptr, h1, 1, 0, st1));
   f.ar.free(a1);
   if (tb) f.ar.free(tb);
   TRY(aalloc(f, &a2, M * r.cout));
-  TRY(groupnorm(f, h1, a2, r.n2g, r.n2b, H * W, r.cout, 1, rec ? &rec->st2 : nullptr));
+  {
+    const GnStat hs{st1, r.cout, nullptr, 0};
+    TRY(groupnorm(f, h1, a2, r.n2g, r.n2b, H * W, r.cout, 1, rec ? &rec->st2 : nullptr, st1 ? &hs : nullptr));
+  }
+  if (st1) f.ar.free(st1);
   if (!rec) f.ar.free(h1);
   const bf16_t* res = x;
   if (r.sc_w) {
@@ -326,7 +359,12 @@ int resblock(VF& f, const VRes& r, const bf16_t* x, int H, int W, bf16_t** out, 
   } else {
     TRY(aalloc(f, &y, M * r.cout));
   }
-  TRY(conv3x3(f, a2, H, W, r.cout, r.conv2, r.cout, r.c2b, res, y, 1, dst ? ldd : 0));
+  float* sty = nullptr;
+  if (ys && st_out) {
+    TRY(aalloc(f, &sty, M / 128 * r.cout));
+    *ys = sty;
+  }
+  TRY(conv3x3(f, a2, H, W, r.cout, r.conv2, r.cout, r.c2b, res, y, 1, dst ? ldd : 0, sty));
   f.ar.free(a2);
   if (sc) f.ar.free(sc);
   *out = y;

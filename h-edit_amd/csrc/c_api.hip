@@ -168,6 +168,40 @@ int hedit_k_gemm(const void* A, const void* W, const float* bias, const void* re
   return gemm_launch(p, s, reinterpret_cast<float*>(partial_ws), S(stream));
 } catch (...) { return hedit_abi_catch(); }
 
+/* hedit_k_gemm for a convolution (mode 1..3) that also writes the GroupNorm pair statistics of its output (csrc/gnstat.h) */
+int hedit_k_conv_gn(const void* A, const void* W, const float* bias, const void* residual, void* C, int M, int N, int K, int ldc,
+                    int ldr, int mode, int Hin, int Win, int Cin, int Hout, int Wout, int splits, void* partial_ws, float* gn_part,
+                    void* stream) try {
+  ARG_CHECK(A && W && C && gn_part, "conv_gn args");
+  GemmParams p{};
+  p.A = reinterpret_cast<const bf16_t*>(A);
+  p.W = reinterpret_cast<const bf16_t*>(W);
+  p.M = M; p.N = N; p.K = K; p.lda = Cin; p.mode = mode;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout;
+  p.bias = bias;
+  p.residual = reinterpret_cast<const bf16_t*>(residual);
+  p.ldr = ldr;
+  p.C = reinterpret_cast<bf16_t*>(C);
+  p.ldc = ldc;
+  p.gn_part = gn_part;
+  if (splits < 0) {
+    const int kt = K / 64;
+    const int s = gemm_pick_splits(M, N, K, -splits);
+    p.chunk_kt = (kt + s - 1) / s;
+    return gemm_launch(p, 1, nullptr, S(stream));
+  }
+  const int s = gemm_pick_splits(M, N, K, splits);
+  return gemm_launch(p, s, reinterpret_cast<float*>(partial_ws), S(stream));
+} catch (...) { return hedit_abi_catch(); }
+
+int hedit_k_groupnorm_from_parts(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G,
+                                 float eps, int silu, const float* part_a, int ca, const float* part_b, int cb, void* ws,
+                                 void* stream) try {
+  ARG_CHECK(x && y && gamma && beta && part_a && ws, "groupnorm_from_parts args");
+  return groupnorm_from_parts_launch(reinterpret_cast<const bf16_t*>(x), reinterpret_cast<bf16_t*>(y), gamma, beta, B, HW, C, G,
+                                     eps, silu, part_a, ca, part_b, cb, reinterpret_cast<float*>(ws), S(stream));
+} catch (...) { return hedit_abi_catch(); }
+
 int hedit_k_pack_geglu(const float* w, const float* bias, void* w_packed_bf16, float* bias_packed, int inner, int K,
                        void* stream) try {
   ARG_CHECK(w && w_packed_bf16, "pack_geglu args");
@@ -260,7 +294,7 @@ int hedit_k_lin_chain(const void* a, int64_t lda, const void* r1, int64_t ldr1, 
 } catch (...) { return hedit_abi_catch(); }
 
 int hedit_test_set_flags(int flags) try {
-  ARG_CHECK(flags >= 0 && flags <= 3, "hedit_test_set_flags: bit 0 drained ring waits, bit 1 exact self-attention pass");
+  ARG_CHECK(flags >= 0 && flags <= 7, "hedit_test_set_flags: bit 0 drained ring waits, bit 1 exact self-attention pass, bit 2 pixel-UNet GroupNorm statistics path flipped");
   g_test_flags.store(flags, std::memory_order_relaxed);
   return HEDIT_OK;
 } catch (...) { return hedit_abi_catch(); }

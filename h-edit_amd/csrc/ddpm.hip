@@ -41,9 +41,15 @@ struct hedit_ddpm : ParamStore {
 
 namespace {
 
+// GroupNorm statistics from the producing convolutions (gnstat.h) -- default of this build, and hedit_test_set_flags bit 2
+// flips it so that tests/test_gpu_gn_stats.py can compare both paths on one library
+constexpr bool DDPM_GN_FUSE_DEFAULT = true;
+bool ddpm_gn_fuse() { return DDPM_GN_FUSE_DEFAULT != ((hedit_test_flags() & 4) != 0); }
+
 int forward_impl(hedit_ddpm* h, const float* x, float t, int B, float* out, void* ws, size_t ws_bytes, hipStream_t st,
                  bool dry, size_t* peak) {
   VF f{32, B, st, Arena{}};
+  f.gn_fuse = ddpm_gn_fuse();
   f.ar.dry = dry;
   f.ar.base = reinterpret_cast<char*>(ws);
   f.ar.cap = ws_bytes;
@@ -59,40 +65,53 @@ int forward_impl(hedit_ddpm* h, const float* x, float t, int B, float* out, void
   RUN(f, gemv_launch(h->t1_w, t0, h->t1_b, nullptr, temb, tc, tc, 1, st));
 
   int H = c.image_size, W = c.image_size;
-  struct Skip { bf16_t* p; int ch; };
+  // st: the tensor's GroupNorm pair statistics, taken by the convolution that produced it (gnstat.h), or nullptr: every
+  // GroupNorm whose input carries them skips its own statistics pass over the tensor
+  struct Skip { bf16_t* p; int ch; float* st; };
   std::vector<Skip> hs;
+  auto stat_of = [](const Skip& s) { return GnStat{s.st, s.ch, nullptr, 0}; };
   bf16_t* x0;
   TRY(aalloc(f, &x0, (size_t)B * H * W * ch));
   RUN(f, conv_in_launch(x, h->in_w, h->in_b, x0, B, c.in_channels, H, W, ch, st));
-  hs.push_back({x0, ch});
+  hs.push_back({x0, ch, nullptr});
   for (int i = 0; i < L; ++i) {
     const DLevel& lv = h->down[i];
     for (int j = 0; j < nrb; ++j) {
       bf16_t* y;
-      TRY(resblock(f, lv.block[j], hs.back().p, H, W, &y, nullptr, temb));
+      float* yst = nullptr;
+      const GnStat xs = stat_of(hs.back());
+      TRY(resblock(f, lv.block[j], hs.back().p, H, W, &y, nullptr, temb, nullptr, 0, &xs, &yst));
       if (!lv.attn.empty()) {
         bf16_t* a;
         TRY(attention(f, lv.attn[j], y, H, W, &a));
         f.ar.free(y);
+        if (yst) f.ar.free(yst);
+        yst = nullptr;
         y = a;
       }
-      hs.push_back({y, lv.ch});
+      hs.push_back({y, lv.ch, yst});
     }
     if (lv.samp_w) {
       bf16_t* y;
+      float* yst = nullptr;
       TRY(aalloc(f, &y, (size_t)B * (H / 2) * (W / 2) * lv.ch));
-      TRY(conv3x3(f, hs.back().p, H, W, lv.ch, lv.samp_w, lv.ch, lv.samp_b, nullptr, y, 2));
+      if (gn_stats_shape(f, (H / 2) * (W / 2), lv.ch)) TRY(aalloc(f, &yst, (size_t)B * (H / 2) * (W / 2) / 128 * lv.ch));
+      TRY(conv3x3(f, hs.back().p, H, W, lv.ch, lv.samp_w, lv.ch, lv.samp_b, nullptr, y, 2, 0, yst));
       H /= 2; W /= 2;
-      hs.push_back({y, lv.ch});
+      hs.push_back({y, lv.ch, yst});
     }
   }
   // middle (the last skip stays on the stack: it is popped by the first up block)
   bf16_t *m1, *m2, *cur;
+  float* cur_st = nullptr;
   int cur_ch = hs.back().ch;
-  TRY(resblock(f, h->mid1, hs.back().p, H, W, &m1, nullptr, temb));
+  {
+    const GnStat xs = stat_of(hs.back());
+    TRY(resblock(f, h->mid1, hs.back().p, H, W, &m1, nullptr, temb, nullptr, 0, &xs));
+  }
   TRY(attention(f, h->mida, m1, H, W, &m2));
   f.ar.free(m1);
-  TRY(resblock(f, h->mid2, m2, H, W, &cur, nullptr, temb));
+  TRY(resblock(f, h->mid2, m2, H, W, &cur, nullptr, temb, nullptr, 0, nullptr, &cur_st));
   f.ar.free(m2);
   // up path.  As in unet.hip, the block that produces `cur` writes it straight into the left columns of the next
   // concatenation buffer; only the skip half is copied.
@@ -120,35 +139,51 @@ int forward_impl(hedit_ddpm* h, const float* x, float t, int B, float* out, void
         ldd = lv.ch + hs.back().ch;
         TRY(aalloc(f, &dst, M * ldd));
       }
+      // statistics of the concatenation = the pairs of its two producers (both or nothing)
+      const GnStat xs = (cur_st && s.st) ? GnStat{cur_st, cur_ch, s.st, s.ch} : GnStat{};
+      // the output's statistics, unless its consumer is the upsampling convolution
+      const bool want_st = !(j == nrb && lv.samp_w);
+      float* yst = nullptr;
       if (!lv.attn.empty()) {
-        TRY(resblock(f, lv.block[j], cat, H, W, &y, nullptr, temb));
+        TRY(resblock(f, lv.block[j], cat, H, W, &y, nullptr, temb, nullptr, 0, &xs));
         f.ar.free(cat);
         bf16_t* a;
         TRY(attention(f, lv.attn[j], y, H, W, &a, nullptr, dst, ldd));
         f.ar.free(y);
         y = a;
       } else {
-        TRY(resblock(f, lv.block[j], cat, H, W, &y, nullptr, temb, dst, ldd));
+        TRY(resblock(f, lv.block[j], cat, H, W, &y, nullptr, temb, dst, ldd, &xs, want_st ? &yst : nullptr));
         f.ar.free(cat);
       }
+      if (cur_st) f.ar.free(cur_st);
+      if (s.st) f.ar.free(s.st);
       cur = y;
+      cur_st = yst;
       cur_ch = lv.ch;
       in_cat = to_cat;
     }
     if (lv.samp_w) {
       const int ldd = cur_ch + hs.back().ch;     // left half of the next level's first concatenation
       bf16_t* y;
+      float* yst = nullptr;
       TRY(aalloc(f, &y, (size_t)B * H * W * 4 * ldd));
-      TRY(conv3x3(f, cur, H, W, cur_ch, lv.samp_w, cur_ch, lv.samp_b, nullptr, y, 3, ldd));
+      if (gn_stats_shape(f, 4 * H * W, cur_ch)) TRY(aalloc(f, &yst, (size_t)B * H * W * 4 / 128 * cur_ch));
+      TRY(conv3x3(f, cur, H, W, cur_ch, lv.samp_w, cur_ch, lv.samp_b, nullptr, y, 3, ldd, yst));
       f.ar.free(cur);
+      if (cur_st) f.ar.free(cur_st);
       cur = y;
+      cur_st = yst;
       H *= 2; W *= 2;
       in_cat = true;
     }
   }
   bf16_t* xn;
   TRY(aalloc(f, &xn, (size_t)B * H * W * cur_ch));
-  TRY(groupnorm(f, cur, xn, h->no_g, h->no_b, H * W, cur_ch, 1));
+  {
+    const GnStat xs{cur_st, cur_ch, nullptr, 0};
+    TRY(groupnorm(f, cur, xn, h->no_g, h->no_b, H * W, cur_ch, 1, nullptr, cur_st ? &xs : nullptr));
+  }
+  if (cur_st) f.ar.free(cur_st);
   f.ar.free(cur);
   TRY(conv_out(f, xn, H, W, cur_ch, h->out_w, h->out_b, c.out_ch, out));
   f.ar.free(xn);

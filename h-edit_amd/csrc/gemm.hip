@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gnstat.h"
 #include "kernels.h"
 
 namespace {
@@ -64,7 +65,9 @@ struct Smem {
 // DRAIN (tests/test_gpu_ring_hazard.py only): every counted wait of the operand rings becomes vmcnt(0) -- same arithmetic in
 // the same order, but nothing in LDS is read while any DMA of the wave is in flight.  Its output is the reference the
 // product schedule (DRAIN = false) must reproduce bit for bit under memory load (the protocol that found round 3's race).
-template <int BM, int BN, int MODE, bool CHUNK, bool DRAIN = false, bool DEEP = false>
+// GNS (128-column tile): the epilogue also writes the GroupNorm pair statistics of the stored tile (gnstat.h) to p.gn_part.  A
+// template parameter, not a run-time branch: the instantiations without it are the kernels of the SD loop, untouched.
+template <int BM, int BN, int MODE, bool CHUNK, bool DRAIN = false, bool DEEP = false, bool GNS = false>
 __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = BM * 2;       // threads: 4 or 8 waves, each owning a 64 x BN/2 sub-tile
@@ -820,6 +823,32 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       const int m = m0 + ml, n = n0 + c * 8;
       if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(p.C + (long)m * p.ldc + n) = ov[it];
     }
+    if constexpr (GNS) {
+      // GroupNorm pair statistics of the tile as stored (ov: after the residual add), in the canonical tree of gnstat.h:
+      // thread (r, c) holds piece c of rows r + RSTEP * it -- exactly the store mapping above for CHUNKS = 16
+      static_assert(BN == 128 && CHUNKS == 16 && ITER == 8, "statistics epilogue: 128-column tile");
+      constexpr int RSTEP = NT / CHUNKS;                    // 16 (128-row tile) or 32 (256-row tile)
+      constexpr int UNITS = BM / GNS_UNIT;
+      constexpr int RED_OFF = BM * CS * 2;                  // behind the staged tile (other threads may still be reading it)
+      static_assert(RED_OFF % 16 == 0 && RED_OFF + UNITS * GNS_RED_BYTES <= S::TOTAL, "statistics scratch must fit the LDS");
+      float2* red = reinterpret_cast<float2*>(smem + RED_OFF);
+      const int r = tid / CHUNKS, c = tid - r * CHUNKS;
+      GnPiece t[2];
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const GnPiece g = gns_piece(ov[it][0], ov[it][1], ov[it][2], ov[it][3]);
+        if (gns_first<RSTEP>(it)) t[gns_slot<RSTEP>(it)] = g; else gns_add(t[gns_slot<RSTEP>(it)], g);
+      }
+      gns_store_t(red, gns_red_row<RSTEP>(r, 0), c, t[0]);
+      gns_store_t(red, gns_red_row<RSTEP>(r, 1), c, t[1]);
+      __syncthreads();
+      if (tid < UNITS * 64) {
+        const int u = tid >> 6, pk = tid & 63;
+        const float2 v = gns_fold_unit(red, u, pk);
+        if (m0 + u * GNS_UNIT < p.M)         // (M % 128 == 0: a unit is whole or absent)
+          *reinterpret_cast<float2*>(p.gn_part + (((long)(m0 / GNS_UNIT + u) * (p.N / 2)) + n0 / 2 + pk) * 2) = v;
+      }
+    }
   } else {
     // ragged right edge (N % 8 == 4) or rows that are only 8-byte aligned: 8-byte pieces
     for (int idx = tid; idx < BM * CHUNKS * 2; idx += NT) {
@@ -870,11 +899,67 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   *reinterpret_cast<uint2*>(p.C + (long)m * p.ldc + n) = o;
 }
 
+// The split-K reduce with the GroupNorm pair statistics (gnstat.h): a block owns one 128-row unit x 128 columns in the piece
+// layout of the 128-row igemm tile (thread (r, c): piece c of rows r + 16 it), every element the arithmetic of
+// splitk_reduce_kernel -- same output bits, same statistics bits as a launch that folds its chunks in registers.
+__global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(GemmParams p) {
+  __shared__ float2 red[32 * 64];
+  const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+  const int m0 = blockIdx.x * GNS_UNIT, n = blockIdx.y * 128 + c * 8;
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  if (p.bias) {
+    b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+  }
+  auto add2 = [](uint32_t a, uint32_t b) __attribute__((always_inline)) {
+    return pack_bf16x2(bf16_to_f32((bf16_t)(a & 0xffff)) + bf16_to_f32((bf16_t)(b & 0xffff)),
+                       bf16_to_f32((bf16_t)(a >> 16)) + bf16_to_f32((bf16_t)(b >> 16)));
+  };
+  GnPiece t[2];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int m = m0 + r + 16 * it;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    for (int s = 0; s < p.splits; ++s) {
+      const float* src = p.partial + ((long)s * p.M + m) * p.N + n;
+      v0 += *reinterpret_cast<const f32x4*>(src);
+      v1 += *reinterpret_cast<const f32x4*>(src + 4);
+    }
+    v0 = v0 + b0;
+    v1 = v1 + b1;
+    u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+    if (p.residual) {
+      const u32x4 rr = *reinterpret_cast<const u32x4*>(p.residual + (long)m * p.ldr + n);
+      o[0] = add2(o[0], rr[0]); o[1] = add2(o[1], rr[1]); o[2] = add2(o[2], rr[2]); o[3] = add2(o[3], rr[3]);
+    }
+    *reinterpret_cast<u32x4*>(p.C + (long)m * p.ldc + n) = o;
+    const GnPiece g = gns_piece(o[0], o[1], o[2], o[3]);
+    if (gns_first<16>(it)) t[gns_slot<16>(it)] = g; else gns_add(t[gns_slot<16>(it)], g);
+  }
+  gns_store_t(red, gns_red_row<16>(r, 0), c, t[0]);
+  gns_store_t(red, gns_red_row<16>(r, 1), c, t[1]);
+  __syncthreads();
+  if (tid < 64) {
+    const float2 v = gns_fold_unit(red, 0, tid);
+    *reinterpret_cast<float2*>(p.gn_part + ((long)blockIdx.x * (p.N / 2) + blockIdx.y * 64 + tid) * 2) = v;
+  }
+}
+
 template <int BM, int BN, int MODE, bool CHUNK, bool DEEP = false>
 int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
   using S = Smem<BM, BN, DEEP>;
   constexpr int LDS = (MODE == 4 || MODE == 5) ? S::RS_TOTAL : S::TOTAL;
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), splits);
+  // the statistics epilogue: conv modes on the 128-column tile, launches that write the bf16 tile themselves (a split-K launch
+  // leaves them to splitk_reduce_gn_kernel).  No drained twin: the K loop is the one of the GNS = false instantiation.
+  if constexpr (BN == 128 && MODE != 0) {
+    if (p.gn_part && !p.partial) {
+      if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK, false, DEEP, true>), LDS)) return rc;
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, CHUNK, false, DEEP, true>), grid, dim3(BM * 2), LDS, st, p);
+      LAUNCH_CHECK();
+      return HEDIT_OK;
+    }
+  }
   // (only the loops with counted waits have a drained twin: the two-stage loop waits vmcnt(0) as it is)
   constexpr bool COUNTED = MODE == 4 || MODE == 5 || S::STAGES == 3;
   if constexpr (COUNTED) {
@@ -1050,6 +1135,11 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
   } else {
     p.partial = nullptr;
   }
+  if (p.gn_part) {
+    ARG_CHECK(p.mode != 0 && !p.geglu && !p.raw_f32 && !p.ln_out, "gemm: pair statistics come with the bf16 tile of a convolution");
+    ARG_CHECK(p.M % GNS_UNIT == 0 && p.N % 128 == 0 && gemm_pick_bn(p.N) == 128, "gemm: pair statistics need M % 128 == 0 and the 128-column tile");
+    ARG_CHECK(p.ldc % 8 == 0 && (p.residual == nullptr || p.ldr % 8 == 0), "gemm: pair statistics need 16-byte rows");
+  }
   int bn = pick_bn(p);
   // the in-register chunk fold doubles the accumulators: with the upsampling gather's extra lane state the
   // 160-column tile would spill inside the K loop, so that one combination takes the 128-column tile
@@ -1088,6 +1178,11 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
       *p.ln_done = 1;
       return splitk_reduce_ln_launch(p.partial, p.splits, p.bias, p.residual, p.ldr, p.C, p.ln_out, p.ln_gamma, p.ln_beta, p.M, p.N,
                                      p.ln_eps, st);
+    }
+    if (p.gn_part) {
+      hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3(p.M / GNS_UNIT, p.N / 128), dim3(256), 0, st, p);
+      LAUNCH_CHECK();
+      return HEDIT_OK;
     }
     long total = (long)p.M * (p.N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p);

@@ -31,6 +31,9 @@ struct GemmParams {
   bf16_t* ln_out;
   float ln_eps;
   int* ln_done;
+  // optional (conv modes, N % 128 == 0, M % 128 == 0): GroupNorm pair statistics of the stored output, [M / 128][N / 2][2] fp32
+  // (gnstat.h): written by whichever kernel writes the bf16 tile, same bits for every execution form
+  float* gn_part;
 };
 #ifndef GEMM_NOMINAL_BATCH
 #define GEMM_NOMINAL_BATCH 4   // the canonical chunking is sized for this many rows of the batch dimension
@@ -107,6 +110,12 @@ size_t groupnorm_ws_bytes(int B, int HW, int C);
 int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B,
                      int HW, int C, int G, float eps, int silu, float* ws, hipStream_t st,
                      float* stats = nullptr);   // stats: optional [B][G][2] (mean, rstd) for the backward pass
+// GroupNorm on producer-side pair statistics (gnstat.h; GemmParams::gn_part of the launch(es) that wrote x = [a | b])
+bool groupnorm_from_parts_supported(int HW, int C, int G);
+size_t groupnorm_from_parts_ws_bytes(int B);
+int groupnorm_from_parts_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G,
+                                float eps, int silu, const float* part_a, int ca, const float* part_b, int cb, float* ws,
+                                hipStream_t st);
 int groupnorm_affine_launch(const bf16_t* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps,
                             float* ws, hipStream_t st, const float** ss_out);   // *ss_out: [B][C] float2 (scale, shift), inside ws
 int layernorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, long rows,

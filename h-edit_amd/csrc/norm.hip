@@ -652,6 +652,34 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
   }
 }
 
+// (group, image) -> (sum, sum of squares) from producer-side pair statistics, see groupnorm_from_parts_launch.
+// pa [B * units][npa][2], pb [B * units][npb][2] (or null): pair p of the concatenation is pair p of a, or pair p - npa of b.
+__global__ __launch_bounds__(256) void gn_fold_kernel(const float* __restrict__ pa, int npa, const float* __restrict__ pb, int npb,
+                                                      float* __restrict__ out, int units, int ppg) {
+  __shared__ float red[8];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int total = units * ppg;
+  float s = 0.f, q = 0.f;
+  for (int e = tid; e < total; e += 256) {
+    const int u = e / ppg, j = e - u * ppg;
+    const int pr = g * ppg + j;
+    const long row = (long)b * units + u;
+    const float2 v = pr < npa ? *reinterpret_cast<const float2*>(pa + (row * npa + pr) * 2)
+                              : *reinterpret_cast<const float2*>(pb + (row * npb + (pr - npa)) * 2);
+    s += v.x;
+    q += v.y;
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s; red[(tid >> 6) * 2 + 1] = q; }
+  __syncthreads();
+  if (tid == 0) {
+    s = ((red[0] + red[2]) + red[4]) + red[6];
+    q = ((red[1] + red[3]) + red[5]) + red[7];
+    *reinterpret_cast<float2*>(out + ((long)b * gridDim.x + g) * 2) = make_float2(s, q);
+  }
+}
+
 // Pixel slabs per image for the statistics pass.  A function of (HW, C) only -- never of the batch -- so that the
 // fp32 summation order of an image's statistics, and with it every bit of the normalised output, is the same
 // whether the image is evaluated alone or in a batch of 120 (the sampler's reconstruction invariant rests on it).
@@ -721,6 +749,37 @@ int groupnorm_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float
     return HEDIT_OK;
   }
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(total_v)), dim3(256), 0, st, x, y, ss, total_v, HW, C, silu);
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+// GroupNorm whose statistics were taken by the PRODUCER(s) of x (gnstat.h: pair sums per 128-row unit, written by the igemm
+// epilogue / the split-K reduce): gn_fold_kernel assembles (sum, sum of squares) per (image, group) from the pairs of one
+// tensor or of the two halves of a skip concatenation [a | b] -- thread-sequential over (unit, pair) in a fixed order,
+// butterfly over the wave, waves 0..3 in order: a function of the image alone -- in the layout of one statistics slab, and the
+// row-form apply pass finishes as always (mean / rstd formulas and element-wise arithmetic unchanged).  The pass that read
+// the tensor for its statistics (gn_partial_kernel) is gone; what is read instead is 1 / 32 of the tensor's bytes.
+bool groupnorm_from_parts_supported(int HW, int C, int G) {
+  return HW >= 1024 && HW % 128 == 0 && C % 8 == 0 && C / 8 <= 256 && C % G == 0 && (C / G) % 2 == 0 && G <= 64;
+}
+size_t groupnorm_from_parts_ws_bytes(int B) { return (size_t)B * 64 * 2 * sizeof(float); }
+
+int groupnorm_from_parts_launch(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, int B, int HW, int C, int G,
+                                float eps, int silu, const float* part_a, int ca, const float* part_b, int cb, float* ws,
+                                hipStream_t st) {
+  ARG_CHECK(groupnorm_from_parts_supported(HW, C, G), "groupnorm_from_parts: shape");
+  ARG_CHECK(part_a && ca > 0 && ca % 2 == 0 && cb >= 0 && cb % 2 == 0 && ca + cb == C && (cb == 0) == (part_b == nullptr),
+            "groupnorm_from_parts: the pair statistics must cover the C channels");
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(G, B), dim3(256), 0, st, part_a, ca / 2, part_b, cb / 2, ws, HW / 128, C / G / 2);
+  LAUNCH_CHECK();
+  const int CV = C / 8, R = 256 / CV;
+  int ns = (int)(4096 / (B > 0 ? B : 1)) + 1;
+  const int max_ns = HW / (R * 8) > 0 ? HW / (R * 8) : 1;
+  if (ns > max_ns) ns = max_ns;
+  int pix = HW / ns / (4 * R) * (4 * R);
+  if (pix < 4 * R) pix = 4 * R;
+  ns = (HW + pix - 1) / pix;
+  hipLaunchKernelGGL(gn_apply_rows_kernel, dim3(ns, B), dim3(256), 0, st, x, y, ws, gamma, beta, HW, C, G, 1, eps, silu, ns);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }

@@ -161,6 +161,10 @@ _SIGS = {
     "hedit_k_gemm_plan_splits": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "hedit_k_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 13 +
                      [C.c_void_p, C.c_void_p]),
+    "hedit_k_conv_gn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 12 +
+                        [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hedit_k_groupnorm_from_parts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hedit_k_pack_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "hedit_k_gemm_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p]),

@@ -283,6 +283,21 @@ int hedit_k_gemm_plan_splits(int M, int N, int K, int chunk_kt);
 int hedit_k_gemm(const void* A, const void* W, const float* bias, const void* residual, void* C,
                  int M, int N, int K, int lda, int ldc, int ldr, int mode, int Hin, int Win,
                  int Cin, int Hout, int Wout, int splits, void* partial_ws, void* stream);
+/* GroupNorm statistics taken by the producer (csrc/gnstat.h) -- what replaces the statistics pass of torch's GroupNorm in
+ * the ResNet blocks of the pixel UNet (reference face-swapping/diffusion/diffusion.py:27-33 Normalize, :115-134 ResnetBlock).
+ * hedit_k_conv_gn = hedit_k_gemm for a 3x3 convolution (mode 1..3; M % 128 == 0, N % 128 == 0 with the 128-column tile) that
+ *   also writes gn_part[M / 128][N / 2][2] (fp32): (sum, sum of squares) of the stored bf16 output per unit of 128 rows and
+ *   pair of adjacent channels, in a fixed summation tree -- the same bits whether the launch runs as one chain, folds its
+ *   canonical chunks in registers (splits < 0) or goes through split-K slabs (splits > 0), and whatever shares the batch.
+ * hedit_k_groupnorm_from_parts: y = GroupNorm(x) (+SiLU) for x [B][HW][C] = the channel concatenation of tensors with pair
+ *   statistics part_a (ca channels) and part_b (cb channels, or null / 0); HW >= 1024, HW % 128 == 0, (C / G) even.
+ *   ws: B * 512 bytes. */
+int hedit_k_conv_gn(const void* A, const void* W, const float* bias, const void* residual, void* C, int M, int N, int K, int ldc,
+                    int ldr, int mode, int Hin, int Win, int Cin, int Hout, int Wout, int splits, void* partial_ws, float* gn_part,
+                    void* stream);
+int hedit_k_groupnorm_from_parts(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int G,
+                                 float eps, int silu, const float* part_a, int ca, const float* part_b, int cb, void* ws,
+                                 void* stream);
 /* FF1 of the transformer feed-forward with the GEGLU fused into the GEMM epilogue (diffusers
  * GEGLU.forward: hidden, gate = proj(x).chunk(2, -1); out = hidden * gelu(gate)).
  * hedit_k_pack_geglu interleaves the fp32 [2*inner][K] projection weight (and [2*inner] bias) of the
@@ -342,7 +357,10 @@ int hedit_k_lin_chain_sched(const void* a, int64_t lda, const void* r1, int64_t 
  *        (and lgkmcnt(0)) in front of its barrier, same arithmetic in the same order.  The product schedule must reproduce
  *        those bits under any memory load.  (lin_chain_kernel has its own entry above.)
  * bit 1: self-attention takes the exact online-softmax pass only (no pinned-shift pass) -- the reference bits of the
- *        denominator-check / redo logic. */
+ *        denominator-check / redo logic.
+ * bit 2: the pixel UNet (hedit_ddpm_forward) takes the OTHER of its two GroupNorm statistics paths (statistics pass over the
+ *        tensor / pair statistics from the producing convolution's epilogue, csrc/gnstat.h): tests/test_gpu_gn_stats.py
+ *        compares the two on one library. */
 int hedit_test_set_flags(int flags);
 size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C);
 int hedit_k_groupnorm_affine(const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, void* ws,

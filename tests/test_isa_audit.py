@@ -62,10 +62,17 @@ def isa():
 def _igemm(isa):
     out = {}
     for name, st in isa["gemm"].items():
-        m = re.search(r"igemm_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])E", name)
+        m = re.search(r"igemm_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])E", name)
         if m:
-            out[tuple(int(v) for v in m.groups())] = st          # (BM, BN, MODE, CHUNK, DRAIN, DEEP)
+            key = tuple(int(v) for v in m.groups())               # (BM, BN, MODE, CHUNK, DRAIN, DEEP, GNS)
+            if key[6]:
+                GNS_KERNELS[key[:6]] = st
+            else:
+                out[key[:6]] = st
     return out
+
+
+GNS_KERNELS = {}      # the instantiations with the GroupNorm-statistics epilogue (csrc/gnstat.h): same K loop, checked below
 
 
 def test_igemm_rings_issue_every_dma_the_waits_count(isa):
@@ -98,6 +105,21 @@ def test_igemm_rings_issue_every_dma_the_waits_count(isa):
         if (bm == 128 and not deep) or bn == 256:
             assert not drain
             assert max(st["waits"]) <= 4, st           # (the compiler's own small waits around the residual loads of the fold)
+
+
+def test_igemm_statistics_epilogue_leaves_the_k_loop_alone(isa):
+    """igemm_kernel<..., GNS = true> differs from its GNS = false twin in the epilogue only: the same LDS-DMA instructions and
+    the same counted waits (the ring tests of tests/test_gpu_ring_hazard.py therefore cover its K loop too)."""
+    ks = _igemm(isa)
+    assert len(GNS_KERNELS) >= 16
+    for key, st in GNS_KERNELS.items():
+        bm, bn, mode, chunk, drain, deep = key
+        assert bn == 128 and mode != 0 and not drain
+        twin = ks[key]
+        assert st["dma"] == twin["dma"], (key, st, twin)
+        waves = bm // 32
+        w_ch = (bn // 8 + waves - 1) // waves
+        assert {n: c for n, c in st["waits"].items() if n >= w_ch} == {n: c for n, c in twin["waits"].items() if n >= w_ch}, key
 
 
 def test_ffn_chain_ring(isa):
