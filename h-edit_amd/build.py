@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Build libhedit_hip.so (gfx950) in-tree with hipcc.  `python h-edit_amd/build.py [--force]`.
+"""Build libhedit_hip.so (gfx950) in-tree with hipcc.  `python h-edit_amd/build.py [--force] [--f16]`.
+
+--f16: the half-storage build of the same sources (-DHEDIT_STORE_F16, csrc/common.h) -> hedit/libhedit_hip_f16.so, selected at
+run time with HEDIT_STORAGE=f16 (hedit/_lib.py).  The default library, every benchmark figure and BASELINE configs[1] are bfloat16.
 
 No cmake / setuptools indirection: one hipcc invocation per translation unit (objects cached by
 source mtime under h-edit_amd/build/), one link.  The .so lands next to the Python package
@@ -28,8 +31,11 @@ def _deps_mtime():
     return max(os.path.getmtime(p) for p in hdrs)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, f16=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    OBJ = os.path.join(HERE, "build_f16" if f16 else "build")
+    OUT = os.path.join(HERE, "hedit", "libhedit_hip_f16.so" if f16 else "libhedit_hip.so")
+    FLAGS = globals()["FLAGS"] + (["-DHEDIT_STORE_F16"] if f16 else [])
     os.makedirs(OBJ, exist_ok=True)
     hm = _deps_mtime()
     jobs = []
@@ -64,4 +70,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, f16="--f16" in sys.argv)

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
   __syncthreads();
   if (ONES) {
     for (int i = tid; i < C::NSTG * 64; i += 256)
-      reinterpret_cast<bf16_t*>(smem + (i >> 6) * C::STAGE + C::K_BYTES + D * 128)[i & 63] = (bf16_t)0x3F80;
+      reinterpret_cast<bf16_t*>(smem + (i >> 6) * C::STAGE + C::K_BYTES + D * 128)[i & 63] = ST_ONE_BITS;
   }
 
   // Q fragments (B operand): lane holds Q[q][ks*16 + hi*8 .. +8]; zero beyond D, so whatever the
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
     union { u32x4 u; bf16x8 v; } x;
     x.v = kf[KS_P];
     const bool padl = hi == HI_P;
-    x.u[0] = padl ? 0x00003F80u : x.u[0];
+    x.u[0] = padl ? (uint32_t)ST_ONE_BITS : x.u[0];
     x.u[1] = padl ? 0u : x.u[1];
     x.u[2] = padl ? 0u : x.u[2];
     x.u[3] = padl ? 0u : x.u[3];
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
   auto set_q_shift = [&](int g, float m) __attribute__((always_inline)) {   // Q[:, D] := -m (bf16-exact)
     union { u32x4 u; bf16x8 v; } x;
     x.v = qf[g][KS_P];
-    const uint32_t bits = (__float_as_uint(-m) >> 16);
+    const uint32_t bits = st_exact_bits(-m);
     x.u[0] = (hi == HI_P) ? bits : x.u[0];
     qf[g][KS_P] = x.v;
   };
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < DK; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[g][ks], s, 0, 0, 0);
+    for (int ks = 0; ks < DK; ++ks) s = MFMA_32x32x16_ST(kf[ks], qf[g][ks], s, 0, 0, 0);
   };
   // running max over 4 more values of a score block (v_max3 x2; a plain fmaxf chain picks up
   // canonicalising v_max x,x pairs on the MFMA results)
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
     // the SIMD's issue slots the scarce resource, DESIGN.md 5.0 item 7 -- the 14 s_setprio per unit cost more than the
     // priority buys: 2.1 % faster without them at d = 40, 1.5 % at d = 80.)
     auto mfma_hi = [&](const bf16x8& x, const bf16x8& y, f32x16& acc) __attribute__((always_inline)) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
+      acc = MFMA_32x32x16_ST(x, y, acc, 0, 0, 0);
     };
     constexpr int NPV = PV16 ? 2 * DT16 : 2 * DT;
     // with a single stream the P.V of unit U-1 (formed against the old maximum) has to be
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
       if (first || !__all(over <= RESCALE_THR)) {
         float alpha;
         if (FOLD) {
-          const float m_new = (float)(__bf16)(m_run[A] + fmaxf(over, first ? -1e30f : 0.f));
+          const float m_new = (float)(st_elem_t)(m_run[A] + fmaxf(over, first ? -1e30f : 0.f));
           const float delta = m_new - m_run[A];
           alpha = fast_exp2(-delta);
           m_run[A] = m_new;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
       } else {
         const int i = sl - qk_before;                      // index among the P.V MFMAs
         if constexpr (PV16)
-          o16[AP][i / DT16][i % DT16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf16[i % DT16], pf_prev[i / DT16], o16[AP][i / DT16][i % DT16], 0, 0, 0);
+          o16[AP][i / DT16][i % DT16] = MFMA_16x16x32_ST(vf16[i % DT16], pf_prev[i / DT16], o16[AP][i / DT16][i % DT16], 0, 0, 0);
         else
           mfma_hi(vf[i % DT][i / DT], pf_prev[i / DT], o[AP][i % DT]);
         // V^T fragments of unit U (kept for the pair when QG == 2) once the last P.V is issued
@@ -593,12 +593,12 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
         for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
           for (int dt = 0; dt < DT16; ++dt)
-            o16[AL][gq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf16[dt], pf_last[gq], o16[AL][gq][dt], 0, 0, 0);
+            o16[AL][gq][dt] = MFMA_16x16x32_ST(vf16[dt], pf_last[gq], o16[AL][gq][dt], 0, 0, 0);
       } else {
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[AL][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][0], pf_last[0], o[AL][dt], 0, 0, 0);
+      for (int dt = 0; dt < DT; ++dt) o[AL][dt] = MFMA_32x32x16_ST(vf[dt][0], pf_last[0], o[AL][dt], 0, 0, 0);
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[AL][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][1], pf_last[1], o[AL][dt], 0, 0, 0);
+      for (int dt = 0; dt < DT; ++dt) o[AL][dt] = MFMA_32x32x16_ST(vf[dt][1], pf_last[1], o[AL][dt], 0, 0, 0);
       }
     }
   };
@@ -640,8 +640,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
       bool bad = false;
 #pragma unroll
       for (int a = 0; a < NS; ++a) {
-        if constexpr (PV16) bad |= !(denom16(a, 0) < 0x1p60f) || !(denom16(a, 1) < 0x1p60f);
-        else bad |= !(denom(a) < 0x1p60f);
+        // (half storage: a probability must stay below 65504, so a denominator of 2^15 already sends the block to the exact pass)
+        constexpr float DEN_MAX = HEDIT_F16 ? 0x1p15f : 0x1p60f;
+        if constexpr (PV16) bad |= !(denom16(a, 0) < DEN_MAX) || !(denom16(a, 1) < DEN_MAX);
+        else bad |= !(denom(a) < DEN_MAX);
       }
       redo = __syncthreads_or(bad ? 1 : 0);        // (also: nobody reads the ring any more)
     }
@@ -784,7 +786,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void cross_attn_kernel(Cros
 #pragma unroll
       for (int ks = 0; ks < H::DK; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (nt * 32 + ql) * H::KS + ks * 16 + hi * 8);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        s = MFMA_32x32x16_ST(kf, qf[ks], s, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void cross_attn_kernel(Cros
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const bf16x8 vf = read_perm_frag(sV, dt * 32 + ql, WS, nt * 32 + 16 * s2 + 4 * hi);
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[nt][s2], o[dt], 0, 0, 0);
+          o[dt] = MFMA_32x32x16_ST(vf, pf[nt][s2], o[dt], 0, 0, 0);
         }
     }
     if (q_ok) {
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void cross_attn_kernel(Cros
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 mf = read_perm_frag(sM, nt * 32 + ql, WS, wt * 32 + 16 * s2 + 4 * hi);
-        mix[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf, pf[wt][s2], mix[nt], 0, 0, 0);
+        mix[nt] = MFMA_32x32x16_ST(mf, pf[wt][s2], mix[nt], 0, 0, 0);
       }
   }
   __syncthreads();          // everyone is done with the source K / V^T
@@ -951,7 +953,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(AttnProbsParams p) {
       const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float kv = __uint_as_float((j & 1) ? (w[j >> 1] & 0xffff0000u) : (w[j >> 1] << 16));
+        const float kv = (j & 1) ? st_hi(w[j >> 1]) : st_lo(w[j >> 1]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += qs[r][c + j] * kv;
       }

@@ -5,8 +5,31 @@
 #include <stdio.h>
 #include <string>
 
-typedef uint16_t bf16_t;  // raw bfloat16 bits in memory
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// ---- the 16-bit storage format of activations and weights in HBM = the MFMA operand type.
+// Default: bfloat16, what BASELINE configs[1] names and what every measured figure of this repository is quoted on.
+// -DHEDIT_STORE_F16 compiles the SAME kernels on IEEE half (libhedit_hip_f16.so, build.py --f16): same MFMA rate, three more
+// mantissa bits -- the eps error of the SD UNet against the fp32 reference falls from 1.2e-2 to 1.7e-3 (DESIGN.md 5.0 item 3,
+// storage emulation), i.e. the "fp16 tolerance" of the reference's own half-precision mode (text-guided/main_p2p.py:106 loads fp32;
+// diffusers' torch_dtype=float16 is the mode users run).  The type names keep their bf16 spelling: `bf16_t` = 16 raw storage
+// bits, `bf16x8` = one MFMA operand register pair, pack_bf16x2 / bf16_to_f32 = the storage conversions of the build.
+// The split-bf16 "precise" GEMMs of the reward networks (pnet.hip) stay bf16 triples in either build (half's lo part would go
+// subnormal below 0.1): they use the *_always helpers and igemm_kernel's OPB instantiations.
+typedef uint16_t bf16_t;  // raw 16-bit storage element in memory
+#if defined(HEDIT_STORE_F16)
+#define HEDIT_F16 1
+typedef _Float16 st_elem_t;
+#define MFMA_16x16x32_ST __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define MFMA_32x32x16_ST __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define MFMA_ST_SFX "f16"
+#else
+#define HEDIT_F16 0
+typedef __bf16 st_elem_t;
+#define MFMA_16x16x32_ST __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MFMA_32x32x16_ST __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define MFMA_ST_SFX "bf16"
+#endif
+typedef __attribute__((ext_vector_type(8))) st_elem_t bf16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 true_bf16x8;      // operands of the split-bf16 GEMMs, either build
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -59,13 +82,14 @@ inline bool hedit_test_drained() { return (hedit_test_flags() & 1) != 0; }
     }                                                                                         \
   } while (0)
 
-// ---- bf16 <-> f32 (round to nearest even), usable on host and device
-__host__ __device__ inline float bf16_to_f32(bf16_t h) {
+// ---- bfloat16 <-> f32 proper (round to nearest even), usable on host and device: the split-bf16 path and the C entries that
+// are bf16 by contract in either build
+__host__ __device__ inline float bf16_to_f32_always(bf16_t h) {
   union { uint32_t u; float f; } v;
   v.u = ((uint32_t)h) << 16;
   return v.f;
 }
-__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+__host__ __device__ inline bf16_t f32_to_bf16_always(float f) {
   union { uint32_t u; float f; } v;
   v.f = f;
   uint32_t u = v.u;
@@ -73,12 +97,43 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
-// native conversion: lets the compiler emit v_cvt_pk_bf16_f32 (round-to-nearest-even)
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// ---- storage element <-> f32 (round to nearest even), host and device
+#if HEDIT_F16
+__host__ __device__ inline float bf16_to_f32(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__host__ __device__ inline bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+#else
+__host__ __device__ inline float bf16_to_f32(bf16_t h) { return bf16_to_f32_always(h); }
+__host__ __device__ inline bf16_t f32_to_bf16(float f) { return f32_to_bf16_always(f); }
+#endif
+// native conversion: lets the compiler emit v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 (round-to-nearest-even)
+typedef __attribute__((ext_vector_type(2))) st_elem_t bf16x2_t;
 __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
   union { bf16x2_t v; uint32_t u; } x;
-  x.v = (bf16x2_t){(__bf16)lo, (__bf16)hi};
+  x.v = (bf16x2_t){(st_elem_t)lo, (st_elem_t)hi};
   return x.u;
+}
+// 1.0 in the storage format, and the storage bits of a value that is exactly representable in it (attn.hip's folded shift)
+#if HEDIT_F16
+constexpr bf16_t ST_ONE_BITS = 0x3C00;
+__device__ __forceinline__ uint32_t st_exact_bits(float v) { return (uint32_t)__builtin_bit_cast(bf16_t, (_Float16)v); }
+#else
+constexpr bf16_t ST_ONE_BITS = 0x3F80;
+__device__ __forceinline__ uint32_t st_exact_bits(float v) { return __builtin_bit_cast(uint32_t, v) >> 16; }
+#endif
+// the two storage elements of a dword as fp32 (bfloat16: one shift / one mask; half: v_cvt_f32_f16)
+__device__ __forceinline__ float st_lo(uint32_t u) {
+#if HEDIT_F16
+  return (float)__builtin_bit_cast(bf16x2_t, u)[0];
+#else
+  return __builtin_bit_cast(float, u << 16);
+#endif
+}
+__device__ __forceinline__ float st_hi(uint32_t u) {
+#if HEDIT_F16
+  return (float)__builtin_bit_cast(bf16x2_t, u)[1];
+#else
+  return __builtin_bit_cast(float, u & 0xffff0000u);
+#endif
 }
 __device__ inline float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ inline float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

@@ -71,8 +71,8 @@ __host__ __device__ inline int ffn_unit_of_reg(int r, int hi) { return (r >> 2) 
 __device__ __forceinline__ void unpack8v(const u32x4& v, float* f) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    f[2 * q] = __builtin_bit_cast(float, v[q] << 16);
-    f[2 * q + 1] = __builtin_bit_cast(float, v[q] & 0xffff0000u);
+    f[2 * q] = st_lo(v[q]);
+    f[2 * q + 1] = st_hi(v[q]);
   }
 }
 
@@ -168,25 +168,25 @@ __device__ __forceinline__ void static_for(F&& f) {
 // accumulator are the hardware's back-to-back accumulate (same destination and C), and no VALU result feeds an MFMA
 // closer than several bundles (the H fragments are pinned an iteration early).
 __device__ __forceinline__ void mfma_s(f32x16& acc, const bf16x8& w, const bf16x8& a) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(a));
+  asm volatile("v_mfma_f32_32x32x16_" MFMA_ST_SFX " %0, %1, %2, %0" : "+v"(acc) : "v"(w), "a"(a));
 }
 // first MFMA of an FF1 chain: the accumulator start (bias) is a separate, read-only operand -- a v_mov into the
 // accumulator right in front of an asm MFMA would be a VALU-write -> MFMA-read hazard nobody pads.  The other way
 // round (the MFMA still reading C while something overwrites it) is excluded by keeping C's registers live for
 // several more MFMAs (the empty asm statement at bundle 9)
 __device__ __forceinline__ void mfma_s0(f32x16& acc, const bf16x8& w, const bf16x8& a, const f32x16& c) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(w), "a"(a), "v"(c));
+  asm volatile("v_mfma_f32_32x32x16_" MFMA_ST_SFX " %0, %1, %2, %3" : "=&v"(acc) : "v"(w), "a"(a), "v"(c));
 }
 // first MFMA of the second FF1 chain: C = 0 (inline constant)
 __device__ __forceinline__ void mfma_z(f32x16& acc, const bf16x8& w, const bf16x8& a) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "a"(a));
+  asm volatile("v_mfma_f32_32x32x16_" MFMA_ST_SFX " %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "a"(a));
 }
 __device__ __forceinline__ void mfma_o(f32x16& acc, const bf16x8& w, const bf16x8& h) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(h));
+  asm volatile("v_mfma_f32_32x32x16_" MFMA_ST_SFX " %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(h));
 }
 // linear layers: accumulator AND activation fragment in AGPRs
 __device__ __forceinline__ void mfma_l(f32x16& acc, const bf16x8& w, const bf16x8& a) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "a"(a));
+  asm volatile("v_mfma_f32_32x32x16_" MFMA_ST_SFX " %0, %1, %2, %0" : "+a"(acc) : "v"(w), "a"(a));
 }
 
 // GEGLU of one FF1 pair = 8 elements per lane (registers e and e + 8 of the pair's accumulator are value and gate of
@@ -314,10 +314,10 @@ __global__ __launch_bounds__(256, 1) void ffn_chain_kernel(ChainKernelParams p) 
         const int c = 2 * k + c2, nb = c / 4, q = c % 4;
         f32x4 bb = {0.f, 0.f, 0.f, 0.f};
         if (bias) bb = *reinterpret_cast<const f32x4*>(bias + nb * 32 + q * 8 + hi * 4);
-        O[nb][4 * q] = __builtin_bit_cast(float, half[c2][0] << 16) + bb[0];
-        O[nb][4 * q + 1] = __builtin_bit_cast(float, half[c2][0] & 0xffff0000u) + bb[1];
-        O[nb][4 * q + 2] = __builtin_bit_cast(float, half[c2][1] << 16) + bb[2];
-        O[nb][4 * q + 3] = __builtin_bit_cast(float, half[c2][1] & 0xffff0000u) + bb[3];
+        O[nb][4 * q] = st_lo(half[c2][0]) + bb[0];
+        O[nb][4 * q + 1] = st_hi(half[c2][0]) + bb[1];
+        O[nb][4 * q + 2] = st_lo(half[c2][1]) + bb[2];
+        O[nb][4 * q + 3] = st_hi(half[c2][1]) + bb[3];
       }
     }
   };

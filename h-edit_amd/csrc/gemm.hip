@@ -67,7 +67,18 @@ struct Smem {
 // product schedule (DRAIN = false) must reproduce bit for bit under memory load (the protocol that found round 3's race).
 // GNS (128-column tile): the epilogue also writes the GroupNorm pair statistics of the stored tile (gnstat.h) to p.gn_part.  A
 // template parameter, not a run-time branch: the instantiations without it are the kernels of the SD loop, untouched.
-template <int BM, int BN, int MODE, bool CHUNK, bool DRAIN = false, bool DEEP = false, bool GNS = false>
+// OPB (half-storage build only, HEDIT_STORE_F16): the operands are bfloat16 whatever the storage format -- the [hi | hi | lo]
+// triples of the split-bf16 GEMMs (pnet.hip), which only ever take the fp32 slab / raw-product exit of the epilogue.
+template <bool OPB>
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+#if HEDIT_F16
+  if constexpr (OPB)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(true_bf16x8, a), __builtin_bit_cast(true_bf16x8, b), c, 0, 0, 0);
+#endif
+  return MFMA_16x16x32_ST(a, b, c, 0, 0, 0);
+}
+
+template <int BM, int BN, int MODE, bool CHUNK, bool DRAIN = false, bool DEEP = false, bool GNS = false, bool OPB = false>
 __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = BM * 2;       // threads: 4 or 8 waves, each owning a 64 x BN/2 sub-tile
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<OPB>(wf[j], xf[i], acc[i][j]);
     };
     // half `part` (DMA groups 2*part, 2*part+1 of this wave) of the activation tile of tap row g -> tile g&1
     struct ASrc { unsigned v[2]; int s; };
@@ -500,7 +511,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<OPB>(wf[j], xf[i], acc[i][j]);
     };
     for (int t = 0; t < 3 && t < nk; ++t) issue_glds(kt_begin + t, t);
     if (nk > 0) {
@@ -586,7 +597,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<OPB>(wf[j], xf[i], acc[i][j]);
       __builtin_amdgcn_s_setprio(0);
     };
     // Steady state of one K-tile i (two MFMA groups of MI*NI, one barrier between them):
@@ -626,7 +637,7 @@ __global__ __launch_bounds__(BM * 2, 2) void igemm_kernel(GemmParams p) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<OPB>(wf[j], xf[i], acc[i][j]);
     };
     if (nk > 0) {
       issue_glds(kt_begin, 0);
@@ -952,6 +963,14 @@ int launch_igemm_impl(const GemmParams& p, int splits, hipStream_t st) {
   dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), splits);
   // the statistics epilogue: conv modes on the 128-column tile, launches that write the bf16 tile themselves (a split-K launch
   // leaves them to splitk_reduce_gn_kernel).  No drained twin: the K loop is the one of the GNS = false instantiation.
+#if HEDIT_F16
+  if (p.op_bf16) {      // (gemm_launch has checked that the launch leaves through the fp32 exit)
+    if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK, false, DEEP, false, true>), LDS)) return rc;
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, CHUNK, false, DEEP, false, true>), grid, dim3(BM * 2), LDS, st, p);
+    LAUNCH_CHECK();
+    return HEDIT_OK;
+  }
+#endif
   if constexpr (BN == 128 && MODE != 0) {
     if (p.gn_part && !p.partial) {
       if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, CHUNK, false, DEEP, true>), LDS)) return rc;
@@ -1135,6 +1154,7 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
   } else {
     p.partial = nullptr;
   }
+  ARG_CHECK(!p.op_bf16 || (p.raw_f32 && !p.geglu && !p.gn_part), "gemm: bfloat16-by-contract operands come with the raw fp32 output");
   if (p.gn_part) {
     ARG_CHECK(p.mode != 0 && !p.geglu && !p.raw_f32 && !p.ln_out, "gemm: pair statistics come with the bf16 tile of a convolution");
     ARG_CHECK(p.M % GNS_UNIT == 0 && p.N % 128 == 0 && gemm_pick_bn(p.N) == 128, "gemm: pair statistics need M % 128 == 0 and the 128-column tile");

@@ -34,6 +34,9 @@ struct GemmParams {
   // optional (conv modes, N % 128 == 0, M % 128 == 0): GroupNorm pair statistics of the stored output, [M / 128][N / 2][2] fp32
   // (gnstat.h): written by whichever kernel writes the bf16 tile, same bits for every execution form
   float* gn_part;
+  // the operands are bfloat16 whatever the storage format of the build (the split-bf16 triples of pnet.hip; raw_f32 output only).
+  // No effect in the bfloat16 build.
+  int op_bf16;
 };
 #ifndef GEMM_NOMINAL_BATCH
 #define GEMM_NOMINAL_BATCH 4   // the canonical chunking is sized for this many rows of the batch dimension

@@ -104,11 +104,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 // accumulator and activation fragment in AGPRs, the weight fragment in VGPRs (asm: the register files are ours to choose;
 // what the compiler does not do for an asm MFMA is hazard padding -- see settle / publish below and ffn.hip)
 __device__ __forceinline__ void mfma_l(f32x16& acc, const bf16x8& w, const bf16x8& a) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "a"(a));
+  asm volatile("v_mfma_f32_32x32x16_" MFMA_ST_SFX " %0, %1, %2, %0" : "+a"(acc) : "v"(w), "a"(a));
 }
 // first k-step of a layer: C = 0 (inline constant)
 __device__ __forceinline__ void mfma_l0(f32x16& acc, const bf16x8& w, const bf16x8& a) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(acc) : "v"(w), "a"(a));
+  asm volatile("v_mfma_f32_32x32x16_" MFMA_ST_SFX " %0, %1, %2, 0" : "=&a"(acc) : "v"(w), "a"(a));
 }
 
 // NPOST: layers behind the LayerNorm (1 or 3).  GNIN: the first layer's input is GroupNorm'd on the fly and there is no
@@ -262,8 +262,8 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
         float x[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          x[2 * e] = __builtin_bit_cast(float, raw[e] << 16);
-          x[2 * e + 1] = __builtin_bit_cast(float, raw[e] & 0xffff0000u);
+          x[2 * e] = st_lo(raw[e]);
+          x[2 * e + 1] = st_hi(raw[e]);
         }
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {
@@ -483,10 +483,10 @@ __global__ __launch_bounds__(256, 1) void lin_chain_kernel(LinKernelParams p) {
           float r4[4] = {0.f, 0.f, 0.f, 0.f};
           if constexpr (!GNIN) {
             const u32x2 u = *reinterpret_cast<const u32x2*>(smem + adr);
-            r4[0] = __builtin_bit_cast(float, u[0] << 16);
-            r4[1] = __builtin_bit_cast(float, u[0] & 0xffff0000u);
-            r4[2] = __builtin_bit_cast(float, u[1] << 16);
-            r4[3] = __builtin_bit_cast(float, u[1] & 0xffff0000u);
+            r4[0] = st_lo(u[0]);
+            r4[1] = st_hi(u[0]);
+            r4[2] = st_lo(u[1]);
+            r4[3] = st_hi(u[1]);
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {

@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
     const int pix = i / ppp, j = i - pix * ppp;
     const uint32_t u = xin[(long)pix * (C / 2) + j];
     gs_pairs[i] = u;
-    const float a = __uint_as_float(u << 16), c = __uint_as_float(u & 0xffff0000u);
+    const float a = st_lo(u), c = st_hi(u);
     s += a; s += c;
     q += a * a; q += c * c;
   }
@@ -645,8 +645,8 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
     const uint32_t u = gs_pairs[i];
     const int c0 = g * cpg + 2 * j;
     const float sc0 = rstd * gamma[c0], sc1 = rstd * gamma[c0 + 1];
-    float a = __uint_as_float(u << 16) * sc0 + (beta[c0] - m * sc0);
-    float c = __uint_as_float(u & 0xffff0000u) * sc1 + (beta[c0 + 1] - m * sc1);
+    float a = st_lo(u) * sc0 + (beta[c0] - m * sc0);
+    float c = st_hi(u) * sc1 + (beta[c0 + 1] - m * sc1);
     if (silu) { a = silu_f(a); c = silu_f(c); }
     yout[(long)pix * (C / 2) + j] = pack_bf16x2(a, c);
   }

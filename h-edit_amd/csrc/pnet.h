@@ -72,6 +72,7 @@ int pgemm(PF& f, const bf16_t* A, const PConv& c, bool dgrad, int mode, int Hin,
   p.ldc = N;
   TRY(palloc(f, out, (size_t)M * N));
   p.raw_f32 = *out;
+  p.op_bf16 = 1;
   // batch-independent summation order, as everywhere (gemm_canonical_chunk): the batch is in M
   p.chunk_kt = gemm_canonical_chunk((int)(M / f.B) * GEMM_NOMINAL_BATCH, N, p.K);
   const int splits = gemm_plan_splits(p.M, p.N, p.K, p.chunk_kt);

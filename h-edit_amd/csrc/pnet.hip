@@ -18,7 +18,7 @@
 
 namespace {
 
-__device__ __forceinline__ bf16_t bf16_rn(float f) { return f32_to_bf16(f); }
+__device__ __forceinline__ bf16_t bf16_rn(float f) { return f32_to_bf16_always(f); }   // bfloat16 in either build (common.h)
 
 // one thread per output element (row, j) of the bf16 operand [rows_out][Kp]; j -> (part, channel)
 __global__ __launch_bounds__(256) void split3_kernel(Split3Params s, long total) {
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void split3_kernel(Split3Params s, long total)
         }
       }
       const bf16_t hi = bf16_rn(v);
-      o = part == (s.worder ? 1 : 2) ? bf16_rn(v - bf16_to_f32(hi)) : hi;
+      o = part == (s.worder ? 1 : 2) ? bf16_rn(v - bf16_to_f32_always(hi)) : hi;
     }
     s.out[idx] = o;
   }
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void split3_v8_kernel(Split3Params s, long tot
             default: y = v[e];
           }
           const bf16_t hi = bf16_rn(y);
-          const bf16_t ov = part == (s.worder ? 1 : 2) ? bf16_rn(y - bf16_to_f32(hi)) : hi;
+          const bf16_t ov = part == (s.worder ? 1 : 2) ? bf16_rn(y - bf16_to_f32_always(hi)) : hi;
           if (e & 1) w[e >> 1] |= (uint32_t)ov << 16; else w[e >> 1] = ov;
         }
         o = make_uint4(w[0], w[1], w[2], w[3]);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void pack_split3_w_kernel(const float* __restr
       float v = w[((long)o * I + i) * kk + t];
       if (scale) v *= scale[o];
       const bf16_t hi = bf16_rn(v);
-      ov = part == 1 ? bf16_rn(v - bf16_to_f32(hi)) : hi;
+      ov = part == 1 ? bf16_rn(v - bf16_to_f32_always(hi)) : hi;
     }
     (void)rows_out;
     out[idx] = ov;

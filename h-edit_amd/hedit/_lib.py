@@ -3,7 +3,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhedit_hip.so")
+# HEDIT_STORAGE=f16 selects the half-storage build of the same kernels (`python h-edit_amd/build.py --f16`, csrc/common.h): same
+# MFMA rate, the eps error of the SD UNet against fp32 1.7e-3 instead of bfloat16's 1.2e-2.  One storage format per process,
+# decided before the library is first used.  Default and every benchmark figure: bfloat16 (BASELINE configs[1]).
+STORAGE = os.environ.get("HEDIT_STORAGE", "bf16").lower()
+if STORAGE not in ("bf16", "f16"):
+    raise ValueError(f"HEDIT_STORAGE must be bf16 or f16, not {STORAGE!r}")
+LIB_PATH = os.path.join(_HERE, "libhedit_hip_f16.so" if STORAGE == "f16" else "libhedit_hip.so")
 HEDIT_MAX_LEVELS = 8
 
 
@@ -169,6 +175,7 @@ _SIGS = {
     "hedit_k_gemm_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p]),
     "hedit_test_set_flags": (C.c_int, [C.c_int]),
+    "hedit_storage_is_f16": (C.c_int, []),
     "hedit_k_lin_chain_stream_bytes": (C.c_size_t, [C.c_int]),
     "hedit_k_lin_chain_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "hedit_k_lin_chain": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -223,15 +230,23 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise HipLibraryMissing(
-                f"{LIB_PATH} not found: build it with `python h-edit_amd/build.py` "
+                f"{LIB_PATH} not found: build it with `python h-edit_amd/build.py{' --f16' if STORAGE == 'f16' else ''}` "
                 "(hipcc --offload-arch=gfx950); hedit has no CPU/eager fallback")
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)     # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if bool(l.hedit_storage_is_f16()) != (STORAGE == "f16"):
+            raise HipLibraryMissing(f"{LIB_PATH} was not built for HEDIT_STORAGE={STORAGE}")
         _lib = l
     return _lib
+
+
+def storage_dtype():
+    """torch dtype of the 16-bit tensors the kernel-level entries (hedit_k_*) and the P2P mix tables exchange with the library"""
+    import torch
+    return torch.float16 if STORAGE == "f16" else torch.bfloat16
 
 
 class HipError(RuntimeError):

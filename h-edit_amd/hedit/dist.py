@@ -81,13 +81,15 @@ def broadcast_state_dict(shapes, sd, src=0, device="cpu", group=None, bf16_names
     the surplus keys come back as `UnexpectedKey` entries behind the real ones, so a strict load sees them everywhere."""
     rank = dist.get_rank(group)
     bf16_names = set(bf16_names)
-    plans = {torch.bfloat16: [], torch.float32: []}
-    totals = {torch.bfloat16: 0, torch.float32: 0}
+    from . import _lib
+    st16 = _lib.storage_dtype()       # bfloat16, or half in the HEDIT_STORAGE=f16 build: the executor's own 16-bit copies
+    plans = {st16: [], torch.float32: []}
+    totals = {st16: 0, torch.float32: 0}
     for name, shape in shapes.items():
-        dt = torch.bfloat16 if name in bf16_names else torch.float32
+        dt = st16 if name in bf16_names else torch.float32
         n = _numel(shape)
         plans[dt].append((name, tuple(shape), totals[dt], n))
-        align = 16 // (2 if dt == torch.bfloat16 else 4)
+        align = 16 // (2 if dt == st16 else 4)
         totals[dt] += (n + align - 1) // align * align
     extra = []
     if rank == src and problem is None:

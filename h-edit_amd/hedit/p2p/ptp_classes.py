@@ -203,7 +203,7 @@ class _PlanState:
             A, b = m._mix_tables()                      # (T1,77,77), (T1,77)
             mixT[:, i, :MAX_NUM_WORDS, :MAX_NUM_WORDS] = A.transpose(1, 2)
             bvec[:, i, :MAX_NUM_WORDS] = b
-        self.mixT = mixT.to(torch.bfloat16).contiguous().to(dev)
+        self.mixT = mixT.to(_lib.storage_dtype()).contiguous().to(dev)
         self.bvec = bvec.contiguous().to(dev)
         self.layers = unet.store_layers(H, W)
         heads = unet.heads

@@ -351,6 +351,11 @@ int hedit_k_lin_chain_sched(const void* a, int64_t lda, const void* r1, int64_t 
                             const float* bias_pre, const float* gamma, const float* beta, float eps, const void* w_stream, void* out_mid,
                             int64_t ldmid, void* out_q, int64_t ldq, void* out_k, int64_t ldk, void* out, int64_t ldo, int M, int C,
                             int sched, void* stream);
+/* The 16-bit storage format of this build: 0 = bfloat16 (libhedit_hip.so: the default, BASELINE configs[1], every benchmark
+ * figure), 1 = IEEE half (libhedit_hip_f16.so, `build.py --f16`: the same kernels with -DHEDIT_STORE_F16).  Wherever this header
+ * says "bf16" for a buffer of a kernel-level entry or for the P2P mix tables, read "the storage format of the build"; the
+ * executors' own boundaries (images, latents, eps, checkpoints) are fp32 in either build. */
+int hedit_storage_is_f16(void);
 /* Test switch (tests/test_gpu_ring_hazard.py), process-wide, 0 by default and in every product path.
  * bit 0: the kernels whose operand rings are retired by COUNTED s_waitcnt vmcnt(N) -- igemm_kernel's three-stage ring and
  *        row-sharing 3x3 loop, ffn_chain_kernel, self_attn_kernel -- launch their drained twin: every ring wait is vmcnt(0)

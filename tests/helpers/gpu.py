@@ -11,7 +11,7 @@ def dev():
 
 
 def bf(t):
-    return t.to(device=dev(), dtype=torch.bfloat16).contiguous()
+    return t.to(device=dev(), dtype=_lib.storage_dtype()).contiguous()
 
 
 def f32(t):

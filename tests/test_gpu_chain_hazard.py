@@ -45,9 +45,9 @@ class Chains:
         self.rows, self.N, self.M = rows, tokens, rows * tokens
         g = torch.Generator().manual_seed(seed)
         M, dev = self.M, self.dev
-        self.x = (torch.randn(M, C, generator=g) * 1.5).to(torch.bfloat16).to(dev)
-        self.a = torch.randn(M, C, generator=g).to(torch.bfloat16).to(dev)
-        self.t1 = (torch.randn(M, C, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+        self.x = (torch.randn(M, C, generator=g) * 1.5).to(_lib.storage_dtype()).to(dev)
+        self.a = torch.randn(M, C, generator=g).to(_lib.storage_dtype()).to(dev)
+        self.t1 = (torch.randn(M, C, generator=g) * 1.5).to(_lib.storage_dtype()).to(dev)
         self.gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(dev)
         self.beta = (0.1 * torch.randn(C, generator=g)).to(dev)
         self.bo = (0.3 * torch.randn(C, generator=g)).to(dev)
@@ -72,8 +72,8 @@ class Chains:
                                                    p(self.ws2), p(mid), C, None, 0, None, 0, p(q), C, M, C, sched, _lib.cur_stream()))
             return mid, q
         # GroupNorm apply -> proj_in -> norm1 -> q | k | v^T
-        mid, qk, vt = out if out else (torch.empty_like(self.x), torch.empty(M, 2 * C, dtype=torch.bfloat16, device=self.dev),
-                                       torch.empty(C, M, dtype=torch.bfloat16, device=self.dev))
+        mid, qk, vt = out if out else (torch.empty_like(self.x), torch.empty(M, 2 * C, dtype=_lib.storage_dtype(), device=self.dev),
+                                       torch.empty(C, M, dtype=_lib.storage_dtype(), device=self.dev))
         _lib.check(lib.hedit_k_lin_chain_sched(p(self.x), C, None, 0, p(self.ss), self.N, p(self.bo), p(self.gamma), p(self.beta), 1e-5,
                                                p(self.ws4), p(mid), C, p(qk), 2 * C, qk.data_ptr() + 2 * C, 2 * C, p(vt), M, M, C, sched,
                                                _lib.cur_stream()))

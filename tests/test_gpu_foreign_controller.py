@@ -61,7 +61,7 @@ def test_probabilities_and_apply_kernels(lib, d, heads, N, M, kstride):
     v = G.bf(torch.randn(B, kstride, Cc, generator=g))
     vt = v.reshape(B * kstride, Cc).t().contiguous()
     probs = torch.empty(B * heads, N, M, dtype=torch.float32, device=G.dev())
-    out = torch.zeros(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
+    out = torch.zeros(B, N, Cc, dtype=_lib.storage_dtype(), device=G.dev())
     _lib.check(lib.hedit_k_attn_probs(_lib.ptr(q), Cc, _lib.ptr(k), Cc, _lib.ptr(probs), B, N, M, kstride, heads, d, None))
     _lib.check(lib.hedit_k_attn_apply(_lib.ptr(probs), _lib.ptr(vt), B * kstride, _lib.ptr(out), Cc, B, N, M, kstride, heads, d, None))
     G.sync()

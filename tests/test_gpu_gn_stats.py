@@ -48,7 +48,7 @@ def conv_pair(lib, xb, wq, bias, res, B, H, Cin, Cout, mode, splits):
     M, K = B * Ho * Ho, 9 * Cin
     wsb = lib.hedit_k_gemm_ws_bytes(M, Cout, K, abs(splits))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=G.dev())
-    out = torch.zeros(M, Cout, dtype=torch.bfloat16, device=G.dev())
+    out = torch.zeros(M, Cout, dtype=_lib.storage_dtype(), device=G.dev())
     plain = torch.zeros_like(out)
     part = torch.full((M // 128, Cout // 2, 2), float("nan"), dtype=torch.float32, device=G.dev())
     _lib.check(lib.hedit_k_conv_gn(_lib.ptr(xb), _lib.ptr(wq), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(out), M, Cout, K, Cout, Cout,
@@ -82,7 +82,7 @@ def test_conv_epilogue_statistics_are_the_canonical_tree(lib, mode, B, H, Cin, C
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
     bias = G.f32(torch.randn(Cout, generator=g))
     xb = G.bf(x)
-    wq = torch.empty(Cout * 9 * Cin, dtype=torch.bfloat16, device=G.dev())
+    wq = torch.empty(Cout * 9 * Cin, dtype=_lib.storage_dtype(), device=G.dev())
     wd = G.f32(w)
     _lib.check(lib.hedit_k_pack_conv3x3(_lib.ptr(wd), _lib.ptr(wq), Cout, Cin, None))
     Ho = H // 2 if mode == 2 else (2 * H if mode == 3 else H)
@@ -105,7 +105,7 @@ def test_chunk_fold_and_split_k_write_the_same_statistics(lib):
     g = torch.Generator().manual_seed(9)
     B, H, Cin, Cout = 16, 64, 128, 256
     xb = G.bf(torch.randn(B, H, H, Cin, generator=g))
-    wq = torch.empty(Cout * 9 * Cin, dtype=torch.bfloat16, device=G.dev())
+    wq = torch.empty(Cout * 9 * Cin, dtype=_lib.storage_dtype(), device=G.dev())
     wd = G.f32(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
     _lib.check(lib.hedit_k_pack_conv3x3(_lib.ptr(wd), _lib.ptr(wq), Cout, Cin, None))
     bias = G.f32(torch.randn(Cout, generator=g))
@@ -152,9 +152,9 @@ def test_groupnorm_from_parts(lib, B, HW, ca, cb, silu):
 
 
 def test_conv_gn_rejects_shapes_without_the_128_column_tile(lib):
-    x = torch.zeros(1, 32, 32, 64, dtype=torch.bfloat16, device=G.dev())
-    w = torch.zeros(320 * 9 * 64, dtype=torch.bfloat16, device=G.dev())
-    out = torch.zeros(1024, 320, dtype=torch.bfloat16, device=G.dev())
+    x = torch.zeros(1, 32, 32, 64, dtype=_lib.storage_dtype(), device=G.dev())
+    w = torch.zeros(320 * 9 * 64, dtype=_lib.storage_dtype(), device=G.dev())
+    out = torch.zeros(1024, 320, dtype=_lib.storage_dtype(), device=G.dev())
     part = torch.zeros(8, 160, 2, device=G.dev())
     rc = lib.hedit_k_conv_gn(_lib.ptr(x), _lib.ptr(w), None, None, _lib.ptr(out), 1024, 320, 576, 320, 320, 1, 32, 32, 64, 32, 32, 0,
                              None, _lib.ptr(part), None)

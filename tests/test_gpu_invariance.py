@@ -29,7 +29,7 @@ def lib():
 
 
 def _gemm(lib, A, W, bias, res, M, N, K, lda, mode, conv, splits):
-    out = torch.zeros(M, N, dtype=torch.bfloat16, device=G.dev())
+    out = torch.zeros(M, N, dtype=_lib.storage_dtype(), device=G.dev())
     ws = torch.empty(max(lib.hedit_k_gemm_ws_bytes(M, N, K, abs(splits)), 16), dtype=torch.uint8, device=G.dev())
     _lib.check(lib.hedit_k_gemm(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(out), M, N, K,
                                 lda, N, N, mode, *conv, splits, _lib.ptr(ws), None))
@@ -63,7 +63,7 @@ def test_conv_chunks_folded_equal_slabs(lib, mode, B, H, Wd, Cin, Cout, S):
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
     bias = G.f32(torch.randn(Cout, generator=g))
     xb = G.bf(x)
-    wq = torch.empty(Cout * 9 * Cin, dtype=torch.bfloat16, device=G.dev())
+    wq = torch.empty(Cout * 9 * Cin, dtype=_lib.storage_dtype(), device=G.dev())
     _lib.check(lib.hedit_k_pack_conv3x3(_lib.ptr(G.f32(w)), _lib.ptr(wq), Cout, Cin, None))
     Ho, Wo = (H // 2, Wd // 2) if mode == 2 else ((2 * H, 2 * Wd) if mode == 3 else (H, Wd))
     M = B * Ho * Wo

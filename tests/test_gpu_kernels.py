@@ -23,7 +23,7 @@ def lib():
 
 
 def run_gemm(lib, A, W, bias, res, M, N, K, lda, ldc, ldr, mode=0, conv=(0, 0, 0, 0, 0), splits=0):
-    out = torch.zeros(M, ldc, dtype=torch.bfloat16, device=G.dev())
+    out = torch.zeros(M, ldc, dtype=_lib.storage_dtype(), device=G.dev())
     wsb = lib.hedit_k_gemm_ws_bytes(M, N, K, splits)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=G.dev())
     _lib.check(lib.hedit_k_gemm(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(out), M, N, K,
@@ -58,7 +58,7 @@ def test_gemm_conv3x3(lib, mode, B, H, Wd, Cin, Cout):
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
     bias = torch.randn(Cout, generator=g)
     xb = G.bf(x.permute(0, 2, 3, 1))                       # NHWC
-    wq = torch.empty(Cout * 9 * Cin, dtype=torch.bfloat16, device=G.dev())
+    wq = torch.empty(Cout * 9 * Cin, dtype=_lib.storage_dtype(), device=G.dev())
     wd = G.f32(w)
     _lib.check(lib.hedit_k_pack_conv3x3(_lib.ptr(wd), _lib.ptr(wq), Cout, Cin, None))
     xr = xb.float().permute(0, 3, 1, 2)
@@ -93,7 +93,7 @@ def test_conv3x3_row_sharing_loop_bits(lib, mode, B, H, Cin, Cout, splits):
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
     bias = G.f32(torch.randn(Cout, generator=g))
     xb = G.bf(x.permute(0, 2, 3, 1))
-    wq = torch.empty(Cout * 9 * Cin, dtype=torch.bfloat16, device=G.dev())
+    wq = torch.empty(Cout * 9 * Cin, dtype=_lib.storage_dtype(), device=G.dev())
     wd = G.f32(w)
     _lib.check(lib.hedit_k_pack_conv3x3(_lib.ptr(wd), _lib.ptr(wq), Cout, Cin, None))
     Ho = H if mode == 1 else 2 * H
@@ -114,7 +114,7 @@ def test_conv3x3_row_sharing_loop_bits(lib, mode, B, H, Cin, Cout, splits):
     if mode == 3:
         xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
     want = F.conv2d(xr, G.bf(w).float(), bias, padding=1).permute(0, 2, 3, 1).reshape(B * Ho * Ho, Cout)
-    want = want.to(torch.bfloat16).float() + res.float()
+    want = want.to(_lib.storage_dtype()).float() + res.float()
     assert G.rel_err(big.float(), want) < 6e-3
 
 
@@ -145,7 +145,7 @@ def test_layernorm_geglu(lib, rows, Cc):
     G.sync()
     assert G.rel_err(y.float(), F.layer_norm(x.float(), (Cc,), gamma, beta, 1e-5)) < 5e-3
     inner = Cc // 2
-    z = torch.empty(rows, inner, dtype=torch.bfloat16, device=G.dev())
+    z = torch.empty(rows, inner, dtype=_lib.storage_dtype(), device=G.dev())
     _lib.check(lib.hedit_k_geglu(_lib.ptr(x), _lib.ptr(z), rows, inner, None))
     G.sync()
     h, gt = x.float().chunk(2, dim=-1)
@@ -161,13 +161,13 @@ def test_gemm_geglu_fused(lib, M, inner, K):
     w = torch.randn(2 * inner, K, generator=g) / math.sqrt(K)
     b = torch.randn(2 * inner, generator=g) * 0.5
     wd, bd = G.f32(w), G.f32(b)
-    wp = torch.empty(2 * inner, K, dtype=torch.bfloat16, device=G.dev())
+    wp = torch.empty(2 * inner, K, dtype=_lib.storage_dtype(), device=G.dev())
     bp = torch.empty(2 * inner, dtype=torch.float32, device=G.dev())
     _lib.check(lib.hedit_k_pack_geglu(_lib.ptr(wd), _lib.ptr(bd), _lib.ptr(wp), _lib.ptr(bp), inner, K, None))
-    out = torch.zeros(M, inner, dtype=torch.bfloat16, device=G.dev())
+    out = torch.zeros(M, inner, dtype=_lib.storage_dtype(), device=G.dev())
     _lib.check(lib.hedit_k_gemm_geglu(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bp), _lib.ptr(out), M, inner, K, K, inner, None))
     G.sync()
-    proj = x.float() @ wd.to(torch.bfloat16).float().t() + bd
+    proj = x.float() @ wd.to(_lib.storage_dtype()).float().t() + bd
     h, gate = proj.chunk(2, dim=-1)
     want = h * F.gelu(gate)
     assert G.rel_err(out.float(), want) < 6e-3
@@ -206,23 +206,23 @@ def test_ffn_fused(lib, M):
     summation order inside a 32-deep FF2 k-step."""
     Cc, x, gamma, beta, w1, b1, w2, b2, ws, bp = _ffn_setup(lib, M, 11 + M)
     out = _ffn_run(lib, x, gamma, beta, ws, bp, b2, Cc)
-    xn = F.layer_norm(x.float(), (Cc,), gamma, beta, 1e-5).to(torch.bfloat16).float()
-    proj = xn @ w1.to(torch.bfloat16).float().t() + b1
+    xn = F.layer_norm(x.float(), (Cc,), gamma, beta, 1e-5).to(_lib.storage_dtype()).float()
+    proj = xn @ w1.to(_lib.storage_dtype()).float().t() + b1
     h, gate = proj.chunk(2, dim=-1)
-    hid = (h * F.gelu(gate)).to(torch.bfloat16).float()
-    y = (hid @ w2.to(torch.bfloat16).float().t() + b2).to(torch.bfloat16).float()
+    hid = (h * F.gelu(gate)).to(_lib.storage_dtype()).float()
+    y = (hid @ w2.to(_lib.storage_dtype()).float().t() + b2).to(_lib.storage_dtype()).float()
     want = y + x.float()
     assert torch.isfinite(out.float()).all()
     assert G.rel_err(out.float(), want) < 6e-3
     # the unfused chain of the same library
     xn_k = torch.empty_like(x)
     _lib.check(lib.hedit_k_layernorm(_lib.ptr(x), _lib.ptr(xn_k), _lib.ptr(gamma), _lib.ptr(beta), M, Cc, 1e-5, None))
-    wp = torch.empty(8 * Cc, Cc, dtype=torch.bfloat16, device=G.dev())
+    wp = torch.empty(8 * Cc, Cc, dtype=_lib.storage_dtype(), device=G.dev())
     b1p = torch.empty(8 * Cc, dtype=torch.float32, device=G.dev())
     _lib.check(lib.hedit_k_pack_geglu(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(wp), _lib.ptr(b1p), 4 * Cc, Cc, None))
-    hid_k = torch.empty(M, 4 * Cc, dtype=torch.bfloat16, device=G.dev())
+    hid_k = torch.empty(M, 4 * Cc, dtype=_lib.storage_dtype(), device=G.dev())
     _lib.check(lib.hedit_k_gemm_geglu(_lib.ptr(xn_k), _lib.ptr(wp), _lib.ptr(b1p), _lib.ptr(hid_k), M, 4 * Cc, Cc, Cc, 4 * Cc, None))
-    w2b = w2.to(torch.bfloat16).contiguous()
+    w2b = w2.to(_lib.storage_dtype()).contiguous()
     out_k = torch.empty_like(x)
     _lib.check(lib.hedit_k_gemm(_lib.ptr(hid_k), _lib.ptr(w2b), _lib.ptr(b2), _lib.ptr(x), _lib.ptr(out_k), M, Cc, 4 * Cc,
                                 4 * Cc, Cc, Cc, 0, 0, 0, 0, 0, 0, 1, None, None))
@@ -263,14 +263,14 @@ def test_lin_chain_out_then_query(lib, M, impl):
 
     def run(a_, r1_):
         m = a_.shape[0]
-        mid = torch.zeros(m, Cc, dtype=torch.bfloat16, device=G.dev())
-        q = torch.zeros(m, Cc, dtype=torch.bfloat16, device=G.dev())
+        mid = torch.zeros(m, Cc, dtype=_lib.storage_dtype(), device=G.dev())
+        q = torch.zeros(m, Cc, dtype=_lib.storage_dtype(), device=G.dev())
         _lib.check(f_run(_lib.ptr(a_), Cc, _lib.ptr(r1_), Cc, None, 0, _lib.ptr(bo), _lib.ptr(gamma), _lib.ptr(beta), 1e-5,
                                          _lib.ptr(ws), _lib.ptr(mid), Cc, None, 0, None, 0, _lib.ptr(q), Cc, m, Cc, None))
         G.sync()
         return mid, q
     mid, q = run(a, r1)
-    bfr = lambda t: t.to(torch.bfloat16).float()
+    bfr = lambda t: t.to(_lib.storage_dtype()).float()
     t1 = a.float() @ bfr(wo).t() + bo + r1.float()
     want_q = bfr(F.layer_norm(t1, (Cc,), gamma, beta, 1e-5)) @ bfr(wq * scale).t()
     assert torch.isfinite(q.float()).all()
@@ -309,16 +309,16 @@ def test_lin_chain_groupnorm_to_qkv(lib, B, N, impl):
         m = b * N
         ss = torch.empty(b, Cc, 2, dtype=torch.float32, device=G.dev())
         _lib.check(lib.hedit_k_groupnorm_affine(_lib.ptr(x_), _lib.ptr(gn_g), _lib.ptr(gn_b), b, N, Cc, 32, 1e-6, _lib.ptr(gws), _lib.ptr(ss), None))
-        mid = torch.zeros(m, Cc, dtype=torch.bfloat16, device=G.dev())
-        qk = torch.zeros(m, 2 * Cc, dtype=torch.bfloat16, device=G.dev())
-        vt = torch.zeros(Cc, m, dtype=torch.bfloat16, device=G.dev())
+        mid = torch.zeros(m, Cc, dtype=_lib.storage_dtype(), device=G.dev())
+        qk = torch.zeros(m, 2 * Cc, dtype=_lib.storage_dtype(), device=G.dev())
+        vt = torch.zeros(Cc, m, dtype=_lib.storage_dtype(), device=G.dev())
         _lib.check(f_run(_lib.ptr(x_), Cc, None, 0, _lib.ptr(ss), N, _lib.ptr(b_in), _lib.ptr(gamma), _lib.ptr(beta), 1e-5,
                          _lib.ptr(ws), _lib.ptr(mid), Cc, _lib.ptr(qk), 2 * Cc, qk.data_ptr() + 2 * Cc, 2 * Cc,
                          _lib.ptr(vt), m, m, Cc, None))
         G.sync()
         return mid, qk, vt
     mid, qk, vt = run(x)
-    bfr = lambda t: t.to(torch.bfloat16).float()
+    bfr = lambda t: t.to(_lib.storage_dtype()).float()
     xf = x.float()
     xg = F.group_norm(xf.transpose(1, 2), 32, gn_g, gn_b, 1e-6).transpose(1, 2).reshape(M, Cc)
     t0 = bfr(xg) @ bfr(w_in).t() + b_in
@@ -355,7 +355,7 @@ def test_ffn_chain(lib, M):
     bp = torch.empty(lib.hedit_k_ffn_bias_bytes(), dtype=torch.uint8, device=G.dev())
     _lib.check(lib.hedit_k_ffn_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(wo), _lib.ptr(wp), _lib.ptr(ws), _lib.ptr(bp), None))
     ld_o = Cc + 320                                                 # ... and the result goes into a concatenation buffer
-    outw = torch.zeros(M, ld_o, dtype=torch.bfloat16, device=G.dev())
+    outw = torch.zeros(M, ld_o, dtype=_lib.storage_dtype(), device=G.dev())
 
     def run(a_, t1_, xw_, outw_):
         _lib.check(lib.hedit_k_ffn_chain(_lib.ptr(a_), Cc, _lib.ptr(t1_), Cc, _lib.ptr(xw_), ld_x, _lib.ptr(bo), _lib.ptr(gamma), _lib.ptr(beta),
@@ -364,7 +364,7 @@ def test_ffn_chain(lib, M):
     run(a, t1, xw, outw)
     out = outw[:, :Cc]
     assert float(outw[:, Cc:].abs().max()) == 0.0
-    bfr = lambda t: t.to(torch.bfloat16).float()
+    bfr = lambda t: t.to(_lib.storage_dtype()).float()
     t2 = a.float() @ bfr(wo).t() + bo + t1.float()
     xn = bfr(F.layer_norm(t2, (Cc,), gamma, beta, 1e-5))
     proj = xn @ bfr(w1).t() + b1
@@ -374,15 +374,15 @@ def test_ffn_chain(lib, M):
     assert torch.isfinite(out.float()).all()
     assert G.rel_err(out.float(), want) < 6e-3
     # the chain of single kernels (t2 and t3 rounded to bf16 in between, as they were in HBM)
-    t2_k = torch.empty(M, Cc, dtype=torch.bfloat16, device=G.dev())
-    _lib.check(lib.hedit_k_gemm(_lib.ptr(a), _lib.ptr(wo.to(torch.bfloat16).contiguous()), _lib.ptr(bo), _lib.ptr(t1), _lib.ptr(t2_k), M, Cc, Cc,
+    t2_k = torch.empty(M, Cc, dtype=_lib.storage_dtype(), device=G.dev())
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(a), _lib.ptr(wo.to(_lib.storage_dtype()).contiguous()), _lib.ptr(bo), _lib.ptr(t1), _lib.ptr(t2_k), M, Cc, Cc,
                                 Cc, Cc, Cc, 0, 0, 0, 0, 0, 0, 1, None, None))
     ws0 = torch.empty(lib.hedit_k_ffn_stream_bytes(0), dtype=torch.uint8, device=G.dev())
     _lib.check(lib.hedit_k_ffn_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), None, None, _lib.ptr(ws0), _lib.ptr(bp), None))
     t3_k = _ffn_run(lib, t2_k, gamma, beta, ws0, bp, b2, Cc)
-    out_k = torch.empty(M, Cc, dtype=torch.bfloat16, device=G.dev())
+    out_k = torch.empty(M, Cc, dtype=_lib.storage_dtype(), device=G.dev())
     xc = x.contiguous()
-    _lib.check(lib.hedit_k_gemm(_lib.ptr(t3_k), _lib.ptr(wp.to(torch.bfloat16).contiguous()), _lib.ptr(bpo), _lib.ptr(xc), _lib.ptr(out_k), M, Cc, Cc,
+    _lib.check(lib.hedit_k_gemm(_lib.ptr(t3_k), _lib.ptr(wp.to(_lib.storage_dtype()).contiguous()), _lib.ptr(bpo), _lib.ptr(xc), _lib.ptr(out_k), M, Cc, Cc,
                                 Cc, Cc, Cc, 0, 0, 0, 0, 0, 0, 1, None, None))
     G.sync()
     assert G.rel_err(out.float(), out_k.float()) < 6e-3
@@ -391,7 +391,7 @@ def test_ffn_chain(lib, M):
     run(a, t1, xw, again)
     assert torch.equal(again, outw)
     lo = min(M - 1, 100)
-    part = torch.zeros(M - lo, ld_o, dtype=torch.bfloat16, device=G.dev())
+    part = torch.zeros(M - lo, ld_o, dtype=_lib.storage_dtype(), device=G.dev())
     run(a[lo:].contiguous(), t1[lo:].contiguous(), xw[lo:].contiguous(), part)
     assert torch.equal(part, outw[lo:])
 
@@ -419,7 +419,7 @@ def test_self_attention(lib, d, heads, N, B):
     v = G.bf(torch.randn(B, N, Cc, generator=g))
     qk = torch.cat([q, k], dim=-1).contiguous()                       # [B*N][2C]
     vt = v.reshape(B * N, Cc).t().contiguous()                        # [C][B*N]
-    out = torch.zeros(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
+    out = torch.zeros(B, N, Cc, dtype=_lib.storage_dtype(), device=G.dev())
     k_view = qk.reshape(B * N, 2 * Cc)[:, Cc:]
     _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * Cc, C.c_void_p(k_view.data_ptr()), 2 * Cc, _lib.ptr(vt),
                                      B * N, _lib.ptr(out), Cc, B, N, heads, d, None, None, None))
@@ -453,7 +453,7 @@ def test_self_attention_is_deterministic(lib, d, heads, N):
     k_view = qk[:, Cc:]
     outs = []
     for _ in range(3):
-        out = torch.zeros(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
+        out = torch.zeros(B, N, Cc, dtype=_lib.storage_dtype(), device=G.dev())
         _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * Cc, C.c_void_p(k_view.data_ptr()), 2 * Cc, _lib.ptr(vt),
                                          B * N, _lib.ptr(out), Cc, B, N, heads, d, None, None, None))
         G.sync()
@@ -475,7 +475,7 @@ def test_self_attention_online_softmax_rescale(lib):
     q, k, v = G.bf(q), G.bf(k), G.bf(v)
     qk = torch.cat([q, k], dim=-1).contiguous()
     vt = v.reshape(B * N, Cc).t().contiguous()
-    out = torch.zeros(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
+    out = torch.zeros(B, N, Cc, dtype=_lib.storage_dtype(), device=G.dev())
     k_view = qk.reshape(B * N, 2 * Cc)[:, Cc:]
     _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * Cc, C.c_void_p(k_view.data_ptr()), 2 * Cc, _lib.ptr(vt),
                                      B * N, _lib.ptr(out), Cc, B, N, heads, d, None, None, None))
@@ -509,7 +509,7 @@ def test_self_attention_pinned_shift_and_exact_fallback(lib, d, heads, N, lift):
     k_view = qk.reshape(B * N, 2 * Cc)[:, Cc:]
     outs = []
     for _ in range(2):
-        out = torch.zeros(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
+        out = torch.zeros(B, N, Cc, dtype=_lib.storage_dtype(), device=G.dev())
         _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * Cc, C.c_void_p(k_view.data_ptr()), 2 * Cc, _lib.ptr(vt),
                                          B * N, _lib.ptr(out), Cc, B, N, heads, d, None, None, None))
         G.sync()
@@ -521,7 +521,7 @@ def test_self_attention_pinned_shift_and_exact_fallback(lib, d, heads, N, lift):
     for (b, qi, ki) in rows:                                                       # the rows the spikes own
         assert G.max_err(outs[0][b, qi].float(), want[b, qi]) < 3e-2
     # a block's path depends on its own rows only: the second batch row alone gives the same bits
-    out1 = torch.zeros(1, N, Cc, dtype=torch.bfloat16, device=G.dev())
+    out1 = torch.zeros(1, N, Cc, dtype=_lib.storage_dtype(), device=G.dev())
     qk1, vt1 = qk[1:].contiguous(), v[1].reshape(N, Cc).t().contiguous()
     _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk1), 2 * Cc, C.c_void_p(qk1.reshape(N, 2 * Cc)[:, Cc:].data_ptr()), 2 * Cc,
                                      _lib.ptr(vt1), N, _lib.ptr(out1), Cc, 1, N, heads, d, None, None, None))
@@ -555,7 +555,7 @@ def test_cross_attention_p2p(lib, d, heads, N):
     mixT_d, bv_d = G.bf(mixT), G.f32(bv)
     plan, keep = G.make_plan(n_pairs=1, pair_src=[2], pair_tar=[3], singles=[0, 1], mixT=mixT_d, bvec=bv_d, mode=2)
     store = torch.zeros(1, 2, heads, N, 77, dtype=torch.float32, device=G.dev())
-    out = torch.zeros(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
+    out = torch.zeros(B, N, Cc, dtype=_lib.storage_dtype(), device=G.dev())
     for rep in range(2):        # two passes: the store must accumulate
         _lib.check(lib.hedit_k_cross_attn(_lib.ptr(q), Cc, _lib.ptr(kc), Cc, _lib.ptr(vt), B * CT, _lib.ptr(out),
                                           Cc, B, N, heads, d, C.byref(plan), _lib.ptr(store), None))

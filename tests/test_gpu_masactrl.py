@@ -25,17 +25,17 @@ def test_self_attention_reads_kv_of_another_row(heads, d, N):
     g = torch.Generator().manual_seed(heads * 1000 + N)
     q, k, v = (torch.randn(B, N, Cc, generator=g) * 0.5 for _ in range(3))
     scale = d ** -0.5 * 1.4426950408889634
-    qk = torch.cat([q * scale, k], dim=-1).to(torch.bfloat16).to(G.dev()).contiguous()
-    vt = v.to(torch.bfloat16).permute(2, 0, 1).reshape(Cc, B * N).contiguous().to(G.dev())
-    out = torch.empty(B, N, Cc, dtype=torch.bfloat16, device=G.dev())
+    qk = torch.cat([q * scale, k], dim=-1).to(_lib.storage_dtype()).to(G.dev()).contiguous()
+    vt = v.to(_lib.storage_dtype()).permute(2, 0, 1).reshape(Cc, B * N).contiguous().to(G.dev())
+    out = torch.empty(B, N, Cc, dtype=_lib.storage_dtype(), device=G.dev())
     src = torch.tensor([0, 0, 2, 2], dtype=torch.int32, device=G.dev())
     k_view = qk.view(B * N, 2 * Cc)[:, Cc:]
     _lib.check(lib.hedit_k_self_attn(_lib.ptr(qk), 2 * Cc, C.c_void_p(k_view.data_ptr()), 2 * Cc, _lib.ptr(vt), B * N,
                                      _lib.ptr(out), Cc, B, N, heads, d, None, _lib.ptr(src), None))
     G.sync()
-    qb = q.to(torch.bfloat16).float().reshape(B, N, heads, d).transpose(1, 2)
-    kb = k.to(torch.bfloat16).float().reshape(B, N, heads, d).transpose(1, 2)[src.cpu().long()]
-    vb = v.to(torch.bfloat16).float().reshape(B, N, heads, d).transpose(1, 2)[src.cpu().long()]
+    qb = q.to(_lib.storage_dtype()).float().reshape(B, N, heads, d).transpose(1, 2)
+    kb = k.to(_lib.storage_dtype()).float().reshape(B, N, heads, d).transpose(1, 2)[src.cpu().long()]
+    vb = v.to(_lib.storage_dtype()).float().reshape(B, N, heads, d).transpose(1, 2)[src.cpu().long()]
     want = (torch.softmax(qb @ kb.transpose(-1, -2) * d ** -0.5, -1) @ vb).transpose(1, 2).reshape(B, N, Cc)
     assert G.rel_err(out.float(), want) < 1.2e-2
 

@@ -40,7 +40,7 @@ DEV = "cuda:0"
 
 
 def _bf(t):
-    return t.to(torch.bfloat16).to(DEV)
+    return t.to(_lib.storage_dtype()).to(DEV)
 
 
 def _stress(run, launches, hog):
@@ -128,7 +128,7 @@ class Gemm:
         self.ws = torch.empty(max(self.lib.hedit_k_gemm_ws_bytes(self.M, N, self.K, abs(chunks)), 16), dtype=torch.uint8, device=DEV)
 
     def run(self, out=None):
-        o = out[0] if out else torch.empty(self.M, self.N, dtype=torch.bfloat16, device=DEV)
+        o = out[0] if out else torch.empty(self.M, self.N, dtype=_lib.storage_dtype(), device=DEV)
         p = _lib.ptr
         _lib.check(self.lib.hedit_k_gemm(p(self.A), p(self.W), p(self.bias), p(self.R), p(o), self.M, self.N, self.K,
                                          self.cin if self.mode else self.K, self.N, self.N, self.mode, *self.conv, self.splits,
@@ -161,7 +161,7 @@ def test_igemm_drained_twin_matches_fp32():
     x = gm.A.float().reshape(8, 64, 64, 128).permute(0, 3, 1, 2)
     w4 = gm.W.float().view(128, 3, 3, 128).permute(0, 3, 1, 2).contiguous()
     ref = torch.nn.functional.conv2d(x, w4, gm.bias, padding=1).permute(0, 2, 3, 1).reshape(gm.M, 128)
-    ref = ref.to(torch.bfloat16).float() + gm.R.float()
+    ref = ref.to(_lib.storage_dtype()).float() + gm.R.float()
     assert float((o.float() - ref).norm() / ref.norm()) < 4e-3
 
 
@@ -189,7 +189,7 @@ class Ffn:
         torch.cuda.synchronize()
 
     def run(self, out=None):
-        o = out[0] if out else torch.empty(self.M, self.C, dtype=torch.bfloat16, device=DEV)
+        o = out[0] if out else torch.empty(self.M, self.C, dtype=_lib.storage_dtype(), device=DEV)
         p, Cc = _lib.ptr, self.C
         if self.outer:
             _lib.check(self.lib.hedit_k_ffn_chain(p(self.a), Cc, p(self.t1), Cc, p(self.x), Cc, p(self.bpre), p(self.gamma), p(self.beta),
@@ -230,7 +230,7 @@ class SelfAttn:
         self.k_ptr = C.c_void_p(self.qk.reshape(B * N, 2 * Cc)[:, Cc:].data_ptr())
 
     def run(self, out=None):
-        o = out[0] if out else torch.empty(self.B, self.N, self.Cc, dtype=torch.bfloat16, device=DEV)
+        o = out[0] if out else torch.empty(self.B, self.N, self.Cc, dtype=_lib.storage_dtype(), device=DEV)
         _lib.check(self.lib.hedit_k_self_attn(_lib.ptr(self.qk), 2 * self.Cc, self.k_ptr, 2 * self.Cc, _lib.ptr(self.vt), self.B * self.N,
                                               _lib.ptr(o), self.Cc, self.B, self.N, self.heads, self.d, None, None, _lib.cur_stream()))
         return (o,)
