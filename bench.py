@@ -48,12 +48,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--images", type=int, default=24, help="images edited in lock-step per GPU (one 'step'); 24 = 120-row UNet calls: +5 % over 8 and +2.5 % over 16, flat beyond")
+    ap.add_argument("--images", type=int, default=24, help="images edited in lock-step per GPU (one 'step'); 24 = 120-row UNet calls: +5 %% over 8 and +2.5 %% over 16, flat beyond")
     ap.add_argument("--diffusion-steps", type=int, default=50)
     ap.add_argument("--opt-steps", type=int, default=1, help="implicit optimisation ('Langevin') steps K")
     ap.add_argument("--workload", choices=("p2p", "style", "face"), default="p2p",
                     help="p2p = BASELINE configs[1] (the quoted metric, default); style = configs[4], combined "
                          "text + CLIP-style editing: every step adds VAE decode forward + backward and the style encoder")
+    ap.add_argument("--storage", choices=("bf16", "f16"), default=None,
+                    help="16-bit storage format of activations / weights: bf16 = BASELINE configs[1] and the default line; f16 = the "
+                         "half-storage build of the same kernels (libhedit_hip_f16.so, eps error 1.5e-3 instead of 1.2e-2 vs fp32). "
+                         "Default: the HEDIT_STORAGE environment variable, else bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-every", type=int, default=25, help="bracket every n-th UNet call with HIP events")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny network instead of SD-1.5 shape")
@@ -132,7 +136,7 @@ def face_pass(args, rank, dev, dist, n, T, K, steps, warmup):
     return {
         "metric": "face-swapped images/sec (256^2, 100 steps, K=3)", "value": round(imgs / elapsed, 4), "unit": "images/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.storage, "data": "synthetic",
         "config": {"workload": "BASELINE configs[3] per GPU: face-swapping h_Edit_R, CelebA-HQ-256-shaped random-init pixel DDPM "
                                f"UNet (113.7M), ArcFace IR-SE50 identity reward + LPIPS-VGG16 reward (native, random init), {T} steps, "
                                f"K={K}; {n} faces per GPU in lock-step",
@@ -161,6 +165,9 @@ def run_face(args, world, rank, local, dev, dist):
 
 def main():
     args = parse()
+    if args.storage:                        # decided before hedit is first imported: one storage format per process
+        os.environ["HEDIT_STORAGE"] = args.storage
+    args.storage = os.environ.get("HEDIT_STORAGE", "bf16").lower()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -480,7 +487,7 @@ def main():
         "metric": "edited images/sec (512^2, 50 steps, K Langevin)" + (" + style guidance" if style else ""), "value": round(imgs / elapsed, 4),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.storage, "data": "synthetic",
         "config": {"workload": ("BASELINE configs[1]: text-guided h_Edit_p2p_implicit (h-Edit-R + P2P), "
                                 "SD-1.5-shaped random-init UNet (859.5M), 64x64 latent (512^2 image), "
                                 f"{T} DDIM steps, K={K} implicit step(s), CFG (1,5,7.5), xa 0.4, sa 0.35; "

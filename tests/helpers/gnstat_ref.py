@@ -10,15 +10,20 @@ of two exact fp32 numbers = one fp32 addition: the restatement is bit-exact with
 import numpy as np
 
 
-def bf16_bits_to_f32(bits):
-    return (np.asarray(bits, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+def bf16_bits_to_f32(bits, half=False):
+    """storage bits -> fp32: bfloat16, or IEEE half for the HEDIT_STORAGE=f16 build (squares of 11-bit mantissas are exact in
+    fp32 too, so the restatement below stays bit-exact)"""
+    bits = np.asarray(bits, dtype=np.uint16)
+    if half:
+        return bits.view(np.float16).astype(np.float32)
+    return (bits.astype(np.uint32) << 16).view(np.float32)
 
 
-def pair_stats(bits):
+def pair_stats(bits, half=False):
     """bits: uint16 [M][N] (M % 128 == 0, N % 2 == 0) -> float32 [M // 128][N // 2][2]"""
     M, N = bits.shape
     assert M % 128 == 0 and N % 2 == 0
-    v = bf16_bits_to_f32(bits).reshape(M // 128, 4, 32, N // 2, 2)       # [unit][i][r][pair][a, b]: row = r + 32 i
+    v = bf16_bits_to_f32(bits, half).reshape(M // 128, 4, 32, N // 2, 2)  # [unit][i][r][pair][a, b]: row = r + 32 i
     a, b = v[..., 0], v[..., 1]
     s = a + b
     q = b * b + a * a                                                    # (both products exact, one rounding)

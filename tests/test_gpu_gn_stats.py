@@ -29,6 +29,7 @@ from helpers.tiny import hash_normal  # noqa: E402
 from hedit import _lib  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+HALF = _lib.STORAGE == "f16"
 
 
 @pytest.fixture(scope="module")
@@ -89,7 +90,7 @@ def test_conv_epilogue_statistics_are_the_canonical_tree(lib, mode, B, H, Cin, C
     res = G.bf(torch.randn(B * Ho * Ho, Cout, generator=g)) if with_res else None
     out, plain, part = conv_pair(lib, xb, wq, bias, res, B, H, Cin, Cout, mode, splits)
     assert torch.equal(out, plain), "the statistics epilogue changed the output"
-    want = gnstat_ref.pair_stats(bits_of(out))
+    want = gnstat_ref.pair_stats(bits_of(out), HALF)
     got = part.cpu().numpy()
     assert np.isfinite(got).all()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
@@ -122,11 +123,11 @@ def test_groupnorm_from_parts(lib, B, HW, ca, cb, silu):
     x = G.bf(torch.randn(B, HW, C, generator=g) * 2 + 0.5)
     gamma, beta = G.f32(1 + 0.1 * torch.randn(C, generator=g)), G.f32(0.1 * torch.randn(C, generator=g))
     xa = x[:, :, :ca].contiguous()
-    pa = torch.from_numpy(gnstat_ref.pair_stats(bits_of(xa).reshape(B * HW, ca))).to(G.dev())
+    pa = torch.from_numpy(gnstat_ref.pair_stats(bits_of(xa).reshape(B * HW, ca), HALF)).to(G.dev())
     pb = None
     if cb:
         xbh = x[:, :, ca:].contiguous()
-        pb = torch.from_numpy(gnstat_ref.pair_stats(bits_of(xbh).reshape(B * HW, cb))).to(G.dev())
+        pb = torch.from_numpy(gnstat_ref.pair_stats(bits_of(xbh).reshape(B * HW, cb), HALF)).to(G.dev())
     y = torch.empty_like(x)
     ws = torch.empty(B * 512, dtype=torch.uint8, device=G.dev())
     _lib.check(lib.hedit_k_groupnorm_from_parts(_lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), B, HW, C, 32, 1e-6, silu,
