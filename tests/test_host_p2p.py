@@ -121,6 +121,26 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert _lib.lib().hedit_version() >= 1
 
 
+def test_half_storage_library_exports_the_same_abi():
+    """libhedit_hip_f16.so (build.py --f16: the same sources with -DHEDIT_STORE_F16) exports every declared symbol, says what it
+    is, and a process that asks for one storage format is not handed the other library."""
+    import subprocess
+    import sys
+    f16 = os.path.join(os.path.dirname(_lib.LIB_PATH), "libhedit_hip_f16.so")
+    assert os.path.exists(f16), "build it: python h-edit_amd/build.py --f16"
+    lib = ctypes.CDLL(f16)
+    for name in _lib.EXPORTS:
+        assert hasattr(lib, name), f"{name} not exported by the half-storage build"
+    assert lib.hedit_storage_is_f16() == 1 and _lib.lib().hedit_storage_is_f16() == 0
+    code = ("import sys; sys.path.insert(0, %r); from hedit import _lib; import torch; "
+            "assert _lib.LIB_PATH.endswith('libhedit_hip_f16.so') and _lib.lib().hedit_storage_is_f16() == 1 "
+            "and _lib.storage_dtype() == torch.float16; print('ok')") % os.path.join(ROOT, "h-edit_amd")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HEDIT_STORAGE="f16"), capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HEDIT_STORAGE="fp8"), capture_output=True, text=True)
+    assert r.returncode != 0 and "HEDIT_STORAGE" in r.stderr
+
+
 def test_no_fallback_without_library(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libhedit_hip.so")
