@@ -43,15 +43,19 @@ def _stats(path):
     return out
 
 
-@pytest.fixture(scope="module")
-def isa():
+# both builds of the sources: bfloat16 storage (the product) and half storage (-DHEDIT_STORE_F16, csrc/common.h): the rings, their
+# DMA instructions and their counted waits must not depend on the operand type
+@pytest.fixture(scope="module", params=["bf16", "f16"])
+def isa(request):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
     tmp = tempfile.mkdtemp(prefix="hedit_isa_")
+    GNS_KERNELS.clear()
+    extra = ["-DHEDIT_STORE_F16"] if request.param == "f16" else []
 
     def cc(unit):
         out = os.path.join(tmp, unit + ".s")
-        r = subprocess.run([HIPCC] + FLAGS + UNIT_FLAGS.get(unit, []) + ["-o", out, os.path.join(SRC, unit + ".hip")],
+        r = subprocess.run([HIPCC] + FLAGS + extra + UNIT_FLAGS.get(unit, []) + ["-o", out, os.path.join(SRC, unit + ".hip")],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         return unit, _stats(out)
