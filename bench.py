@@ -425,6 +425,14 @@ def main():
         config3["batch_8"] = {"value": blk8["value"], "unit": "images/s", "ms_per_step": blk8["ms_per_step"],
                               "roofline_frac_eps_network": blk8["roofline"]["frac"]}
 
+    # auxiliary (outside the timed region): the half-storage build of the same kernels (libhedit_hip_f16.so, HEDIT_STORAGE=f16) beside
+    # the bfloat16 one on THIS box -- one storage format per process, so both are timed in child processes by tools/unet_time.py
+    # (SD-1.5-shaped random-init UNet, 120 rows = the timed loop's P2P call).  Accuracy of the two formats against the fp32 oracle:
+    # profiles/r05_f16_storage.txt (eps error 1.45e-3 vs 1.16e-2).  Never part of `value`.
+    half = None
+    if not args.no_config2 and style is None and world == 1 and not args.tiny and args.storage == "bf16":
+        half = half_storage_block()
+
     finite = bool(torch.isfinite(edit).all())
     recon_err = float(((recon - w0).norm() / w0.norm()).item())
     prof = unet.prof_collect()
@@ -508,13 +516,35 @@ def main():
         "single_image": None if single_s is None else {"latency_s": round(single_s, 4), "images_per_s": round(1.0 / single_s, 4),
                                                         "note": "configs[1] read literally (1 image, 450 sample-forwards), "
                                                                 "measured after the timed region"},
-        "configs2": config2, "configs3": config3, "configs4": config4, "cse_variant": cse,
+        "configs2": config2, "configs3": config3, "configs4": config4, "half_storage": half, "cse_variant": cse,
         "finite": finite, "recon_rel_err": round(recon_err, 7),
         "setup_s": {"weights_create_broadcast_load": round(t_weights, 1), "ddpm_inversion_untimed": round(t_inversion, 2)},
     }
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def half_storage_block(rows=120, calls=5):
+    """ms per UNet call in both storage formats, each in a child process; any failure becomes a note, never an exception"""
+    import re
+    import subprocess
+    torch.cuda.empty_cache()
+    out = {"workload": f"one SD-1.5-shaped UNet call of {rows} rows (random weights, no controller), tools/unet_time.py in a child process per format",
+           "eps_error_vs_fp32_oracle": {"bf16": 1.16e-2, "f16": 1.45e-3, "source": "profiles/r05_f16_storage.txt (tests/diag/diag_storage_eps_error.py, tests/test_gpu_unet.py)"}}
+    for fmt in ("bf16", "f16"):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "unet_time.py"), str(rows), str(calls)],
+                               env=dict(os.environ, HEDIT_STORAGE=fmt), capture_output=True, text=True, timeout=240)
+            m = re.search(r"storage %s: \d+ rows, ([0-9.]+) ms per UNet call" % fmt, r.stdout)
+            out[fmt] = {"ms_per_unet_call": float(m.group(1))} if m else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:      # noqa: BLE001 -- an auxiliary block must not cost the bench line
+            out[fmt] = {"error": repr(e)[:300]}
+    try:
+        out["f16_over_bf16"] = round(out["f16"]["ms_per_unet_call"] / out["bf16"]["ms_per_unet_call"], 4)
+    except Exception:               # noqa: BLE001
+        pass
+    return out
 
 
 def cpu_baseline(cfg, sd_cpu, T, K, tok, text_layers=12, text_heads=12):
