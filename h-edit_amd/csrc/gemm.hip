@@ -23,6 +23,9 @@
 //     ahead, counted vmcnt -- the queue never drains.
 //   * split-K (grid.y) for the low-resolution, weight-heavy layers: fp32 partial slabs + a
 //     reduce/epilogue kernel.
+//   * optional epilogue extras, each a template parameter so that the plain instantiations stay
+//     byte-identical: GNS = GroupNorm pair statistics of the stored tile (gnstat.h; 128-column tile),
+//     OPB = bfloat16 operands in the half-storage build (the split-bf16 GEMMs of pnet.hip).
 #include <type_traits>
 
 #include "common.h"
