@@ -3,6 +3,7 @@ rank 0, max-over-ranks timing, whole-job unit count)."""
 import os
 import socket
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -73,8 +74,10 @@ def _driver_worker(rank, world, port, q, ckpt_dir):
             return CK.read_component(ckpt_dir)[1]
         got = HD.state_dict_from_rank0(read, shapes, device="cpu", bf16_names={"m.weight", "conv.weight"})
         surplus = [k for k in got if k not in shapes]
-        q.put((rank, {k: (str(got[k].dtype), got[k].float().clone(), got[k].data_ptr() % 16) for k in shapes}, len(reads), (rk, w),
-               list(got), surplus))
+        # numpy payloads: a torch tensor on an mp.Queue travels as a file descriptor the parent must fetch from THIS process
+        # while it is still alive (rebuild_storage_fd) -- under load the worker had exited first.  ndarrays are pickled by value.
+        q.put((rank, {k: (str(got[k].dtype), got[k].float().numpy().copy(), got[k].data_ptr() % 16) for k in shapes}, len(reads),
+               (rk, w), list(got), surplus))
     finally:
         dist.destroy_process_group()
 
@@ -105,9 +108,9 @@ def test_driver_reads_on_rank0_and_broadcasts(tmp_path):
     assert keys0 == keys1 == list(shapes) + ["unused.extra"] and sur0 == sur1 == ["unused.extra"]
     for k in shapes:
         assert a[k][0] == b[k][0] == ("torch.bfloat16" if k in ("m.weight", "conv.weight") else "torch.float32")
-        assert torch.equal(a[k][1], b[k][1])                       # every rank holds the same bits
+        assert np.array_equal(a[k][1], b[k][1])                    # every rank holds the same bits
         want = sd[k].to(torch.bfloat16).float() if k in ("m.weight", "conv.weight") else sd[k]
-        assert torch.equal(a[k][1], want)                          # bf16 only where it was asked for; fp32 tensors exact
+        assert np.array_equal(a[k][1], want.numpy())               # bf16 only where it was asked for; fp32 tensors exact
         assert a[k][2] == 0 and b[k][2] == 0                       # 16-byte aligned views
 
 
