@@ -66,6 +66,7 @@ def parse():
                          "as n extra rows of the P2P pass (same arithmetic either way)")
     ap.add_argument("--force-dist", action="store_true", help="init the RCCL process group even for one rank")
     ap.add_argument("--no-single", action="store_true", help="skip the auxiliary one-image latency measurement")
+    ap.add_argument("--no-half-storage", action="store_true", help="skip the auxiliary half-storage re-run of the loop (a child process)")
     ap.add_argument("--no-config2", action="store_true",
                     help="skip the auxiliary blocks after the timed region: BASELINE configs[2] (32 images, K = 3), configs[3] (face "
                          "swapping, 32 and 8 faces), configs[4] (text + style, 16 images), one pass each")
@@ -425,14 +426,6 @@ def main():
         config3["batch_8"] = {"value": blk8["value"], "unit": "images/s", "ms_per_step": blk8["ms_per_step"],
                               "roofline_frac_eps_network": blk8["roofline"]["frac"]}
 
-    # auxiliary (outside the timed region): the half-storage build of the same kernels (libhedit_hip_f16.so, HEDIT_STORAGE=f16) beside
-    # the bfloat16 one on THIS box -- one storage format per process, so both are timed in child processes by tools/unet_time.py
-    # (SD-1.5-shaped random-init UNet, 120 rows = the timed loop's P2P call).  Accuracy of the two formats against the fp32 oracle:
-    # profiles/r05_f16_storage.txt (eps error 1.45e-3 vs 1.16e-2).  Never part of `value`.
-    half = None
-    if not args.no_config2 and style is None and world == 1 and not args.tiny and args.storage == "bf16":
-        half = half_storage_block()
-
     finite = bool(torch.isfinite(edit).all())
     recon_err = float(((recon - w0).norm() / w0.norm()).item())
     prof = unet.prof_collect()
@@ -477,9 +470,17 @@ def main():
     if os.path.exists(pmc):
         try:
             summ = json.load(open(pmc))
-            if summ.get("config") == want_cfg:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from csrc_hash import csrc_hash
+            roof["csrc_sha256"] = csrc_hash(ROOT)
+            if summ.get("csrc_sha256") != roof["csrc_sha256"]:
+                # counters of an older build say nothing about this one's re-reads
+                roof["traffic_source"] = ("profiles/pmc_summary.json was measured on other kernel sources (its csrc_sha256 "
+                                          f"{str(summ.get('csrc_sha256'))[:12]} != this tree's {roof['csrc_sha256'][:12]}): refused; "
+                                          "re-run tools/pmc_traffic.sh")
+            elif summ.get("config") == want_cfg:
                 roof["traffic"] = summ["classes"].get(dk, {}).get("hbm_bytes_per_launch")
-                roof["traffic_source"] = "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this configuration)"
+                roof["traffic_source"] = "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this configuration and of these kernel sources)"
                 if roof["traffic"] and roof["alg_bytes_per_launch"]:
                     roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["alg_bytes_per_launch"], 3)
             else:
@@ -490,6 +491,10 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu_baseline and not args.tiny and style is None:
         cpu = cpu_baseline(cfg, sd_cpu, T, K, tok)
+    # auxiliary (after the timed region, rank 0, one GPU): the same loop in half storage, see half_storage_block.  Never part of `value`.
+    half = None
+    if not args.no_config2 and not args.no_half_storage and style is None and world == 1 and not args.tiny and args.storage == "bf16":
+        half = half_storage_block(args, imgs / elapsed)
 
     out = {
         "metric": "edited images/sec (512^2, 50 steps, K Langevin)" + (" + style guidance" if style else ""), "value": round(imgs / elapsed, 4),
@@ -525,25 +530,34 @@ def main():
         dist.destroy_process_group()
 
 
-def half_storage_block(rows=120, calls=5):
-    """ms per UNet call in both storage formats, each in a child process; any failure becomes a note, never an exception"""
-    import re
+def half_storage_block(args, bf16_value):
+    """The WHOLE timed loop of this bench (same configuration, one step after one warm-up step) in half storage: bench.py re-invoked in
+    a child process with --storage f16 (a process has one storage format).  The parent drops its torch cache first; its kernels'
+    handles stay (a few GB of the 288).  Any failure becomes a note, never an exception -- an auxiliary block must not cost the line."""
     import subprocess
     torch.cuda.empty_cache()
-    out = {"workload": f"one SD-1.5-shaped UNet call of {rows} rows (random weights, no controller), tools/unet_time.py in a child process per format",
-           "eps_error_vs_fp32_oracle": {"bf16": 1.16e-2, "f16": 1.45e-3, "source": "profiles/r05_f16_storage.txt (tests/diag/diag_storage_eps_error.py, tests/test_gpu_unet.py)"}}
-    for fmt in ("bf16", "f16"):
-        try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "unet_time.py"), str(rows), str(calls)],
-                               env=dict(os.environ, HEDIT_STORAGE=fmt), capture_output=True, text=True, timeout=240)
-            m = re.search(r"storage %s: \d+ rows, ([0-9.]+) ms per UNet call" % fmt, r.stdout)
-            out[fmt] = {"ms_per_unet_call": float(m.group(1))} if m else {"error": (r.stderr or r.stdout)[-300:]}
-        except Exception as e:      # noqa: BLE001 -- an auxiliary block must not cost the bench line
-            out[fmt] = {"error": repr(e)[:300]}
+    out = {"workload": "the timed loop of this line (configs[1], same images per GPU) re-run by a child `bench.py --storage f16 --steps 1 --warmup 1`: "
+                       "libhedit_hip_f16.so, the same kernels on IEEE-half storage (csrc/common.h)",
+           "accuracy": "quoted, not measured in this run: SD-1.5-shape eps error vs the fp32 oracle 1.45e-3 (half) / 1.16e-2 (bfloat16), "
+                       "profiles/r05_f16_storage.txt; 50-step loop vs the oracle trajectory in both formats: profiles/r06_loop_divergence.txt; "
+                       "both asserted by tests/test_gpu_unet.py / tests/test_gpu_loop_trajectory.py through tests/test_gpu_f16_suite.py"}
     try:
-        out["f16_over_bf16"] = round(out["f16"]["ms_per_unet_call"] / out["bf16"]["ms_per_unet_call"], 4)
-    except Exception:               # noqa: BLE001
-        pass
+        cmd = [sys.executable, os.path.abspath(__file__), "--storage", "f16", "--steps", "1", "--warmup", "1", "--images", str(args.images),
+               "--diffusion-steps", str(args.diffusion_steps), "--opt-steps", str(args.opt_steps), "--no-config2", "--no-cpu-baseline",
+               "--no-single", "--no-half-storage"]
+        env = dict(os.environ)
+        env.pop("HEDIT_STORAGE", None)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            out["error"] = (r.stderr or r.stdout)[-400:]
+            return out
+        d = json.loads(line[-1])
+        out.update({"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "finite": d["finite"],
+                    "recon_rel_err": d["recon_rel_err"], "mfma_frac_whole_loop": d["mfma_frac_whole_loop"],
+                    "f16_over_bf16_images_per_s": round(d["value"] / bf16_value, 4) if bf16_value else None})
+    except Exception as e:      # noqa: BLE001
+        out["error"] = repr(e)[:400]
     return out
 
 

@@ -296,7 +296,7 @@ int hedit_k_lin_chain(const void* a, int64_t lda, const void* r1, int64_t ldr1, 
 int hedit_storage_is_f16(void) { return HEDIT_F16; }
 
 int hedit_test_set_flags(int flags) try {
-  ARG_CHECK(flags >= 0 && flags <= 7, "hedit_test_set_flags: bit 0 drained ring waits, bit 1 exact self-attention pass, bit 2 pixel-UNet GroupNorm statistics path flipped");
+  ARG_CHECK(flags >= 0 && flags <= 15, "hedit_test_set_flags: bit 0 drained ring waits, bit 1 exact self-attention pass, bit 2 pixel-UNet GroupNorm statistics path flipped, bit 3 no persistent linear kernel");
   g_test_flags.store(flags, std::memory_order_relaxed);
   return HEDIT_OK;
 } catch (...) { return hedit_abi_catch(); }

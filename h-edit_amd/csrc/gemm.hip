@@ -1183,6 +1183,7 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
     const double w_bytes = (double)p.N * p.K;
     p.n_fastest = a_bytes >= w_bytes ? 1 : 0;
   }
+  if (pgemm_supported(p, splits, bn)) return pgemm_launch(p, bn, st);      // persistent ring across tiles (pgemm.hip): same bits
   int rc;
 #define DISPATCH(BNV)                                                     \
   switch (p.mode) {                                                       \

@@ -48,6 +48,9 @@ int gemm_canonical_chunk(int M_nom, int N_nom, int K);     // batch-independent 
 int gemm_plan_splits(int M, int N, int K, int chunk_kt);   // slabs this launch uses to execute it (1 = in registers)
 size_t gemm_partial_bytes(int M, int N, int splits);
 int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st);
+// pgemm.hip: the persistent form of the linear (mode 0) launches -- same bits as igemm_kernel, chosen by shape inside gemm_launch
+bool pgemm_supported(const GemmParams& p, int splits, int bn);
+int pgemm_launch(const GemmParams& p, int bn, hipStream_t st);
 
 // ---------------------------------------------------------------- ffn.hip
 // The token-local tail of a transformer block in one kernel (C = ffn_fused_channels() only):

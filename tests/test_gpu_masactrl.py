@@ -37,7 +37,7 @@ def test_self_attention_reads_kv_of_another_row(heads, d, N):
     kb = k.to(_lib.storage_dtype()).float().reshape(B, N, heads, d).transpose(1, 2)[src.cpu().long()]
     vb = v.to(_lib.storage_dtype()).float().reshape(B, N, heads, d).transpose(1, 2)[src.cpu().long()]
     want = (torch.softmax(qb @ kb.transpose(-1, -2) * d ** -0.5, -1) @ vb).transpose(1, 2).reshape(B, N, Cc)
-    assert G.rel_err(out.float(), want) < 1.2e-2
+    G.within(G.rel_err(out.float(), want), 1.2e-2)
 
 
 @pytest.fixture(scope="module")
@@ -72,8 +72,8 @@ def test_masactrl_loop_matches_oracle(setup, skip, K, step, layer):
     G.sync()
     assert e_h.shape == (1, 4, 32, 32) and torch.isfinite(e_h).all()
     tol_edit, tol_recon = (8e-2, 1e-2) if after <= 4 else (1.8e-1, 5e-2)
-    assert G.rel_err(r_h, r_o) < tol_recon
-    assert G.rel_err(e_h, e_o) < tol_edit
+    G.within(G.rel_err(r_h, r_o), tol_recon)
+    G.within(G.rel_err(e_h, e_o), tol_edit)
     assert ed_h.cur_step == ed_o.cur_step == after * K
 
 

@@ -83,9 +83,19 @@ def _stress(run, launches, hog):
 # (name, mode, M-or-(B, Hin, Win), Cin / K, N, chunks)   chunks: 0 = plain chain, n = canonical-style fold of n chunks in
 # registers (hedit_k_gemm splits = -n), -n = n split-K slabs; the first twelve are large enough for the 256-row tile (>= 200 tiles, K >= 1024)
 GEMM_CASES = [
-    ("ring3 160 plain  FF2 L1", 0, 122880, 2560, 640, 0),
+    # >= 2 tiles per CU, no fold: the persistent kernel (csrc/pgemm.hip) -- its ring runs across tiles with the epilogue's loads
+    # and stores in the vmcnt queue; both column tiles, with / without the residual rows, a ragged row tile, K = 3 tiles (the
+    # shortest ring: every DMA of a tile belongs to the next one)
+    ("persist 160 res    FF2 L1", 0, 122880, 2560, 640, 0),
+    ("persist 160 nores  qk L1", 0, 122880, 640, 1280, 0, False),
+    ("persist 160 res    out-proj L1 ragged", 0, 122880 + 72, 640, 640, 0),
+    ("persist 128 res    ragged", 0, 2 * 65536 + 100, 1024, 1024, 0),
+    ("persist 128 nores  K = 192", 0, 4 * 65536, 192, 384, 0, False),
+    ("persist 160 res    K = 192, N = 200", 0, 4 * 65536 + 8, 192, 200, 0),
+    # 200 <= tiles < 2 per CU: the one-shot three-stage ring of the 256-row tile
+    ("ring3 160 plain  FF2", 0, 20480, 2560, 640, 0),
     ("ring3 160 fold   FF2 L1", 0, 122880, 2560, 640, 4),
-    ("ring3 128 plain", 0, 65536 + 100, 1024, 1024, 0),               # ragged last row tile
+    ("ring3 128 plain", 0, 8192 + 100, 1024, 1024, 0),               # ragged last row tile
     ("ring3 128 fold", 0, 65536, 2048, 1024, 2),
     ("ring3 160 plain  stride-2 conv", 2, (40, 64, 64), 320, 320, 0),
     ("rowshare 160 plain  64x64 320->320", 1, (60, 64, 64), 320, 320, 0),
@@ -107,7 +117,7 @@ GEMM_CASES = [
 
 
 class Gemm:
-    def __init__(self, mode, shape, cin, N, chunks, seed=0):
+    def __init__(self, mode, shape, cin, N, chunks, res=True, seed=0):
         self.lib = _lib.lib()
         g = torch.Generator().manual_seed(seed)
         self.mode, self.N, self.cin = mode, N, cin
@@ -123,14 +133,14 @@ class Gemm:
             self.conv = (Hin, Win, cin, Ho, Wo)
         self.W = _bf(torch.randn(N, self.K, generator=g) / math.sqrt(self.K))
         self.bias = torch.randn(N, generator=g).to(DEV)
-        self.R = _bf(torch.randn(self.M, N, generator=g))
+        self.R = _bf(torch.randn(self.M, N, generator=g)) if res else None
         self.splits = -chunks               # hedit_k_gemm: < 0 folded in registers, > 0 split-K slabs + reduce
         self.ws = torch.empty(max(self.lib.hedit_k_gemm_ws_bytes(self.M, N, self.K, abs(chunks)), 16), dtype=torch.uint8, device=DEV)
 
     def run(self, out=None):
         o = out[0] if out else torch.empty(self.M, self.N, dtype=_lib.storage_dtype(), device=DEV)
         p = _lib.ptr
-        _lib.check(self.lib.hedit_k_gemm(p(self.A), p(self.W), p(self.bias), p(self.R), p(o), self.M, self.N, self.K,
+        _lib.check(self.lib.hedit_k_gemm(p(self.A), p(self.W), p(self.bias), p(self.R) if self.R is not None else None, p(o), self.M, self.N, self.K,
                                          self.cin if self.mode else self.K, self.N, self.N, self.mode, *self.conv, self.splits,
                                          p(self.ws), _lib.cur_stream()))
         return (o,)
@@ -138,8 +148,8 @@ class Gemm:
 
 @pytest.mark.parametrize("case", GEMM_CASES, ids=[c[0].replace(" ", "_") for c in GEMM_CASES])
 def test_igemm_counted_waits_reproduce_the_drained_schedule(case):
-    name, mode, shape, cin, N, chunks = case
-    gm = Gemm(mode, shape, cin, N, chunks)
+    name, mode, shape, cin, N, chunks = case[:6]
+    gm = Gemm(mode, shape, cin, N, chunks, *case[6:])
     # the case must reach a kernel WITH counted waits, i.e. differ in code from its drained twin: checked through time
     n = max(20, int(LAUNCHES * (0.5 if gm.M * N * gm.K > 2e14 else 1.0)))
     bad, elems = _stress(gm.run, n, 2)

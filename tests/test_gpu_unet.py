@@ -38,7 +38,7 @@ def test_tiny_unet_forward(tiny, B, t):
     got = hip.unet(G.f32(x), t, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"use_controller": False}).sample
     G.sync()
     err = G.rel_err(got, want)
-    assert err < TOL_TINY, err
+    G.within(err, TOL_TINY)
     # determinism: a second evaluation is bit-identical
     got2 = hip.unet(G.f32(x), t, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"use_controller": False}).sample
     assert torch.equal(got, got2)
@@ -71,20 +71,20 @@ def test_tiny_unet_p2p_pass(tiny, pi, cur_step):
             want = om.unet(x, torch.tensor(401), encoder_hidden_states=ctx, cross_attention_kwargs={"save_attn": True}).sample
         got = hip.unet(G.f32(x), 401, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"save_attn": True}).sample
         G.sync()
-        assert G.rel_err(got, want) < TOL_TINY
+        G.within(G.rel_err(got, want), TOL_TINY)
         assert hc.cur_step == oc.cur_step == cur_step + 1 and hc.cur_att_layer == 0
         for key in ("down_cross", "mid_cross", "up_cross"):
             assert len(hc.attention_store[key]) == len(oc.attention_store[key])
             for a, b in zip(hc.attention_store[key], oc.attention_store[key]):
                 assert a.shape == b.shape
-                assert G.rel_err(a, b) < 2e-2
+                G.within(G.rel_err(a, b), 2e-2)
         # a save_attn=False pass applies the edit but leaves counters and store untouched
         before = [t.clone() for t in hc.attention_store["down_cross"]]
         with torch.no_grad():
             want2 = om.unet(x, torch.tensor(401), encoder_hidden_states=ctx, cross_attention_kwargs={"save_attn": False}).sample
         got2 = hip.unet(G.f32(x), 401, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"save_attn": False}).sample
         G.sync()
-        assert G.rel_err(got2, want2) < TOL_TINY
+        G.within(G.rel_err(got2, want2), TOL_TINY)
         assert hc.cur_step == cur_step + 1
         for a, b in zip(before, hc.attention_store["down_cross"]):
             assert torch.equal(a, b)
@@ -118,7 +118,7 @@ def test_sd15_unet_forward_full_size():
     got = hip.unet(G.f32(x), 481, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"use_controller": False}).sample
     G.sync()
     err = G.rel_err(got, want)
-    assert err < TOL_SD, err
+    G.within(err, TOL_SD, 3e-3, 'SD-1.5 eps vs the fp32 oracle')      # half storage: north_star's fp16 tolerance (measured 1.45e-3)
     assert len(hip.unet.attn_processors) == 32
     assert sum(int(torch.tensor(s).prod()) for s in hip.unet.param_shapes.values()) == 859520964
     # Where the error comes from: the same fp32 oracle with a STORAGE format emulated -- weights, the output of every leaf module
@@ -153,8 +153,9 @@ def test_sd15_unet_forward_full_size():
     e_fp16 = emulate(torch.float16, torch.float16)
     print(f"sd15 eps error vs fp32 oracle: HIP {err:.3e} | oracle with bf16 storage {e_bf16:.3e}, bf16 storage + fp32 residual stream "
           f"{e_bf16_res32:.3e}, fp16 storage {e_fp16:.3e}")
-    # the kernels add nothing of their own to the price of BASELINE's bf16 tensors
-    assert err < 1.5 * e_bf16, (err, e_bf16)
+    # the kernels add nothing of their own to the price of the storage format's tensors (bfloat16: BASELINE configs[1]'s; half: the
+    # same kernels against the oracle with fp16 tensors emulated)
+    assert err < 1.5 * (e_fp16 if G.F16 else e_bf16), (err, e_bf16, e_fp16)
 
 
 def test_tiny_unet_rectangular_latent(tiny):
@@ -169,7 +170,7 @@ def test_tiny_unet_rectangular_latent(tiny):
     got = hip.unet(G.f32(x), 301, encoder_hidden_states=G.f32(ctx), cross_attention_kwargs={"use_controller": False}).sample
     G.sync()
     assert got.shape == want.shape
-    assert G.rel_err(got, want) < TOL_TINY
+    G.within(G.rel_err(got, want), TOL_TINY)
 
 
 def test_rows_are_independent_of_batch_position(tiny):

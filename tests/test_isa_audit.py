@@ -26,20 +26,32 @@ UNIT_FLAGS = {"attn": ["-fno-honor-nans"], "ffn": ["-fno-honor-nans"]}          
 
 def _stats(path):
     cur, out = None, {}
+    pending = None           # vmcnt immediate of the last s_waitcnt, until the next instruction shows whether a barrier follows
     for line in open(path):
         m = re.match(r"^(_Z\w+):", line)
         if m:
             cur = m.group(1)
-            out[cur] = {"dma": 0, "waits": {}}
+            out[cur] = {"dma": 0, "waits": {}, "loads": 0, "stores": 0, "ring_waits": []}
+            pending = None
             continue
         if cur is None:
             continue
+        ins = line.strip()
+        if ins and not ins.startswith((";", ".", "s_waitcnt", "s_nop")) and pending is not None:
+            if ins.startswith("s_barrier"):
+                out[cur]["ring_waits"].append(pending)
+            pending = None
         if re.search(r"buffer_load_dwordx4.* lds", line) or "global_load_lds" in line:
             out[cur]["dma"] += 1
+        elif re.search(r"\b(buffer|global)_load_", line):
+            out[cur]["loads"] += 1
+        elif re.search(r"\b(buffer|global)_store_", line):
+            out[cur]["stores"] += 1
         m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", line)
         if m:
             n = int(m.group(1))
             out[cur]["waits"][n] = out[cur]["waits"].get(n, 0) + 1
+            pending = n
     return out
 
 
@@ -60,7 +72,7 @@ def isa(request):
         assert r.returncode == 0, r.stderr[-2000:]
         return unit, _stats(out)
     with ThreadPoolExecutor(4) as ex:
-        return dict(ex.map(cc, ["gemm", "ffn", "attn", "linchain"]))
+        return dict(ex.map(cc, ["gemm", "pgemm", "ffn", "attn", "linchain"]))
 
 
 def _igemm(isa):
@@ -174,3 +186,27 @@ def test_lin_chain_twins(isa):
         assert st["waits"].get(12, 0) >= 32, st      # the ring's steady-state window
         pairs += 1
     assert pairs >= 3
+
+
+def test_pgemm_ring_counts_every_vector_memory_instruction(isa):
+    """csrc/pgemm.hip keeps counted waits with the epilogue's loads and stores in the queue: per tile a wave must issue EXACTLY
+    NI bias loads + RL residual loads, ST stores and (first K-tile, middle K-tiles, deferred) NDMA LDS-DMAs each, on every path --
+    masked lanes are out-of-range buffer offsets, never cleared exec bits -- and the waits in front of the ring barriers must be
+    vmcnt(NDMA) (prologue, middle, last K-tile) and vmcnt(ST + NDMA) (first K-tile of a tile), all vmcnt(0) in the drained twin."""
+    ks = {}
+    for name, st in isa["pgemm"].items():
+        m = re.search(r"pgemm_kernelILi(\d+)ELb([01])ELb([01])E", name)
+        if m:
+            ks[tuple(int(v) for v in m.groups())] = st          # (BN, RES, DRAIN)
+    assert len(ks) == 8
+    for (bn, res, drain), st in ks.items():
+        ni = bn // 32
+        ndma = 4 + (bn // 8 + 7) // 8
+        nq = (16 * (bn // 16) + 63) // 64
+        stn = 4 * nq
+        assert st["dma"] == 6 * ndma, ((bn, res, drain), st)             # prologue 3 K-tiles | first | middle | deferred
+        assert st["loads"] == ni + (stn if res else 0), ((bn, res, drain), st)
+        assert st["stores"] == stn, ((bn, res, drain), st)
+        want = [0, 0, 0, 0] if drain else [ndma, stn + ndma, ndma, ndma]
+        assert st["ring_waits"] == want, ((bn, res, drain), st["ring_waits"], want)
+        assert ks[(bn, res, 1 - drain)]["dma"] == st["dma"]

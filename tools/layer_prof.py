@@ -14,6 +14,8 @@ from hedit.unet import UNet2DConditionModel
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = "cuda:0"
+if os.environ.get("HEDIT_TEST_FLAGS"):        # e.g. 8 = without the persistent linear kernel (A/B of csrc/pgemm.hip)
+    _lib.check(_lib.lib().hedit_test_set_flags(int(os.environ["HEDIT_TEST_FLAGS"])))
 unet = UNet2DConditionModel(device=dev); unet.init_random(0)
 x = torch.randn(B, 4, 64, 64, device=dev); ctx = torch.randn(B, 77, 768, device=dev)
 for _ in range(2):

@@ -8,11 +8,17 @@ is doubled; WRITE_SIZE matched the algorithmic output size of the FF1 GEMM to <1
 calibration launch (tools/pmc_probe.py) and is used as is."""
 import collections
 import json
+import os
 import sqlite3
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_hash import csrc_hash  # noqa: E402
+
 
 def klass(name):
+    if "pgemm_kernel" in name:          # the persistent linear kernel (csrc/pgemm.hip)
+        return "linear_gemm"
     if "igemm_kernel" in name:
         args = [a.strip() for a in name.split("igemm_kernel<")[1].split(">")[0].split(",")]   # BM, BN, MODE
         return "linear_gemm" if args[2] == "0" else "conv3x3_gemm"
@@ -66,7 +72,7 @@ def main():
         n = max(nf, nw, 1)
         out[k] = {"launches": n, "fetch_kib_raw_per_launch": f / max(nf, 1), "write_kib_per_launch": w / max(nw, 1),
                   "hbm_bytes_per_launch": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0}
-    json.dump({"config": cfg, "counters": "rocprofv3 --pmc FETCH_SIZE (x2: gfx950 counts 128-B requests as 64 B) + WRITE_SIZE, KiB",
+    json.dump({"config": cfg, "csrc_sha256": csrc_hash(), "counters": "rocprofv3 --pmc FETCH_SIZE (x2: gfx950 counts 128-B requests as 64 B) + WRITE_SIZE, KiB",
                "classes": out}, sys.stdout, indent=1)
 
 
