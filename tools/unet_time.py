@@ -15,6 +15,9 @@ def main():
     rows = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     calls = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     dev = torch.device("cuda:0")
+    flags = int(os.environ.get("HEDIT_TEST_FLAGS", "0"))        # A/B runs: 8 = one-shot igemm instead of the persistent kernels
+    if flags:
+        _lib.check(_lib.lib().hedit_test_set_flags(flags))
     unet = UNet2DConditionModel(dict(SD15_CONFIG), device="cuda:0")
     g = torch.Generator().manual_seed(3)
     sd = {k: torch.randn(*s, generator=g) * (0.02 if len(s) > 1 else 0.1) + (1.0 if k.endswith("norm.weight") or "norm" in k and k.endswith("weight") else 0.0)
@@ -32,7 +35,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / calls
-    print(f"storage {_lib.STORAGE}: {rows} rows, {ms:.2f} ms per UNet call = {rows * 803.2 / ms:.0f} TFLOP/s algorithmic, finite "
+    print(f"storage {_lib.STORAGE}{' flags ' + str(flags) if flags else ''}: {rows} rows, {ms:.2f} ms per UNet call = {rows * 803.2 / ms:.0f} TFLOP/s algorithmic, finite "
           f"{bool(torch.isfinite(out).all())}", flush=True)
 
 
