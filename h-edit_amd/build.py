@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "hedit", "libhedit_hip.so")
-UNITS = ["gemm.hip", "pgemm.hip", "ffn.hip", "linchain.hip", "norm.hip", "attn.hip", "step.hip", "grad.hip", "pnet.hip", "unet.hip", "vae.hip", "ddpm.hip", "irse.hip", "lpips.hip", "vit.hip", "c_api.hip"]
+UNITS = ["gemm.hip", "pgemm.hip", "pconv.hip", "ffn.hip", "linchain.hip", "norm.hip", "attn.hip", "step.hip", "grad.hip", "pnet.hip", "unet.hip", "vae.hip", "ddpm.hip", "irse.hip", "lpips.hip", "vit.hip", "c_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 # per-unit extras.  attn.hip: the row-max chains run on raw MFMA results; without the no-NaN promise
 # every fmaxf operand is first canonicalised (v_max x,x), tripling the instruction count of the

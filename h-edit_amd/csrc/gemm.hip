@@ -1184,6 +1184,7 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st) {
     p.n_fastest = a_bytes >= w_bytes ? 1 : 0;
   }
   if (pgemm_supported(p, splits, bn)) return pgemm_launch(p, bn, st);      // persistent ring across tiles (pgemm.hip): same bits
+  if (pconv_supported(p, splits, bn)) return pconv_launch(p, bn, st);      // the same for the row-sharing 3x3 loop (pconv.hip)
   int rc;
 #define DISPATCH(BNV)                                                     \
   switch (p.mode) {                                                       \

@@ -51,6 +51,9 @@ int gemm_launch(GemmParams p, int splits, float* partial_ws, hipStream_t st);
 // pgemm.hip: the persistent form of the linear (mode 0) launches -- same bits as igemm_kernel, chosen by shape inside gemm_launch
 bool pgemm_supported(const GemmParams& p, int splits, int bn);
 int pgemm_launch(const GemmParams& p, int bn, hipStream_t st);
+// pconv.hip: the persistent form of the row-sharing 3x3 launches (kernel modes 4 / 5) -- same bits, chosen by shape inside gemm_launch
+bool pconv_supported(const GemmParams& p, int splits, int bn);
+int pconv_launch(const GemmParams& p, int bn, hipStream_t st);
 
 // ---------------------------------------------------------------- ffn.hip
 // The token-local tail of a transformer block in one kernel (C = ffn_fused_channels() only):

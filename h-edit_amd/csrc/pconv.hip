@@ -1,0 +1,551 @@
+// Persistent form of igemm_kernel's row-sharing 3x3 loop (kernel modes 4 / 5: stride-1 3x3 convolution, plain or on the 2x nearest-
+// upsampled image, 256-row tile, image width | 256): the SAME tile, wave layout, K-tile order, MFMA chain, chunk fold and epilogue
+// arithmetic -- hence the same bits -- but a block walks over its tiles and neither the weight ring nor the two activation tiles
+// drain between them (VERDICT r5 "do this" 2, second half; csrc/pgemm.hip is the linear form).
+//
+// What a tile of the one-shot launch pays and this one does not: a prologue that waits one HBM round trip with nothing behind it, a
+// K loop whose look-ahead starts from empty, a block barrier + the staging of the whole tile through LDS + its stores with no operand
+// request in flight (one 8-wave block owns the CU: nothing else runs under it).  Here
+//   * one block per CU walks the tiles  X0 + c, X0 + c + nbx, ...  of its XCD's chunk of the XCD-aware tile order;
+//   * the FLAT sequence of tap rows (three K-tiles each: the three taps of one kernel row on one 64-channel slab) of all of the block's
+//     tiles runs through the same two activation tiles (parity of the flat tap-row index) and the same ring of three weight stages
+//     (stage = tap column): the DMA slot of K-tile (g, col) -- weights of K-tile (g + 1, col); for col 0 the second half of activation
+//     tile g + 1, for col 2 the first half of activation tile g + 2 -- simply takes its sources from the NEXT tile when g + 1 / g + 2
+//     run past the tile's last tap row (source state of the next tile is computed a tile ahead);
+//   * the epilogue needs no block barrier and no LDS of its own: after the mid-tile barrier of a tile's last K-tile the activation tile
+//     of its last tap row is dead everywhere, and each wave stages its 64 x BN/2 sub-tile, 16 rows at a time, through ITS OWN 4 KB of
+//     that tile (the target of its own four DMA groups: nobody else writes there, nobody reads there before the next hand-over),
+//     reads it back as 16-byte row pieces, adds the residual and stores.  The one DMA that would overwrite the scratch -- the first
+//     half of the next tile's activation tile 1 -- is deferred behind the epilogue;
+//   * bias, residual and output go through buffer descriptors (a masked lane has an out-of-range offset, not a cleared exec bit), so
+//     every wave issues the same number of vector-memory instructions per tile and the ring keeps COUNTED vmcnt waits with the
+//     epilogue's loads and stores in the queue.  Issue order of a wave around a tile boundary (W = W_CH weight DMAs, 2 = one half of an
+//     activation tile, primes = next tile):
+//         slot (G-2, 2): act(0', half 0) 2 | w(G-1, 2) W          slot (G-1, 0): act(0', half 1) 2 | w(0', 0) W
+//         slot (G-1, 1): w(0', 1) W                               slot (G-1, 2): w(0', 2) W | bias NI | residual RL | stores ST | act(1', half 0) 2
+//         slot (0', 0):  act(1', half 1) 2 | w(1', 0) W           slot (0', 1):  w(1', 1) W          ...
+//     mid-tile wait of K-tile j = "everything K-tile j + 1 reads has landed" = all but the previous slot:
+//         col 2: vmcnt(W)    col 0 / 1: vmcnt(W + 2)    -- as in the one-shot loop, also for the last K-tile of a tile;
+//         first K-tile of a later tile (0', 0): what it needs (w(0', 1)) is OLDER than the bias loads the epilogue has consumed, so only the
+//         epilogue's stores and the deferred DMA may be outstanding: vmcnt(ST + 2); (0', 1) likewise needs w(0', 2): vmcnt(ST + 2 + W + 2).
+//         The stores are thereby never waited for before K-tile (0', 2), two K-tiles after they were issued.
+//     DRAIN twin (tests/test_gpu_ring_hazard.py): every one of these is vmcnt(0).
+// Not here (they keep igemm_kernel): split-K slabs / raw fp32 output, GroupNorm pair statistics, bfloat16-by-contract operands, rows
+// that are not 16-byte aligned, launches with fewer than two tiles per CU.
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+constexpr int BK = 64;
+constexpr int BM = 256;
+constexpr int NT = 512;
+constexpr unsigned OOB = 0x80000000u;
+
+template <int BN>
+struct CS {
+  static constexpr int AP = BM * BK * 2;                    // one activation tile
+  static constexpr int W_BYTES = BN * BK * 2;
+  static constexpr int W0 = 2 * AP;
+  static constexpr int ZERO = W0 + 3 * W_BYTES;             // zero row of activation tile 0 (tile 1: + AP), as Smem<256, BN>::RS_ZERO
+  static constexpr int TOTAL = ZERO + AP + 128;
+  static constexpr int PCH = BN / 16;                       // 16-byte pieces per row of a wave's sub-tile
+  static constexpr int NQ = (16 * PCH + 63) / 64;           // piece instructions per 16-row pass
+  static constexpr int SCR_STRIDE = BN + 16;                // bytes: BN/2 elements + 16 (bank spread)
+  static_assert(16 * SCR_STRIDE <= 4096 && (NQ * 64 / PCH + 1) * SCR_STRIDE <= 4096, "scratch stays inside the wave's own DMA target");
+  static_assert(TOTAL <= 160 * 1024, "must fit the LDS");
+};
+
+template <int BN, bool CHUNK, bool UP, bool RES, bool DRAIN>
+__global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using S = CS<BN>;
+  constexpr int NI = BN / 32, MI = 4;
+  constexpr int A_CH = 4;
+  constexpr int W_GROUPS = BN / 8;
+  constexpr int W_CH = (W_GROUPS + 7) / 8;
+  constexpr int NQ = S::NQ, PCH = S::PCH;
+  constexpr int ST = 4 * NQ;                                // stores per wave and tile
+  constexpr int AP = S::AP;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // ---- the block's tiles (pgemm.hip's walk)
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int nb = tiles_m * tiles_n;
+  const int GR = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, cidx = bid >> 3;
+  const int q8 = nb >> 3, r8 = nb & 7;
+  const int X0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int XN = q8 + (xcd < r8 ? 1 : 0);
+  const int nbx = (GR - xcd + 7) >> 3;                      // blocks of this launch on my XCD
+  if (cidx >= XN) return;
+  const int T = (XN - cidx + nbx - 1) / nbx;
+  const int kt_total = p.K / BK;
+  const int G = kt_total / 3;                               // tap rows per tile: 3 per 64-channel slab (>= 3)
+
+  const int Wimg = UP ? p.Wout : p.Win;                     // a power of two (divides 256)
+  const int wshift = 31 - __builtin_clz((unsigned)Wimg);
+  const unsigned ldc2 = (unsigned)p.ldc * 2u, ldr2 = (unsigned)p.ldr * 2u;
+  const unsigned K2 = (unsigned)p.K * 2u;
+  const unsigned dchunk = (unsigned)(((lane & 7) ^ (lane >> 3)) * 16);
+  const unsigned grp_step = (unsigned)(8 * p.Cin * 2);
+  const int row_bytes = p.Win * p.Cin * 2;
+
+  // ---- DMA sources: lane part + tile part.  A tile starts at a pixel index m0 that is a multiple of 256, hence of the image width:
+  //   weights      row n0 + r  ->  n0 * K bytes (scalar offset of the request)  +  r * K bytes (lane offset, the same for every tile);
+  //   activations  plain: pixel m0 + l -> m0 * Cin (scalar) + l * Cin (lane);  upsampled: output pixel (R, ox) of the batch-wide row
+  //                index R = m0 / W + l / W reads input row R >> 1 (Hout = 2 Hin, so the image index drops out), column ox >> 1, and
+  //                with m0 / W even that is (m0 / 4) * Cin (scalar) + ((lr >> 1) * Win + (ox >> 1)) * Cin (lane), parity = lr & 1.
+  // The tap row's delta (-1, 0, +1 input rows) goes into the lane offset; so that this never wraps for a tile that does not start at
+  // the top of an image, the descriptor's base is one input row BELOW the tensor and the lane offset carries (delta + 1) rows.  What
+  // depends on the tile is then one mask per lane (ok: bit 3 i + dy = tap row dy of group i's pixel is inside the image and the pixel
+  // exists; a masked lane requests an out-of-range offset = zero fill) and two scalars.
+  unsigned al[UP ? A_CH : 1];
+  unsigned apar = 0;
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int l = (wave * A_CH + i) * 8 + (lane >> 3);
+    if (UP) {
+      const int lr = l >> wshift, ox = l & (Wimg - 1);
+      al[i] = (unsigned)((((lr >> 1) * p.Win + (ox >> 1)) * p.Cin) * 2) + dchunk;
+      apar |= (unsigned)(lr & 1) << i;
+    } else if (i == 0) {
+      al[0] = (unsigned)l * (unsigned)(p.Cin * 2) + dchunk;
+    }
+  }
+  unsigned wl[W_CH];
+#pragma unroll
+  for (int i = 0; i < W_CH; ++i) {
+    int wg = wave * W_CH + i;
+    if (wg > W_GROUPS - 1) wg = W_GROUPS - 1;
+    wl[i] = (unsigned)(wg * 8 + (lane >> 3)) * K2 + dchunk;
+  }
+  auto tile_mn = [&](int k, int& m0, int& n0) __attribute__((always_inline)) {
+    const int v = X0 + cidx + k * nbx;
+    const int tm = p.n_fastest ? v / tiles_n : v % tiles_m;
+    const int tn = p.n_fastest ? v % tiles_n : v / tiles_m;
+    m0 = tm * BM;
+    n0 = tn * BN;
+  };
+  // tile part of tile k: the mask (VGPR) and the two scalar byte offsets.  Past the block's last tile: everything masked (zero-fill
+  // requests keep the vmcnt pattern), the weight requests re-read n-tile 0 (valid memory, never used).
+  auto tile_src = [&](int k, unsigned& okm, int& am, int& wn) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_mn(k, m0, n0);
+    const bool live = k < T;
+    okm = 0;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int m = m0 + (wave * A_CH + i) * 8 + (lane >> 3);
+      const unsigned rowi = (unsigned)m >> wshift;          // image row index over the batch: b * Hout + oy
+      const int b = (int)(rowi / (unsigned)p.Hout);
+      const int oy = (int)rowi - b * p.Hout;
+      const bool ok = live && m < p.M;
+      unsigned mk = ok ? 2u : 0u;                           // tap row 1: the pixel's own row
+      if (ok && oy > 0) mk |= 1u;
+      if (ok && oy < p.Hout - 1) mk |= 4u;
+      okm |= mk << (3 * i);
+    }
+    am = live ? (UP ? (m0 >> 2) : m0) * p.Cin * 2 : 0;
+    wn = live ? n0 * p.K * 2 : 0;
+  };
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(p.A) - row_bytes)), (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)((unsigned)p.M * ldc2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), (short)0, p.bias ? p.N * 4 : 0, 0x00020000);   // no bias: every read is out of range = 0
+  const __amdgpu_buffer_rsrc_t rs_r =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.residual), (short)0, RES ? (int)((unsigned)p.M * ldr2) : 0, 0x00020000);
+#endif
+
+  unsigned ok_c, ok_n;       // masks of the current / next tile
+  int am_c, am_n, wn_c, wn_n;
+  // one half (DMA groups 2 part, 2 part + 1 of this wave) of the activation tile of tap row gt, counted from the CURRENT tile's first:
+  // gt >= G is tap row gt - G of the next tile.  (Selects, not a branch: the offsets are woven between the MFMAs of the K-tile's first
+  // half, which a second basic block would prevent.)
+  struct ASrc { unsigned v[2]; int s; };
+  auto a_prep = [&](int gt, int part, ASrc& d) __attribute__((always_inline)) {
+    const bool nxt = gt >= G;
+    const int g = nxt ? gt - G : gt;
+    const int slab = g / 3, dyi = g - slab * 3;
+    const unsigned okm = nxt ? ok_n : ok_c;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = part * 2 + q;
+      const bool ok = (okm >> (3 * i + dyi)) & 1u;
+      if (UP) {
+        const int fy1 = ((int)((apar >> i) & 1u) + dyi + 1) >> 1;               // input row delta + 1, in {0, 1, 2}
+        d.v[q] = ok ? al[UP ? i : 0] + (unsigned)(fy1 * row_bytes) : OOB;
+      } else {
+        d.v[q] = ok ? al[0] + (unsigned)i * grp_step + (unsigned)(dyi * row_bytes) : OOB;
+      }
+    }
+    d.s = slab * BK * 2 + (nxt ? am_n : am_c);
+  };
+  auto a_fire = [&](int buf, int part, const ASrc& d) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    char* sa = smem + buf * AP;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(sa + (wave * A_CH + part * 2 + q) * 1024), 16, d.v[q], d.s, 0, 0);
+#else
+    (void)buf; (void)part; (void)d;
+#endif
+  };
+  // weights of K-tile kt of a tile into ring stage `stage`: scalar offset = the K-tile's column offset + the tile's row offset
+  auto w_soff = [&](int kt) __attribute__((always_inline)) {
+    const int slab = kt / 9, tap = kt - slab * 9;
+    return (tap * p.Cin + slab * BK) * 2;
+  };
+  auto w_fire = [&](int stage, int soff) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    char* sw = smem + S::W0 + stage * S::W_BYTES;
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i) {
+      int wg = wave * W_CH + i;
+      if (wg > W_GROUPS - 1) wg = W_GROUPS - 1;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(sw + wg * 1024), 16, wl[i], soff, 0, 0);
+    }
+#else
+    (void)stage; (void)soff;
+#endif
+  };
+
+  // ---- fragment reads (igemm_kernel's addressing; the side taps read LDS row -1 / +1 of the staged tile, or the zero row at the image
+  // edge -- with Wimg | 256 and m0 % 256 == 0 these offsets do not depend on the tile)
+  const int rd_x = ((fq ^ (fr & 7)) << 4);
+  const int a_rd = (wm * 64 + fr) * 128 + rd_x;
+  const int w_rd = (wn * (BN / 2) + fr) * 128 + rd_x;
+  int a_rdl[MI], a_rdr[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = wm * 64 + i * 16 + fr;
+    const int x = row & (Wimg - 1);
+    const int rl = row - 1, rr = row + 1;
+    a_rdl[i] = x == 0 ? S::ZERO + (fq << 4) : rl * 128 + ((fq ^ (rl & 7)) << 4);
+    a_rdr[i] = x == Wimg - 1 ? S::ZERO + (fq << 4) : rr * 128 + ((fq ^ (rr & 7)) << 4);
+  }
+  bf16x8 xa[MI], wa[NI], xb[MI], wb[NI];
+  auto read_a = [&](int ab, int col, int ks, bf16x8 (&xf)[MI]) __attribute__((always_inline)) {
+    if (col == 1) {
+      const char* pa = smem + ab + (a_rd ^ (ks << 6));
+#pragma unroll
+      for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(pa + i * 2048);
+    } else {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        xf[i] = *reinterpret_cast<const bf16x8*>(smem + ab + ((col == 0 ? a_rdl[i] : a_rdr[i]) ^ (ks << 6)));
+    }
+  };
+  auto read_w = [&](int stage, int ks, bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
+    const char* pw = smem + S::W0 + stage * S::W_BYTES + (w_rd ^ (ks << 6));
+#pragma unroll
+    for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(pw + j * 2048);
+  };
+  f32x4 acc[MI][NI];
+  f32x4 tot[CHUNK ? MI : 1][CHUNK ? NI : 1];
+  int next_flush = 0x7fffffff;
+  auto mfmas = [&](const bf16x8 (&xf)[MI], const bf16x8 (&wf)[NI]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = MFMA_16x16x32_ST(wf[j], xf[i], acc[i][j], 0, 0, 0);
+  };
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (CHUNK) tot[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    if constexpr (CHUNK) next_flush = p.chunk_kt - 1;
+  };
+  auto flush = [&]() __attribute__((always_inline)) {
+    if constexpr (CHUNK) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          tot[i][j] += acc[i][j];
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  };
+
+  // row pieces of a 16-row pass: piece idx = lane + 64 q -> (row r, 16-byte chunk cc) of the wave's [16][BN/2] slab (computed where
+  // they are used: three more registers per piece would otherwise live through the K loop)
+  auto piece = [&](int q, int& r, int& c, bool& v) __attribute__((always_inline)) {
+    int idx = lane + 64 * q;
+    asm volatile("" : "+v"(idx));                           // (keeps the division out of the loop-invariant set)
+    r = idx / PCH;
+    c = idx - r * PCH;
+    v = idx < 16 * PCH;
+  };
+
+  if (tid < 64) reinterpret_cast<uint32_t*>(smem + S::ZERO + (tid >> 5) * AP)[tid & 31] = 0u;
+
+  tile_src(0, ok_c, am_c, wn_c);
+  tile_src(1, ok_n, am_n, wn_n);
+  // prologue, in the issue order of the steady state: act(0) | w(0) | w(1) | [act(1) first half, w(2)]
+  ASrc asrc;
+  a_prep(0, 0, asrc); a_fire(0, 0, asrc);
+  a_prep(0, 1, asrc); a_fire(0, 1, asrc);
+  w_fire(0, w_soff(0) + wn_c);
+  w_fire(1, w_soff(1) + wn_c);
+  a_prep(1, 0, asrc); a_fire(1, 0, asrc);
+  w_fire(2, w_soff(2) + wn_c);
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (2 * W_CH + 2)) : "memory");
+  read_a(0, 0, 0, xa);
+  read_w(0, 0, wa);
+
+  f32x4 biasv[NI];
+  u32x4 resid[RES ? ST : 1];
+  int wso = 0;
+  int gf = 0;                // flat tap-row index (its parity = the activation tile)
+
+  // bias of the lane's column quads and the residual rows of the four passes
+  auto epi_loads = [&](int m0, int n0) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn) {
+      const int n = n0 + wn * (BN / 2) + jn * 16 + fq * 4;
+      biasv[jn] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, n < p.N ? (unsigned)n * 4u : OOB, 0, 0));
+    }
+    if constexpr (RES) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        int pr, pc;
+        bool pv;
+        piece(q, pr, pc, pv);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int m = m0 + wm * 64 + ps * 16 + pr, n = n0 + wn * (BN / 2) + pc * 8;
+          const bool ok = pv && m < p.M && n < p.N;
+          resid[ps * NQ + q] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, ok ? (unsigned)m * ldr2 + (unsigned)n * 2u : OOB, 0, 0);
+        }
+      }
+    }
+#else
+    (void)m0; (void)n0;
+#endif
+  };
+  // one K-tile = tap column col of tap row g of the current tile.  loose: the first two K-tiles of a tile that follows another one
+  // (their waits tolerate the previous epilogue's stores).  LAST: K-tile (G-1, 2) -- no activation DMA (deferred behind the epilogue:
+  // its target is the scratch), no fragment reads of the next K-tile (their registers hold the residual rows instead).
+  auto ktile = [&](auto col_c, auto last_c, int g, bool loose, int m0, int n0) __attribute__((always_inline)) {
+    constexpr int col = decltype(col_c)::value;
+    constexpr bool LAST = decltype(last_c)::value;
+    const int j = g * 3 + col;
+    const int ab = (gf & 1) * AP;
+    read_a(ab, col, 1, xb);
+    read_w(col, 1, wb);
+    __builtin_amdgcn_s_setprio(1);
+    {
+      // sources of this K-tile's DMA slot: this tile's, or the next tile's once the target runs past the last tap row
+      if (col != 1 && !LAST) a_prep(g + (col == 2 ? 2 : 1), col == 2 ? 0 : 1, asrc);
+      const bool nxt = g + 1 >= G;
+      wso = w_soff(nxt ? col : j + 3) + (nxt ? wn_n : wn_c);
+    }
+    mfmas(xa, wa);
+#pragma unroll
+    for (int r = 0; r < MI * NI / 2; ++r) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);      // offsets of this K-tile's DMA slot
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (col == 2) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : W_CH) : "memory");
+    } else if (loose) {
+      if (col == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (ST + 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (ST + 2 + W_CH + 2)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (W_CH + 2)) : "memory");
+    }
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (!LAST) {
+      if (col < 2) {
+        read_a(ab, col + 1, 0, xa);
+        read_w(col + 1, 0, wa);
+      } else {
+        read_a(ab ^ AP, 0, 0, xa);
+        read_w(0, 0, wa);
+      }
+      if (col != 1) a_fire(col == 2 ? (gf & 1) : ((gf + 1) & 1), col == 2 ? 0 : 1, asrc);
+      w_fire(col, wso);
+      mfmas(xb, wb);
+      constexpr int GRD = (MI + NI + 1) / 2;                  // MFMA pairs that carry 2 fragment reads each
+#pragma unroll
+      for (int r = 0; r < MI * NI / 2; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // 2 MFMA
+        if (r < GRD) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 ds_read
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);  // M0 + scalar offset
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 LDS-DMA
+        }
+      }
+    } else {
+      w_fire(2, wso);
+      // without the chunk fold: bias and residual rows in flight under the last MFMA group (the fragment registers of the next K-tile
+      // are free); with it the second accumulator set leaves no room before the fold, they are requested right behind it
+      if constexpr (!CHUNK) epi_loads(m0, n0);
+      mfmas(xb, wb);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (CHUNK) {
+      if (j == next_flush && j + 1 < kt_total) { flush(); next_flush += p.chunk_kt; }
+    }
+  };
+  auto add2 = [](uint32_t a, uint32_t b) __attribute__((always_inline)) {
+    return pack_bf16x2(bf16_to_f32((bf16_t)(a & 0xffff)) + bf16_to_f32((bf16_t)(b & 0xffff)),
+                       bf16_to_f32((bf16_t)(a >> 16)) + bf16_to_f32((bf16_t)(b >> 16)));
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  using C2 = std::integral_constant<int, 2>;
+  using TC = std::true_type;
+  using FC = std::false_type;
+
+  for (int t = 0; t < T; ++t) {
+    int m0, n0;
+    tile_mn(t, m0, n0);
+    zero_acc();
+    {                                   // first tap row: behind another tile its first two waits have the epilogue's stores in the queue
+      const bool loose = t > 0;
+      ktile(C0{}, FC{}, 0, loose, m0, n0);
+      ktile(C1{}, FC{}, 0, loose, m0, n0);
+      ktile(C2{}, FC{}, 0, false, m0, n0);
+      ++gf;
+    }
+    for (int g = 1; g < G - 1; ++g, ++gf) {
+      ktile(C0{}, FC{}, g, false, m0, n0);
+      ktile(C1{}, FC{}, g, false, m0, n0);
+      ktile(C2{}, FC{}, g, false, m0, n0);
+    }
+    ktile(C0{}, FC{}, G - 1, false, m0, n0);
+    ktile(C1{}, FC{}, G - 1, false, m0, n0);
+    ktile(C2{}, TC{}, G - 1, false, m0, n0);
+    if constexpr (CHUNK) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn) acc[i][jn] = tot[i][jn] + acc[i][jn];
+      epi_loads(m0, n0);
+    }
+    // ---- epilogue.  The activation tile of the last tap row (parity of gf) is dead everywhere since the last mid-tile barrier: the
+    // wave's scratch = its own 4 KB of it.  The other activation tile holds the next tile's tap row 0, weight stages 0 / 1 / 2 its
+    // K-tiles 0 (landed, visible) / 1 / 2 (in flight or landed).
+    char* scr = smem + (gf & 1) * AP + wave * 4096;
+    int pr[NQ], pc[NQ];
+    bool pv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) piece(q, pr[q], pc[q], pv[q]);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+#pragma unroll
+      for (int jn = 0; jn < NI; ++jn) {
+        const f32x4 v = acc[ps][jn] + biasv[jn];
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(scr + fr * S::SCR_STRIDE + (jn * 16 + fq * 4) * 2) = o;
+      }
+      u32x4 ov[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) ov[q] = *reinterpret_cast<const u32x4*>(scr + pr[q] * S::SCR_STRIDE + pc[q] * 16);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if constexpr (RES) {
+          const u32x4 rr = resid[ps * NQ + q];
+          ov[q][0] = add2(ov[q][0], rr[0]); ov[q][1] = add2(ov[q][1], rr[1]);
+          ov[q][2] = add2(ov[q][2], rr[2]); ov[q][3] = add2(ov[q][3], rr[3]);
+        }
+        const int m = m0 + wm * 64 + ps * 16 + pr[q], n = n0 + wn * (BN / 2) + pc[q] * 8;
+        const bool ok = pv[q] && m < p.M && n < p.N;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_buffer_store_b128(ov[q], rs_c, ok ? (unsigned)m * ldc2 + (unsigned)n * 2u : OOB, 0, 0);
+#else
+        (void)ok;
+#endif
+      }
+    }
+    // the deferred DMA: first half of the next tile's activation tile 1 into the scratch's tile, once my scratch reads have completed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    a_prep(G + 1, 0, asrc);
+    a_fire(gf & 1, 0, asrc);
+    ++gf;
+    read_a((gf & 1) * AP, 0, 0, xa);
+    read_w(0, 0, wa);
+    ok_c = ok_n; am_c = am_n; wn_c = wn_n;
+    tile_src(t + 2, ok_n, am_n, wn_n);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-fill requests past the end still target this block's LDS
+}
+
+template <int BN, bool CHUNK, bool UP, bool RES>
+int pconv_launch_impl(const GemmParams& p, int grid, hipStream_t st) {
+  constexpr int LDS = CS<BN>::TOTAL;
+  if (hedit_test_drained()) {
+    if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<BN, CHUNK, UP, RES, true>), LDS)) return rc;
+    hipLaunchKernelGGL((pconv_kernel<BN, CHUNK, UP, RES, true>), dim3(grid), dim3(NT), LDS, st, p);
+  } else {
+    if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<BN, CHUNK, UP, RES, false>), LDS)) return rc;
+    hipLaunchKernelGGL((pconv_kernel<BN, CHUNK, UP, RES, false>), dim3(grid), dim3(NT), LDS, st, p);
+  }
+  LAUNCH_CHECK();
+  return HEDIT_OK;
+}
+
+template <int BN, bool CHUNK>
+int pconv_launch_bn(const GemmParams& p, int grid, hipStream_t st) {
+  const bool up = p.mode == 3, res = p.residual != nullptr;
+  if constexpr (!CHUNK) {      // (pconv_supported: the upsampling gather with the chunk fold stays with igemm_kernel)
+    if (up) return res ? pconv_launch_impl<BN, CHUNK, true, true>(p, grid, st) : pconv_launch_impl<BN, CHUNK, true, false>(p, grid, st);
+  }
+  return res ? pconv_launch_impl<BN, CHUNK, false, true>(p, grid, st) : pconv_launch_impl<BN, CHUNK, false, false>(p, grid, st);
+}
+
+}  // namespace
+
+// Does the persistent kernel take this launch?  A choice by shape only -- it never changes a result (same K-tile order, same MFMA chain,
+// same chunk fold, same epilogue arithmetic as igemm_kernel's modes 4 / 5).  p as gemm_launch has prepared it; bn = the tile width
+// gemm_launch picked (the chunk fold exists for the 128-column tile only, as in launch_igemm).
+bool pconv_supported(const GemmParams& p, int splits, int bn) {
+  if (hedit_test_flags() & 8) return false;                 // tests: the one-shot kernel for the A/B comparison
+  if ((p.mode != 1 && p.mode != 3) || splits != 1 || p.geglu || p.partial || p.raw_f32 || p.gn_part || p.op_bf16) return false;
+  if (p.mode == 1 && !(p.Hout == p.Hin && p.Wout == p.Win && p.Win > 0 && 256 % p.Win == 0)) return false;
+  if (p.mode == 3 && !(p.Wout > 0 && 256 % p.Wout == 0 && p.Hout == 2 * p.Hin && p.Wout == 2 * p.Win)) return false;
+  const bool chunk = p.chunk_kt > 0 && p.chunk_kt < p.K / BK;
+  if (bn != 128 && !(bn == 160 && !chunk)) return false;
+  if (p.K / BK < 16) return false;                          // launch_igemm's `big`
+  if (p.N % 8 != 0 || p.ldc % 8 != 0 || (p.residual && p.ldr % 8 != 0)) return false;
+  if (p.N % bn != 0) return false;                          // the weight rows of a tile are addressed through a scalar offset: no ragged n-tile
+  if (p.mode == 3 && (chunk || p.Wout > 128)) return false; // upsampling gather: the tile's first output row must be even; with the chunk fold it spills
+  if ((double)p.M * p.ldc * 2.0 >= 2040.0 * 1048576.0 || (p.residual && (double)p.M * p.ldr * 2.0 >= 2040.0 * 1048576.0)) return false;
+  int cus = 256;
+  if (hedit_cu_count(&cus)) return false;
+  const long tiles = (long)cdiv(p.M, BM) * cdiv(p.N, bn);
+  return tiles >= 2L * cus;                                 // at least two tiles per block: something to carry the ring across
+}
+
+int pconv_launch(const GemmParams& p, int bn, hipStream_t st) {
+  int cus = 256;
+  if (int rc = hedit_cu_count(&cus)) return rc;
+  const long tiles = (long)cdiv(p.M, BM) * cdiv(p.N, bn);
+  const int grid = (int)(tiles < cus ? tiles : cus);
+  const bool chunk = p.chunk_kt > 0 && p.chunk_kt < p.K / BK;
+  if (bn == 160) return pconv_launch_bn<160, false>(p, grid, st);
+  return chunk ? pconv_launch_bn<128, true>(p, grid, st) : pconv_launch_bn<128, false>(p, grid, st);
+}

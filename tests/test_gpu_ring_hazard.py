@@ -98,11 +98,22 @@ GEMM_CASES = [
     ("ring3 128 plain", 0, 8192 + 100, 1024, 1024, 0),               # ragged last row tile
     ("ring3 128 fold", 0, 65536, 2048, 1024, 2),
     ("ring3 160 plain  stride-2 conv", 2, (40, 64, 64), 320, 320, 0),
-    ("rowshare 160 plain  64x64 320->320", 1, (60, 64, 64), 320, 320, 0),
-    ("rowshare 128 fold   32x32 640->640", 1, (120, 32, 32), 640, 640, 2),
+    # row-sharing 3x3 loop, >= 2 tiles per CU: the persistent kernel (csrc/pconv.hip) -- weight ring and activation tiles run across
+    # tiles, the epilogue's loads / stores and the deferred activation DMA sit in the vmcnt queue; both column tiles, the chunk fold,
+    # with / without residual rows, tiles that span images + a ragged last tile, the upsampling gather
+    ("persist-conv 160 plain res   64x64 320->320", 1, (60, 64, 64), 320, 320, 0),
+    ("persist-conv 160 plain nores 64x64 320->320", 1, (60, 64, 64), 320, 320, 0, False),
+    ("persist-conv 128 fold  res   32x32 640->640", 1, (120, 32, 32), 640, 640, 2),
+    ("persist-conv 128 fold  nores 32x32 640->640", 1, (120, 32, 32), 640, 640, 2, False),
+    ("persist-conv 128 plain res   8x8 ragged", 1, (3301, 8, 8), 128, 128, 0),     # 825.25 row tiles, four images per tile
+    ("persist-conv-up 160 plain res   32->64 320", 3, (40, 32, 32), 320, 320, 0),
+    ("persist-conv-up 128 plain nores 16->32 128", 3, (160, 16, 16), 128, 128, 0, False),
+    # 200 <= tiles < 2 per CU: the one-shot row-sharing loop of igemm_kernel (modes 4 / 5)
+    ("rowshare 160 plain  64x64 320->320", 1, (12, 64, 64), 320, 320, 0),
+    ("rowshare 128 fold   32x32 640->640", 1, (24, 32, 32), 640, 640, 2),
     ("rowshare 128 plain  64x64 128->128", 1, (16, 64, 64), 128, 128, 0),
-    ("rowshare 128 plain  8x8 ragged", 1, (3301, 8, 8), 128, 128, 0),     # 825.25 row tiles
-    ("rowshare-up 160 plain 32->64 320", 3, (40, 32, 32), 320, 320, 0),
+    ("rowshare 128 plain  8x8 ragged", 1, (1301, 8, 8), 128, 128, 0),     # 325.25 row tiles
+    ("rowshare-up 160 plain 32->64 320", 3, (12, 32, 32), 320, 320, 0),
     ("rowshare-up 128 fold  16->32 640", 3, (120, 16, 16), 640, 640, 2),
     ("rowshare-up 128 plain 32->64 128", 3, (16, 32, 32), 128, 128, 0),
     # launches with at most one 128-row block per CU: the three-stage ring of the 128-row tile (Smem DEEP); negative chunks =

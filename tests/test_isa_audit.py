@@ -72,7 +72,7 @@ def isa(request):
         assert r.returncode == 0, r.stderr[-2000:]
         return unit, _stats(out)
     with ThreadPoolExecutor(4) as ex:
-        return dict(ex.map(cc, ["gemm", "pgemm", "ffn", "attn", "linchain"]))
+        return dict(ex.map(cc, ["gemm", "pgemm", "pconv", "ffn", "attn", "linchain"]))
 
 
 def _igemm(isa):
@@ -210,3 +210,36 @@ def test_pgemm_ring_counts_every_vector_memory_instruction(isa):
         want = [0, 0, 0, 0] if drain else [ndma, stn + ndma, ndma, ndma]
         assert st["ring_waits"] == want, ((bn, res, drain), st["ring_waits"], want)
         assert ks[(bn, res, 1 - drain)]["dma"] == st["dma"]
+
+
+def test_pconv_ring_counts_every_vector_memory_instruction(isa):
+    """csrc/pconv.hip (persistent row-sharing 3x3 loop): the weight ring and the two activation tiles run across tiles with the epilogue's
+    loads and stores in the vmcnt queue.  Per kernel the object code must contain exactly: the LDS-DMAs of the prologue (act(0) 4 |
+    3 weight K-tiles | first half of act(1)), of the three K-tile bodies of the first tap row, of the middle-row loop, of the last tap row
+    (whose last K-tile issues weights only) and the deferred half tile behind the epilogue = 18 + 12 W_CH; NI bias loads (+ ST residual
+    loads); ST stores; and in front of the ring barriers the waits vmcnt(2 W + 2) (prologue), 3 x vmcnt(W) (tap column 2), 6 x vmcnt(W + 2)
+    (tap columns 0 / 1) plus the two loose waits of a later tile's first tap row, vmcnt(ST + 2) and vmcnt(ST + W + 4) -- all vmcnt(0) in
+    the drained twin, which must issue the same instructions."""
+    from collections import Counter
+    ks = {}
+    for name, st in isa["pconv"].items():
+        m = re.search(r"pconv_kernelILi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])E", name)
+        if m:
+            ks[tuple(int(v) for v in m.groups())] = st          # (BN, CHUNK, UP, RES, DRAIN)
+    assert len(ks) == 20, sorted(ks)                            # 160: plain x {UP} x {RES}; 128: plain x {UP} x {RES} + fold x {RES}; twins
+    for (bn, chunk, up, res, drain), st in ks.items():
+        ni = bn // 32
+        w = (bn // 8 + 7) // 8
+        nq = (16 * (bn // 16) + 63) // 64
+        stn = 4 * nq
+        key = (bn, chunk, up, res, drain)
+        assert st["dma"] == 18 + 12 * w, (key, st)
+        assert st["loads"] == ni + (stn if res else 0), (key, st)
+        assert st["stores"] == stn, (key, st)
+        if drain:       # (the loose and the plain wait of a first-row K-tile are the same instruction here: the compiler may merge the two paths)
+            assert set(st["ring_waits"]) == {0} and 10 <= len(st["ring_waits"]) <= 12, (key, st["ring_waits"])
+        else:
+            want = Counter({2 * w + 2: 1, w: 3, w + 2: 6, stn + 2: 1, stn + w + 4: 1})
+            assert Counter(st["ring_waits"]) == want, (key, st["ring_waits"], want)
+        twin = ks[(bn, chunk, up, res, 1 - drain)]
+        assert twin["dma"] == st["dma"] and twin["loads"] == st["loads"] and twin["stores"] == st["stores"]
