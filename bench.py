@@ -449,8 +449,8 @@ def main():
                    "tflops_per_s": round(v[1] / 1e9 / v[0], 1) if v[0] > 0 and v[1] > 0 else None}
                for k, v in prof.items()}
     sampled_ms = sum(v[0] for v in prof.values())
-    roof = {"bound": "mfma", "kernel": {"conv3x3_gemm": "igemm_kernel<BN,conv> (3x3 conv as implicit GEMM)",
-                                        "linear_gemm": "linear class: igemm_kernel<BN,0> (linear / 1x1) + ffn_chain_kernel / lin_chain_kernel (the token-local chains of the C=320 level, one kernel each)",
+    roof = {"bound": "mfma", "kernel": {"conv3x3_gemm": "3x3 conv as implicit GEMM: pconv_kernel<BN> (persistent row-sharing loop) + igemm_kernel<BN,conv>",
+                                        "linear_gemm": "linear class: igemm_kernel<BN,0> / pgemm_kernel<BN> (linear / 1x1) + ffn_chain_kernel / lin_chain_kernel (the token-local chains of the C=320 level, one kernel each)",
                                         "self_attn": "self_attn_kernel<D>", "cross_attn": "cross_attn_kernel<D>",
                                         "norm": "gn_*/layernorm kernels", "other": "geglu/concat"}[dk],
             "achieved": round(dfl / 1e9 / dms, 2) if dms > 0 else None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -31,6 +31,9 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // (not HIP's uint4 struct, which SROA handles badly)
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#ifndef SA_BURST
+#define SA_BURST 0          // measurement builds only (tools/build_variant.sh ... attn "-DSA_BURST=n"): bit 0 phases, bit 1 + priority
+#endif
 
 template <int D>
 struct HeadCfg {
@@ -478,6 +481,9 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[JN][r] = 0.f;
     }
+#if SA_BURST
+    if (SA_BURST & 2) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int sl = 0; sl < NM; ++sl) {
       const int qk_before = (sl * DK) / NM, qk_after = ((sl + 1) * DK) / NM;
@@ -495,9 +501,20 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
         // V^T fragments of unit U (kept for the pair when QG == 2) once the last P.V is issued
         if (i == NPVS - 1 && (QG == 1 || (JJ & 1) == 0)) read_vf(st_cur, SUB);
       }
+#if !SA_BURST
 #pragma unroll
       for (int c = (sl * 8) / NM; c < ((sl + 1) * 8) / NM; ++c) valu_piece(c);
+#endif
     }
+#if SA_BURST
+    // measurement build: the block's MFMAs as one burst, then its VALU work as one phase (two waves of a SIMD can then run in
+    // anti-phase: one bursting on the matrix pipe, the other on the VALU port)
+    if (SA_BURST & 2) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) valu_piece(c);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (NS == 1 && (QG == 1 || (JJ & 1) == 0)) read_vf(st_cur, SUB);
     if (!ONES) l_run[A] += ls;
     if constexpr (PV16) {

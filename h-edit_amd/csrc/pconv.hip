@@ -94,6 +94,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
 
   const int Wimg = UP ? p.Wout : p.Win;                     // a power of two (divides 256)
   const int wshift = 31 - __builtin_clz((unsigned)Wimg);
+  const bool hpow2 = (p.Hout & (p.Hout - 1)) == 0;
   const unsigned ldc2 = (unsigned)p.ldc * 2u, ldr2 = (unsigned)p.ldr * 2u;
   const unsigned K2 = (unsigned)p.K * 2u;
   const unsigned dchunk = (unsigned)(((lane & 7) ^ (lane >> 3)) * 16);
@@ -147,8 +148,8 @@ __global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
     for (int i = 0; i < A_CH; ++i) {
       const int m = m0 + (wave * A_CH + i) * 8 + (lane >> 3);
       const unsigned rowi = (unsigned)m >> wshift;          // image row index over the batch: b * Hout + oy
-      const int b = (int)(rowi / (unsigned)p.Hout);
-      const int oy = (int)rowi - b * p.Hout;
+      // (a power-of-two height -- every level of the SD UNet -- costs one AND; the general case four unsigned divisions per tile)
+      const int oy = hpow2 ? (int)(rowi & (unsigned)(p.Hout - 1)) : (int)(rowi % (unsigned)p.Hout);
       const bool ok = live && m < p.M;
       unsigned mk = ok ? 2u : 0u;                           // tap row 1: the pixel's own row
       if (ok && oy > 0) mk |= 1u;

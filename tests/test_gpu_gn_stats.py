@@ -163,9 +163,10 @@ def test_conv_gn_rejects_shapes_without_the_128_column_tile(lib):
 
 
 def test_celeba_unet_on_producer_statistics():
-    """CelebA-HQ 256 configuration with every eligible GroupNorm on producer-side statistics (hedit_test_set_flags bit 2 flips
-    the build's default): oracle parity as tests/test_gpu_face.py asserts it for the other path, a row's eps a function of the
-    row alone bit for bit, and the two paths within a fraction of the bf16 error of each other."""
+    """CelebA-HQ 256 configuration on both GroupNorm paths -- the build's default (csrc/ddpm.hip DDPM_GN_FUSE_DEFAULT = true: every
+    eligible GroupNorm on the statistics its producing convolution wrote) and, with hedit_test_set_flags bit 2, the separate statistics
+    pass: on EACH path a row's eps is a function of the row alone bit for bit and repeatable; oracle parity as tests/test_gpu_face.py
+    asserts it; the two paths within a fraction of the bf16 error of each other."""
     from hedit.diffusion import Model
     from oracle import ddpm_unet
     lib = _lib.lib()
@@ -173,27 +174,29 @@ def test_celeba_unet_on_producer_statistics():
     sd = hip.init_random(1)
     x = hash_normal((3, 3, 256, 256), 5) * 0.8
     xg = x.to(G.dev())
-    base = hip(xg, 501.0)
-    G.sync()
-    try:
-        _lib.check(lib.hedit_test_set_flags(4))
-        a = hip(xg, 501.0)
-        b = hip(xg, 501.0)
-        a1 = hip(xg[:1], 501.0)
-        a2 = hip(xg[1:], 501.0)
-        G.sync()
-    finally:
-        lib.hedit_test_set_flags(0)
-    assert torch.isfinite(a).all() and torch.equal(a, b)
-    assert torch.equal(a1, a[:1]) and torch.equal(a2, a[1:])
-    assert not torch.equal(a, base)                       # the other path really ran
+    res = {}
+    for name, flags in (("producer statistics (default)", 0), ("statistics pass (flag 4)", 4)):
+        try:
+            _lib.check(lib.hedit_test_set_flags(flags))
+            a = hip(xg, 501.0)
+            b = hip(xg, 501.0)
+            a1 = hip(xg[:1], 501.0)
+            a2 = hip(xg[1:], 501.0)
+            G.sync()
+        finally:
+            lib.hedit_test_set_flags(0)
+        assert torch.isfinite(a).all() and torch.equal(a, b), name
+        assert torch.equal(a1, a[:1]) and torch.equal(a2, a[1:]), name
+        res[name] = a
+    (n0, r0), (n1, r1) = res.items()
+    assert not torch.equal(r0, r1)                        # the flag really selects another path
     # statistics that differ in their last fp32 bits flip bf16 roundings, and seventy layers amplify the flips to the
     # level of the bf16 noise itself: measured 8.3e-3 between the paths, each 1.2e-2 from the fp32 oracle
-    assert G.rel_err(a, base) < 1.5e-2
+    assert G.rel_err(r0, r1) < 1.5e-2
     om = ddpm_unet.Model(**ddpm_unet.CELEBA_HQ).eval()
     om.load_state_dict(sd)
     with torch.no_grad():
         want = om(x[:1], torch.ones(1) * 501.0)
-    ea, eb = G.rel_err(a[:1], want), G.rel_err(base[:1], want)
-    print(f"eps vs oracle: producer statistics {ea:.3e}, statistics pass {eb:.3e}; between the paths {G.rel_err(a, base):.3e}")
-    assert ea < 2.5e-2 and eb < 2.5e-2
+    e0, e1 = G.rel_err(r0[:1], want), G.rel_err(r1[:1], want)
+    print(f"eps vs oracle: {n0} {e0:.3e}, {n1} {e1:.3e}; between the paths {G.rel_err(r0, r1):.3e}")
+    assert e0 < 2.5e-2 and e1 < 2.5e-2

@@ -19,6 +19,8 @@ from csrc_hash import csrc_hash  # noqa: E402
 def klass(name):
     if "pgemm_kernel" in name:          # the persistent linear kernel (csrc/pgemm.hip)
         return "linear_gemm"
+    if "pconv_kernel" in name:          # the persistent row-sharing 3x3 kernel (csrc/pconv.hip)
+        return "conv3x3_gemm"
     if "igemm_kernel" in name:
         args = [a.strip() for a in name.split("igemm_kernel<")[1].split(">")[0].split(",")]   # BM, BN, MODE
         return "linear_gemm" if args[2] == "0" else "conv3x3_gemm"
