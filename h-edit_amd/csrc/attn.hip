@@ -707,9 +707,14 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
 template <int D, int QG, int NS>
 int launch_self(const SelfAttnParams& p, hipStream_t st) {
   using C = SelfCfg<D, QG>;
-  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&self_attn_kernel<D, QG, NS>), C::TOTAL)) return rc;
+#ifdef SA_OCC1      // measurement build: one workgroup per CU (one wave per SIMD) through an LDS request two cannot share
+  constexpr int LDS = C::TOTAL > 84 * 1024 ? C::TOTAL : 84 * 1024;
+#else
+  constexpr int LDS = C::TOTAL;
+#endif
+  if (int rc = hedit_dyn_lds(reinterpret_cast<const void*>(&self_attn_kernel<D, QG, NS>), LDS)) return rc;
   dim3 grid(cdiv(p.N, 128 * QG) * p.heads * p.B);
-  hipLaunchKernelGGL((self_attn_kernel<D, QG, NS>), grid, dim3(256), C::TOTAL, st, p);
+  hipLaunchKernelGGL((self_attn_kernel<D, QG, NS>), grid, dim3(256), LDS, st, p);
   LAUNCH_CHECK();
   return HEDIT_OK;
 }
