@@ -22,12 +22,12 @@
 //     epilogue's loads and stores in the queue.  Issue order of a wave around a tile boundary (W = W_CH weight DMAs, 2 = one half of an
 //     activation tile, primes = next tile):
 //         slot (G-2, 2): act(0', half 0) 2 | w(G-1, 2) W          slot (G-1, 0): act(0', half 1) 2 | w(0', 0) W
-//         slot (G-1, 1): w(0', 1) W                               slot (G-1, 2): w(0', 2) W | bias NI | residual RL | stores ST | act(1', half 0) 2
+//         slot (G-1, 1): w(0', 1) W                               slot (G-1, 2): w(0', 2) W | residual RL | stores ST | bias(next tile) 1 | act(1', half 0) 2
 //         slot (0', 0):  act(1', half 1) 2 | w(1', 0) W           slot (0', 1):  w(1', 1) W          ...
 //     mid-tile wait of K-tile j = "everything K-tile j + 1 reads has landed" = all but the previous slot:
 //         col 2: vmcnt(W)    col 0 / 1: vmcnt(W + 2)    -- as in the one-shot loop, also for the last K-tile of a tile;
-//         first K-tile of a later tile (0', 0): what it needs (w(0', 1)) is OLDER than the bias loads the epilogue has consumed, so only the
-//         epilogue's stores and the deferred DMA may be outstanding: vmcnt(ST + 2); (0', 1) likewise needs w(0', 2): vmcnt(ST + 2 + W + 2).
+//         first K-tile of a later tile (0', 0): what it needs (w(0', 1)) is older than the epilogue's stores, so the stores, the bias DMA and the
+//         deferred half tile may be outstanding: vmcnt(ST + 1 + 2); (0', 1) likewise needs w(0', 2): vmcnt(ST + 1 + 2 + 2 + W).
 //         The stores are thereby never waited for before K-tile (0', 2), two K-tiles after they were issued.
 //     DRAIN twin (tests/test_gpu_ring_hazard.py): every one of these is vmcnt(0).
 // Not here (they keep igemm_kernel): split-K slabs / raw fp32 output, GroupNorm pair statistics, bfloat16-by-contract operands, rows
@@ -51,7 +51,9 @@ struct CS {
   static constexpr int W_BYTES = BN * BK * 2;
   static constexpr int W0 = 2 * AP;
   static constexpr int ZERO = W0 + 3 * W_BYTES;             // zero row of activation tile 0 (tile 1: + AP), as Smem<256, BN>::RS_ZERO
-  static constexpr int TOTAL = ZERO + AP + 128;
+  static constexpr int BIAS0 = ZERO + AP + 128;             // 8 wave-private slots of BN/2 floats: the tile's bias row halves
+  static constexpr int BIAS_SLOT = BN * 2;
+  static constexpr int TOTAL = BIAS0 + 8 * BIAS_SLOT;
   static constexpr int PCH = BN / 16;                       // 16-byte pieces per row of a wave's sub-tile
   static constexpr int NQ = (16 * PCH + 63) / 64;           // piece instructions per 16-row pass
   static constexpr int SCR_STRIDE = BN + 16;                // bytes: BN/2 elements + 16 (bank spread)
@@ -62,6 +64,7 @@ struct CS {
 template <int BN, bool CHUNK, bool UP, bool RES, bool DRAIN>
 __global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;      // for the epilogue's inline-asm LDS accesses
   using S = CS<BN>;
   constexpr int NI = BN / 32, MI = 4;
   constexpr int A_CH = 4;
@@ -223,6 +226,22 @@ __global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
 #endif
   };
 
+  // the wave's half of the bias row of the tile at column n0 -> its slot behind the ring, by ONE LDS-DMA (BN/8 lanes x 16 B; a lane past N
+  // requests out of range = 0): the epilogue then reads its bias with ds_read_b128 instead of waiting ~1 us for a global load with the
+  // matrix pipe idle (all eight waves reach the epilogue together).  Issued in the prologue for the first tile and right behind the
+  // previous epilogue's stores for every later one: older than every ring wait of the tile that uses it.
+  auto bias_fire = [&](int n0, bool live) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (lane < BN / 8) {
+      const int n = n0 + wn * (BN / 2) + lane * 4;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(smem + S::BIAS0 + wave * S::BIAS_SLOT), 16,
+                                               (live && n < p.N) ? (unsigned)n * 4u : OOB, 0, 0, 0);
+    }
+#else
+    (void)n0; (void)live;
+#endif
+  };
+
   // ---- fragment reads (igemm_kernel's addressing; the side taps read LDS row -1 / +1 of the staged tile, or the zero row at the image
   // edge -- with Wimg | 256 and m0 % 256 == 0 these offsets do not depend on the tile)
   const int rd_x = ((fq ^ (fr & 7)) << 4);
@@ -301,6 +320,11 @@ __global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
   tile_src(1, ok_n, am_n, wn_n);
   // prologue, in the issue order of the steady state: act(0) | w(0) | w(1) | [act(1) first half, w(2)]
   ASrc asrc;
+  {
+    int m0f, n0f;
+    tile_mn(0, m0f, n0f);
+    bias_fire(n0f, true);
+  }
   a_prep(0, 0, asrc); a_fire(0, 0, asrc);
   a_prep(0, 1, asrc); a_fire(0, 1, asrc);
   w_fire(0, w_soff(0) + wn_c);
@@ -316,14 +340,9 @@ __global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
   int wso = 0;
   int gf = 0;                // flat tap-row index (its parity = the activation tile)
 
-  // bias of the lane's column quads and the residual rows of the four passes
+  // the residual rows of the four passes
   auto epi_loads = [&](int m0, int n0) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-    for (int jn = 0; jn < NI; ++jn) {
-      const int n = n0 + wn * (BN / 2) + jn * 16 + fq * 4;
-      biasv[jn] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, n < p.N ? (unsigned)n * 4u : OOB, 0, 0));
-    }
     if constexpr (RES) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -369,8 +388,8 @@ __global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
     if (col == 2) {
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : W_CH) : "memory");
     } else if (loose) {
-      if (col == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (ST + 2)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (ST + 2 + W_CH + 2)) : "memory");
+      if (col == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (ST + 1 + 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (ST + 1 + 2 + W_CH + 2)) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (W_CH + 2)) : "memory");
     }
@@ -399,8 +418,8 @@ __global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
       }
     } else {
       w_fire(2, wso);
-      // without the chunk fold: bias and residual rows in flight under the last MFMA group (the fragment registers of the next K-tile
-      // are free); with it the second accumulator set leaves no room before the fold, they are requested right behind it
+      // without the chunk fold: the residual rows in flight under the last MFMA group (the fragment registers of the next K-tile are
+      // free); with it the second accumulator set leaves no room before the fold, they are requested right behind it
       if constexpr (!CHUNK) epi_loads(m0, n0);
       mfmas(xb, wb);
     }
@@ -448,11 +467,15 @@ __global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
     // ---- epilogue.  The activation tile of the last tap row (parity of gf) is dead everywhere since the last mid-tile barrier: the
     // wave's scratch = its own 4 KB of it.  The other activation tile holds the next tile's tap row 0, weight stages 0 / 1 / 2 its
     // K-tiles 0 (landed, visible) / 1 / 2 (in flight or landed).
-    char* scr = smem + (gf & 1) * AP + wave * 4096;
+    const int scr_off = (int)lds_base + (gf & 1) * AP + wave * 4096;      // LDS byte address of the wave's scratch
     int pr[NQ], pc[NQ];
     bool pv[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) piece(q, pr[q], pc[q], pv[q]);
+    // the bias of the lane's column quads, from the wave's slot
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn)
+      biasv[jn] = *reinterpret_cast<const f32x4*>(smem + S::BIAS0 + wave * S::BIAS_SLOT + (jn * 16 + fq * 4) * 4);
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
 #pragma unroll
@@ -461,11 +484,18 @@ __global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
         uint2 o;
         o.x = pack_bf16x2(v[0], v[1]);
         o.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(scr + fr * S::SCR_STRIDE + (jn * 16 + fq * 4) * 2) = o;
+        // (inline asm: a compiler-visible LDS write that may alias a pending LDS-DMA makes the compiler drain vmcnt(0) in front of it --
+        //  the scratch IS a DMA target; the wave's own program order is what makes it safe, see the header)
+        asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(scr_off + fr * S::SCR_STRIDE + (jn * 16 + fq * 4) * 2)),
+                     "v"(__builtin_bit_cast(unsigned long long, o))
+                     : "memory");
       }
       u32x4 ov[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) ov[q] = *reinterpret_cast<const u32x4*>(scr + pr[q] * S::SCR_STRIDE + pc[q] * 16);
+      for (int q = 0; q < NQ; ++q)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ov[q]) : "v"((unsigned)(scr_off + pr[q] * S::SCR_STRIDE + pc[q] * 16)) : "memory");
+      if constexpr (NQ == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ov[0]), "+v"(ov[1]), "+v"(ov[NQ - 1])::"memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ov[0]), "+v"(ov[NQ - 1])::"memory");
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if constexpr (RES) {
@@ -484,6 +514,11 @@ __global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
     }
     // the deferred DMA: first half of the next tile's activation tile 1 into the scratch's tile, once my scratch reads have completed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      int m0n, n0n;
+      tile_mn(t + 1, m0n, n0n);
+      bias_fire(n0n, t + 1 < T);
+    }
     a_prep(G + 1, 0, asrc);
     a_fire(gf & 1, 0, asrc);
     ++gf;

@@ -21,12 +21,17 @@
 //     alike: profiles/r04_vmcnt_order.txt).  Issue order per wave and tile, and the waits it implies:
 //         K-tile j (0 <= j < nk-1), second half : DMA(f+3)                              [NDMA instructions]
 //         K-tile nk-1, after its mid barrier    : bias loads [NI], residual loads [RL]
-//         epilogue                              : stores [ST], then the deferred DMA(f+3)
+//         epilogue                              : stores [ST], the NEXT tile's bias row [1 DMA, see below], then the deferred DMA(f+3)
 //       mid-tile wait of K-tile j >= 1 : the DMA of K-tile j+1 must have landed, younger than it is only the DMA of K-tile j+2
 //                                        -> vmcnt(NDMA)
 //       mid-tile wait of K-tile 0      : the DMA of K-tile 1 was issued in the previous tile's K-tile nk-2; younger are that tile's
 //                                        bias / residual loads (consumed, hence retired), its ST stores and the deferred DMA
-//                                        -> vmcnt(ST + NDMA)        (first tile: the prologue has already waited for K-tile 1)
+//                                        -> vmcnt(ST + 1 + NDMA)    (first tile: the prologue has already waited for K-tile 1)
+//   * the bias row of a tile does not come from global memory when the epilogue needs it (a ~1 us round trip with the matrix pipe idle:
+//     all eight waves reach the epilogue together): each wave copies its half row (BN/2 floats) by ONE LDS-DMA into a slot of its own
+//     behind the ring -- for the first tile in the prologue, for every later tile right behind the previous epilogue's stores -- and the
+//     epilogue reads it with ds_read_b128.  (The residual rows are requested under the last MFMA group and consumed after the first
+//     pass's staging.)
 //     DRAIN twin (tests/test_gpu_ring_hazard.py): every one of these is vmcnt(0).
 // Not here (they keep igemm_kernel): the in-register chunk fold (two accumulator sets leave no room for the residual rows), split-K,
 // GEGLU, conv modes, rows that are not 16-byte aligned.
@@ -55,7 +60,9 @@ struct PS {
   static constexpr int A_BYTES = BM * BK * 2;
   static constexpr int W_BYTES = BN * BK * 2;
   static constexpr int STAGE = A_BYTES + W_BYTES;
-  static constexpr int TOTAL = 3 * STAGE;
+  static constexpr int BIAS0 = 3 * STAGE;                   // 8 wave-private slots of BN/2 floats: the tile's bias row halves
+  static constexpr int BIAS_SLOT = BN * 2;
+  static constexpr int TOTAL = BIAS0 + 8 * BIAS_SLOT;
   static constexpr int PCH = BN / 16;                       // 16-byte pieces per row of a wave's sub-tile
   static constexpr int NQ = (16 * PCH + 63) / 64;           // piece instructions per 16-row pass
   static constexpr int SCR_STRIDE = BN + 16;                // bytes: BN/2 elements + 16 (bank spread, see the header)
@@ -66,6 +73,7 @@ struct PS {
 template <int BN, bool RES, bool DRAIN>
 __global__ __launch_bounds__(NT, 2) void pgemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;      // for the epilogue's inline-asm LDS accesses
   using S = PS<BN>;
   constexpr int NI = BN / 32, MI = 4;
   constexpr int A_CH = 4;
@@ -154,6 +162,19 @@ __global__ __launch_bounds__(NT, 2) void pgemm_kernel(GemmParams p) {
 #endif
   };
 
+  // the wave's half of the bias row of the tile at column n0 -> its slot (BN/8 lanes x 16 B; a lane past N requests out of range = 0)
+  auto bias_fire = [&](int n0, bool live) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (lane < BN / 8) {
+      const int n = n0 + wn * (BN / 2) + lane * 4;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(smem + S::BIAS0 + wave * S::BIAS_SLOT), 16,
+                                               (live && n < p.N) ? (unsigned)n * 4u : OOB, 0, 0, 0);
+    }
+#else
+    (void)n0; (void)live;
+#endif
+  };
+
   // fragment reads (igemm_kernel's addressing)
   const int rd_x = ((fq ^ (fr & 7)) << 4);
   const int a_rd = (wm * 64 + fr) * 128 + rd_x;
@@ -196,6 +217,11 @@ __global__ __launch_bounds__(NT, 2) void pgemm_kernel(GemmParams p) {
   tile_offsets(0, ao_c, wo_c);
   tile_offsets(1, ao_n, wo_n);
   // prologue: K-tiles 0, 1, 2 of the first tile; K-tiles 0 and 1 are waited for (see the header: K-tile 0's mid wait then holds trivially)
+  {
+    int m0f, n0f;
+    tile_mn(0, m0f, n0f);
+    bias_fire(n0f, true);
+  }
   fire(0, ao_c, wo_c, 0);
   fire(1, ao_c, wo_c, 128);
   fire(2, ao_c, wo_c, 256);
@@ -232,7 +258,7 @@ __global__ __launch_bounds__(NT, 2) void pgemm_kernel(GemmParams p) {
       __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);      // selects
     }
     __builtin_amdgcn_s_setprio(0);
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (FIRST ? ST + NDMA : NDMA)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : (FIRST ? ST + 1 + NDMA : NDMA)) : "memory");
     __builtin_amdgcn_s_setprio(1);
     if constexpr (!LAST) {
       read_frags(nx, 0, xa, wa);
@@ -250,12 +276,7 @@ __global__ __launch_bounds__(NT, 2) void pgemm_kernel(GemmParams p) {
       }
     } else {
 #if defined(__HIP_DEVICE_COMPILE__)
-      // bias of the lane's column quads and the residual rows of the four passes: in flight under the last MFMA group
-#pragma unroll
-      for (int jn = 0; jn < NI; ++jn) {
-        const int n = n0 + wn * (BN / 2) + jn * 16 + fq * 4;
-        biasv[jn] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, n < p.N ? (unsigned)n * 4u : OOB, 0, 0));
-      }
+      // the residual rows of the four passes: in flight under the last MFMA group
       if constexpr (RES) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps)
@@ -289,7 +310,11 @@ __global__ __launch_bounds__(NT, 2) void pgemm_kernel(GemmParams p) {
     // ---- epilogue.  `cur` is the next tile's K-tile 0 (landed and visible: the last mid barrier), cur+1 its K-tile 1 (in flight or
     // landed), cur+2 = the stage the last K-tile used: dead everywhere, the wave's scratch = its own 4 KB of that stage's A area.
     const int sfree = cur == 0 ? 2 : cur - 1;
-    char* scr = smem + sfree * S::STAGE + wave * 4096;
+    const int scr_off = (int)lds_base + sfree * S::STAGE + wave * 4096;      // LDS byte address of the wave's scratch
+    // the bias of the lane's column quads, from the wave's slot (its DMA is older than every ring wait of this tile)
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn)
+      biasv[jn] = *reinterpret_cast<const f32x4*>(smem + S::BIAS0 + wave * S::BIAS_SLOT + (jn * 16 + fq * 4) * 4);
 #pragma unroll
     for (int ps = 0; ps < ((ABL & 8) ? 0 : 4); ++ps) {
 #pragma unroll
@@ -298,11 +323,18 @@ __global__ __launch_bounds__(NT, 2) void pgemm_kernel(GemmParams p) {
         uint2 o;
         o.x = pack_bf16x2(v[0], v[1]);
         o.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(scr + fr * S::SCR_STRIDE + (jn * 16 + fq * 4) * 2) = o;
+        // (inline asm: a compiler-visible LDS write that may alias a pending LDS-DMA makes the compiler drain vmcnt(0) in front of it --
+        //  the scratch IS a DMA target; the wave's own program order is what makes it safe, see the header)
+        asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(scr_off + fr * S::SCR_STRIDE + (jn * 16 + fq * 4) * 2)),
+                     "v"(__builtin_bit_cast(unsigned long long, o))
+                     : "memory");
       }
       u32x4 ov[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) ov[q] = *reinterpret_cast<const u32x4*>(scr + pr[q] * S::SCR_STRIDE + pc[q] * 16);
+      for (int q = 0; q < NQ; ++q)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ov[q]) : "v"((unsigned)(scr_off + pr[q] * S::SCR_STRIDE + pc[q] * 16)) : "memory");
+      if constexpr (NQ == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ov[0]), "+v"(ov[1]), "+v"(ov[NQ - 1])::"memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ov[0]), "+v"(ov[NQ - 1])::"memory");
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if constexpr (RES) {
@@ -321,6 +353,11 @@ __global__ __launch_bounds__(NT, 2) void pgemm_kernel(GemmParams p) {
     }
     // the deferred DMA: K-tile 2 of the next tile into the scratch's stage, once my scratch reads have completed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      int m0n, n0n;
+      tile_mn(t + 1, m0n, n0n);
+      bias_fire(n0n, t + 1 < T);
+    }
     fire(sfree, ao_n, wo_n, 256);
     read_frags(cur, 0, xa, wa);
 #pragma unroll
