@@ -183,7 +183,13 @@ __global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
     const bool nxt = gt >= G;
     const int g = nxt ? gt - G : gt;
     const int slab = g / 3, dyi = g - slab * 3;
-    const unsigned okm = nxt ? ok_n : ok_c;
+    unsigned okm = nxt ? ok_n : ok_c;
+    // (opaque to the optimiser: otherwise the nine (group, tap row) source offsets of a wave are hoisted out of the tile loop as
+    //  loop invariants, spilled, and their reloads -- vector-memory loads consumed at once -- drain the DMA queue with vmcnt(0) in the
+    //  first tap row of every tile)
+    asm volatile("" : "+v"(okm));
+    unsigned rowoff = (unsigned)(dyi * row_bytes);
+    asm volatile("" : "+s"(rowoff));
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int i = part * 2 + q;
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(NT, 2) void pconv_kernel(GemmParams p) {
         const int fy1 = ((int)((apar >> i) & 1u) + dyi + 1) >> 1;               // input row delta + 1, in {0, 1, 2}
         d.v[q] = ok ? al[UP ? i : 0] + (unsigned)(fy1 * row_bytes) : OOB;
       } else {
-        d.v[q] = ok ? al[0] + (unsigned)i * grp_step + (unsigned)(dyi * row_bytes) : OOB;
+        d.v[q] = ok ? al[0] + (unsigned)i * grp_step + rowoff : OOB;
       }
     }
     d.s = slab * BK * 2 + (nxt ? am_n : am_c);
