@@ -8,6 +8,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "h-edit_amd"))
 from hedit import _lib  # noqa: E402
+if os.environ.get("HEDIT_LIB_VARIANT"):       # tools/build_variant.sh side library (A/B of a kernel source on one box)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"lib_{os.environ['HEDIT_LIB_VARIANT']}.so.bin")
 from hedit.unet import SD15_CONFIG, UNet2DConditionModel  # noqa: E402
 
 
@@ -29,14 +31,17 @@ def main():
     out = unet(x, 481, **kw).sample
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    import time
     e0.record()
+    h0 = time.perf_counter()
     for _ in range(calls):
         out = unet(x, 481, **kw).sample
+    host_ms = (time.perf_counter() - h0) * 1e3 / calls           # host time to ENQUEUE one call (no sync inside): the launch-rate headroom
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / calls
     print(f"storage {_lib.STORAGE}{' flags ' + str(flags) if flags else ''}: {rows} rows, {ms:.2f} ms per UNet call = {rows * 803.2 / ms:.0f} TFLOP/s algorithmic, finite "
-          f"{bool(torch.isfinite(out).all())}", flush=True)
+          f"{bool(torch.isfinite(out).all())}; host enqueue {host_ms:.2f} ms per call", flush=True)
 
 
 if __name__ == "__main__":
