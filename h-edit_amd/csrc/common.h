@@ -47,7 +47,8 @@ int hedit_dyn_lds(const void* kernel, int bytes);      // HEDIT_OK, or HEDIT_ERR
 int hedit_cu_count(int* cus);                          // CUs of the CURRENT device
 // Test switch (hedit_test_set_flags in include/hedit.h; tests/test_gpu_ring_hazard.py): bit 0 = the kernels with counted
 // vmcnt rings (igemm, ffn_chain, self_attn) run their DRAINED twin -- every ring wait vmcnt(0) --, bit 1 = self-attention
-// takes the exact online-softmax pass only (no pinned-shift pass).  0 in every product path; never read on a device.
+// takes the exact online-softmax pass only (no pinned-shift pass), bit 2 = the pixel UNet's other GroupNorm-statistics path, bit 3 = the
+// one-shot igemm_kernel instead of the persistent kernels (pgemm.hip / pconv.hip).  0 in every product path; never read on a device.
 int hedit_test_flags();
 inline bool hedit_test_drained() { return (hedit_test_flags() & 1) != 0; }
 #define HEDIT_OK 0

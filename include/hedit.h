@@ -365,7 +365,10 @@ int hedit_storage_is_f16(void);
  *        denominator-check / redo logic.
  * bit 2: the pixel UNet (hedit_ddpm_forward) takes the OTHER of its two GroupNorm statistics paths (statistics pass over the
  *        tensor / pair statistics from the producing convolution's epilogue, csrc/gnstat.h): tests/test_gpu_gn_stats.py
- *        compares the two on one library. */
+ *        compares the two on one library.
+ * bit 3: gemm launches that would run a persistent kernel (csrc/pgemm.hip, csrc/pconv.hip) run the one-shot igemm_kernel of the
+ *        same tile instead -- the same bits by construction; tools/pgemm_ab.py / tools/pconv_ab.py compare them (torch.equal)
+ *        and time both on one box. */
 int hedit_test_set_flags(int flags);
 size_t hedit_k_groupnorm_ws_bytes(int B, int HW, int C);
 int hedit_k_groupnorm_affine(const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, void* ws,
