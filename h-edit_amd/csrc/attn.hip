@@ -231,7 +231,11 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void self_attn_kernel(SelfA
   // that block c of half hi is kv block 2 hi + c, one v_permlane16_swap per packed dword (block 0 of the g = 1 lanes
   // against block 1 of the g = 0 lanes) leaves "the block for queries 0..15" in the first and "the block for queries
   // 16..31" in the second register set of every lane.
+#ifdef SA_NO_PV16   // measurement build: P.V on 32 x 32 x 16 tiles again (4 MFMAs of 32 cycles, no permlane16_swap)
+  constexpr bool PV16 = false;
+#else
   constexpr bool PV16 = D == 40 && QG == 2 && NS == 2;
+#endif
   constexpr int DT16 = (D + 16) / 16;                   // 16-row tiles of O^T, the ones row included
   const int kv_perm = PV16 ? 16 * ((ql >> 2) & 1) + 8 * (ql >> 4) + 4 * ((ql >> 3) & 1) + (ql & 3)
                            : 16 * (ql >> 4) + 8 * ((ql >> 2) & 1) + 4 * ((ql >> 3) & 1) + (ql & 3);
